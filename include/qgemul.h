@@ -1,0 +1,227 @@
+/*
+ * qgemul.h — C-ABI boundary of the MI355X (gfx950) fixed-point GEMM engine.
+ *
+ * This is the drop-in boundary for ONE path of pikapuma/QuBLAS: the fixed-point matrix
+ * multiply `Qgemul<QgemulAddArgs<…>, QgemulMulArgs<…>, QgemulTransposedA<…>>(C, A, B)`
+ * (reference: readme.md:84-87 — the only place the function exists in the snapshot; its
+ * semantics are the composition of Qmul  include/QuBLAS.h:3980-3985 / :3146-3170,
+ * Qreduce include/QuBLAS.h:4960-4990 / :5014-5018 and the converting constructor :2398-2411).
+ *
+ * The reference resolves every quantisation decision at compile time from template tags.
+ * The host header (include/QuBLAS_amd.h, or the binding in include/qgemul_lower.hpp used with
+ * the reference's own header) evaluates the same merger rules at compile time and lowers the
+ * result to the plain-data descriptor below; nothing in this file is a template, nothing
+ * depends on PyTorch, and every pointer is a plain pointer.
+ *
+ * Conventions
+ *   - A format is (I, F, S, Q, O) = intBits, fracBits, isSigned, QuMode, OfMode
+ *     (reference tags include/QuBLAS.h:2346-2359).  W = I + F magnitude bits.  A raw integer r
+ *     stands for the real value r * 2^-F.  Storage always has a sign bit (QuBLAS.h:2384-2385).
+ *   - Host ("reference") layout of a tensor element: int32_t when 1+W <= 32, int64_t when
+ *     1+W <= 64, holding the sign-extended raw value (ArbiInt<N<=64>, QuBLAS.h:347-353).  A complex
+ *     element is the C struct { real; imag; } of those (QuBLAS.h:2512-2513).  Matrices are
+ *     column-major, element (i,j) at i + j*ld (QuBLAS.h:2680-2692).
+ *   - Mode codes are the reference's numeric values (QuBLAS.h:1986-1999, :2209-2225).
+ */
+#ifndef QGEMUL_H_
+#define QGEMUL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QGEMUL_ABI_VERSION 1u
+#define QG_MAX_LEVELS 40 /* tree levels = ceil(log2 K); 40 covers K up to 2^40 */
+
+/* QuMode codes — RND::* / TRN::* `value` members, QuBLAS.h:1986-1999 */
+enum {
+    QG_RND_POS_INF = 0,
+    QG_RND_NEG_INF = 1,
+    QG_RND_ZERO = 2,
+    QG_RND_INF = 3,
+    QG_RND_CONV = 4,
+    QG_TRN_TCPL = 5,
+    QG_TRN_SMGN = 6
+};
+
+/* OfMode codes — SAT::* / WRP::* `value` members, QuBLAS.h:2209-2225 */
+enum {
+    QG_SAT_TCPL = 0,
+    QG_SAT_ZERO = 1,
+    QG_SAT_SMGN = 2,
+    QG_WRP_TCPL = 3,
+    QG_WRP_TCPL_SAT = 4 /* a stub in the reference (QuBLAS.h:2336-2344): rejected, QG_EUNSUPPORTED */
+};
+
+/* complex multiply algorithm — BasicComplexMul QuBLAS.h:3426-3445, TFComplexMul :3510-3534 */
+enum { QG_CMUL_NONE = 0, QG_CMUL_BASIC = 1, QG_CMUL_TF = 2 };
+
+/* slots of qgemul_desc.mul[] */
+enum {
+    QG_MUL_REAL = 0, /* real GEMM: the product format (MulMerger result, QuBLAS.h:3107-3120) */
+    /* BasicComplexMul, x = a+bi, y = c+di (QuBLAS.h:3439-3440) */
+    QG_B_AC = 0, QG_B_BD = 1, QG_B_AD = 2, QG_B_BC = 3,
+    QG_B_RE = 4, /* Qsub<acbdT>(ac, bd) */
+    QG_B_IM = 5, /* Qadd<adbcT>(ad, bc) */
+    /* TFComplexMul (QuBLAS.h:3524-3529); the lowering has already applied the reference's two
+     * quirks: B is quantised with badT and C with cdbT (:3525-3526), and (b-a) always uses the
+     * default merge because baT is never honoured (:3515). */
+    QG_T_AB = 0,  /* Qadd(a, b) */
+    QG_T_CD = 1,  /* Qadd(c, d) */
+    QG_T_BA = 2,  /* Qsub(b, a) */
+    QG_T_A = 3,   /* Qmul(ab, c) */
+    QG_T_B = 4,   /* Qmul(cd, b) */
+    QG_T_C = 5,   /* Qmul(ba, d) */
+    QG_T_RE = 6,  /* Qsub(A, B) */
+    QG_T_IM = 7   /* Qsub(B, C) */
+};
+
+typedef struct qfmt {
+    int16_t I;  /* intBits  (may be negative) */
+    int16_t F;  /* fracBits (may be negative) */
+    uint8_t S;  /* isSigned */
+    uint8_t Q;  /* QuMode code */
+    uint8_t O;  /* OfMode code */
+    uint8_t pad;
+} qfmt;
+
+/*
+ * Fully-resolved description of one Qgemul call.  Every arithmetic node of the reference
+ * expression has its RESULT format written out; the dataflow between nodes is fixed:
+ *
+ *   p[k]   = product(A'[i,k], B[k,j])                  mul[] slots above
+ *   level l: next[t] = cvt_{level[l]}( add_{level_add[l]}(cur[2t], cur[2t+1]) ),
+ *            odd leftover next[last] = cvt_{level[l]}(cur[len-1])        (QuBLAS.h:4973-4980)
+ *   C[i,j] = cvt_{c}( root )                                            (QuBLAS.h:2398-2411)
+ *
+ * where op_{f}(x) means: align/compute exactly, round to f.F with f.Q (fracConvert,
+ * QuBLAS.h:2002-2204), then overflow-handle to (f.I, f.F, f.S) with f.O (intConvert, :2227-2334);
+ * and cvt_{f} is the identity when source and target formats are equal in all five fields.
+ * For a real GEMM level_add[l] == level[l] (Qadd<T_l> yields T_l directly).  For a complex GEMM
+ * the reference ignores a complex type passed as Qadd tag (QuBLAS.h:3549-3564 + :3097-3099), so
+ * level_add[l] is the default merge of the incoming format and level[l] is the level buffer's
+ * type (QuBLAS.h:4966).  Index [0] = real part, [1] = imaginary part.
+ */
+typedef struct qgemul_desc {
+    uint32_t abi;       /* QGEMUL_ABI_VERSION */
+    uint8_t transA;     /* QgemulTransposedA<true>: A is declared dim<K,M>, A'[i,k] = A[k,i] */
+    uint8_t is_complex; /* operands are Qcomplex */
+    uint8_t cmul;       /* QG_CMUL_* (QG_CMUL_NONE for real) */
+    uint8_t reserved;
+    int64_t M, N, K;    /* C is M x N, reduction length K (runtime values, never template depth) */
+    qfmt a[2], b[2], c[2];
+    qfmt mul[8];
+    uint32_t n_levels;  /* ceil(log2 K), 0 when K == 1 */
+    uint32_t reserved2;
+    qfmt level_add[2][QG_MAX_LEVELS];
+    qfmt level[2][QG_MAX_LEVELS];
+} qgemul_desc;
+
+/* leading dimensions of the host-layout operands, in elements; 0 = tight (rows of the declared dim) */
+typedef struct qgemul_opts {
+    int64_t lda, ldb, ldc;
+    int32_t device;        /* HIP device ordinal for qgemul_run; -1 = current */
+    uint32_t flags;        /* QG_OPT_* */
+} qgemul_opts;
+
+enum {
+    QG_OPT_FORCE_TREE = 1u,   /* run the exact tree kernel even when the linear class is provable */
+    QG_OPT_CHECK_RANGE = 2u   /* validate that A and B raw values lie inside their formats */
+};
+
+/* status codes */
+enum {
+    QG_OK = 0,
+    QG_EINVAL = -1,       /* malformed descriptor / null pointer / bad size */
+    QG_EUNSUPPORTED = -2, /* e.g. WRP::TCPL_SAT, an intermediate wider than 62 bits */
+    QG_EHIP = -3,         /* a HIP runtime call failed; qgemul_last_hip_error() has the code */
+    QG_ERCCL = -4,
+    QG_ERANGE = -5,       /* QG_OPT_CHECK_RANGE: an input raw value is outside its format */
+    QG_ENOGPU = -6        /* no gfx950 device visible: the engine has no CPU fallback */
+};
+
+/* exactness class of a descriptor */
+enum {
+    QG_CLASS_LINEAR = 1, /* every intermediate conversion is provably the identity: exact integer
+                            dot product + ONE round/overflow into C (MFMA / wide-int path) */
+    QG_CLASS_TREE = 2    /* products and tree nodes must be quantised one by one, in tree order */
+};
+
+typedef struct qgemul_info {
+    int32_t cls;            /* QG_CLASS_* */
+    int32_t supported;      /* 1 if the GPU engine can run it */
+    int32_t max_bits;       /* widest signed intermediate the expression can produce */
+    int32_t in_bits[2];     /* storage bits (1+W) of A and B elements (max over parts) */
+    int32_t limbs[2];       /* int8 limbs per A / B element on the MFMA path (0 = not MFMA) */
+    int32_t kernel;         /* QG_KERNEL_* chosen by the planner */
+    int32_t host_elem_bytes[3]; /* sizeof host element of A, B, C (complex: whole struct) */
+    int32_t host_imag_off[3];   /* byte offset of .imag inside a complex host element */
+    int64_t packed_bytes[3];    /* device-private packed sizes of A, B, C for this M,N,K */
+    double  ops;                /* 2*M*N*K for real; x3 (TF) or x4 (Basic) real MACs for complex */
+    char    reason[96];         /* why unsupported / why tree */
+} qgemul_info;
+
+enum {
+    QG_KERNEL_NONE = 0,
+    QG_KERNEL_MFMA_I8 = 1,      /* class L, operands <= 8 storage bits: v_mfma_i32_*_i8 */
+    QG_KERNEL_MFMA_I8_LIMB = 2, /* class L, wider operands split into int8 limbs */
+    QG_KERNEL_TREE_I32 = 3,     /* class T, all intermediates fit 32 bits */
+    QG_KERNEL_TREE_I64 = 4,     /* class T, 64-bit intermediates */
+    QG_KERNEL_TREE_CPLX = 5     /* class T, complex */
+};
+
+/* ---- descriptor analysis: pure host code, works without a GPU ---- */
+int qgemul_classify(const qgemul_desc* d, uint32_t opt_flags, qgemul_info* out);
+const char* qgemul_strerror(int status);
+uint32_t qgemul_abi_version(void);
+int qgemul_last_hip_error(void);
+
+/* ---- one-shot entry: what Qgemul<…>(C, A, B) calls.  Host pointers in reference layout;
+ *      C is fully overwritten; the call is synchronous (QuBLAS is synchronous, single-threaded). */
+int qgemul_run(const qgemul_desc* d, void* C, const void* A, const void* B, const qgemul_opts* o);
+
+/* ---- resident-data API (benchmarks, multi-GPU row shards, repeated calls) ---- */
+typedef struct qgemul_ctx qgemul_ctx;   /* one per host thread / device; owns streams + workspace */
+typedef struct qgemul_plan qgemul_plan; /* a descriptor bound to kernels and packed layouts */
+
+int qgemul_ctx_create(int device, qgemul_ctx** out);
+void qgemul_ctx_destroy(qgemul_ctx* c);
+int qgemul_ctx_sync(qgemul_ctx* c);
+void* qgemul_ctx_stream(qgemul_ctx* c); /* the hipStream_t the engine launches on */
+
+int qgemul_plan_create(qgemul_ctx* c, const qgemul_desc* d, uint32_t opt_flags, qgemul_plan** out);
+void qgemul_plan_destroy(qgemul_plan* p);
+int qgemul_plan_info(const qgemul_plan* p, qgemul_info* out);
+
+/* device memory owned by the caller, allocated through the engine (plain hipMalloc/hipFree) */
+int qgemul_dev_alloc(qgemul_ctx* c, size_t bytes, void** out);
+int qgemul_dev_free(qgemul_ctx* c, void* p);
+int qgemul_memcpy_h2d(qgemul_ctx* c, void* dst_dev, const void* src_host, size_t bytes);
+int qgemul_memcpy_d2h(qgemul_ctx* c, void* dst_host, const void* src_dev, size_t bytes);
+
+/* which operand */
+enum { QG_OPERAND_A = 0, QG_OPERAND_B = 1, QG_OPERAND_C = 2 };
+
+/* reference-layout (device-resident copy) -> packed.  `src_dev` is a device pointer to the same
+ * bytes the host tensor holds; ld in elements (0 = tight). */
+int qgemul_pack(qgemul_plan* p, int operand, const void* src_dev, int64_t ld, void* packed_dev);
+/* packed C -> reference layout (device-resident), ready for one D2H copy */
+int qgemul_unpack_c(qgemul_plan* p, const void* packed_dev, void* dst_dev, int64_t ld);
+/* the hot path: packed A, packed B -> packed C, asynchronous on the ctx stream */
+int qgemul_execute(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB);
+/* synthetic operand straight into packed form: raw values uniform over the format's full range
+ * (dist 0, what Qu::fill() does, QuBLAS.h:526-536) or |raw| < 2^(W/2) (dist 1), from
+ * splitmix64(seed ^ linear_index) — the same generator oracle/qoracle.c implements on the host. */
+int qgemul_fill_packed(qgemul_plan* p, int operand, uint64_t seed, int dist, void* packed_dev);
+/* time `iters` back-to-back qgemul_execute launches with HIP events on the ctx stream;
+ * returns average milliseconds per launch */
+int qgemul_time_execute(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB,
+                        int warmup, int iters, float* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QGEMUL_H_ */

@@ -1,0 +1,393 @@
+/*
+ * qoracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C, CPU-only restatement of the arithmetic that the reference header
+ * (/root/reference/include/QuBLAS.h, snapshot 2025-04-04) performs for a fixed-point GEMM
+ *     C[i,j] = cvt_C( Qreduce<AddArgs…>( { Qmul<MulArgs…>(A'[i,k], B[k,j]) }_k ) ).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's
+ * shared object; the engine (qublas_amd/csrc) never links or calls it and has no CPU fallback.
+ *
+ * Pinning: the functions below are checked bit-for-bit against
+ *   (a) the reference's own rounding tests  test/TRN/{TCPL,SMGN}.cpp, test/RND/{POSINF,NEGINF,
+ *       ZERO,INF,CONV}.cpp (40 known answers, tests/golden/ref_rounding_kat.json), and
+ *   (b) golden vectors produced in the build container by oracle/ref_driver.cpp, which includes
+ *       the real reference header and composes Qmul + Qreduce + converting assignment
+ *       (tests/golden/ref_*.json; generator oracle/gen_golden.py).
+ * `Qgemul` itself does not exist in the reference snapshot (only readme.md:84-87 mentions it),
+ * so the GEMM-level composition is "parity unpinned by reference tests" and pinned by (b) only.
+ *
+ * Every intermediate is held in __int128, so the restatement is exact for any expression whose
+ * intermediates stay below 2^120; wider expressions are rejected (the reference would use its
+ * multi-word ArbiInt<N>64> there, QuBLAS.h:566-912).
+ */
+#include "../include/qgemul.h"
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef __int128 qi;
+typedef unsigned __int128 qu;
+
+#define QO_MAX_SHIFT 100
+
+static inline qi qo_shl(qi x, int s) { return (qi)((qu)x << s); }
+static inline qi qo_pow2(int s) { return (qi)((qu)1 << s); }
+
+/* arithmetic shift right that also covers s >= width (staticShiftRight with N <= shift returns
+ * all-sign, QuBLAS.h:1597-1604) */
+static inline qi qo_sar(qi x, int s) { return s >= 127 ? (x < 0 ? -1 : 0) : (x >> s); }
+
+/*
+ * fracConvert<from,to,QuMode>::convert, QuBLAS.h:2002-2204.  d = from - to.
+ * d <= 0: exact left shift for every mode (:2011-2014, :2166 via the negative-shift overload
+ * :1689-1694, :2181-2184).
+ */
+static qi qo_round(qi x, int d, int mode)
+{
+    if (d <= 0) return qo_shl(x, -d);
+    qi h = qo_sar(x, d);                       /* Xh = staticShiftRight<d>(val) */
+    qi l = x & (qo_pow2(d) - 1);               /* Xl = val & allOnes<d> */
+    qi T = qo_pow2(d - 1);                     /* staticShiftLeft<d-1>(1) */
+    switch (mode) {
+    case QG_RND_POS_INF: return h + (l >= T);                                  /* :2026 */
+    case QG_RND_NEG_INF: return h + (l > T);                                   /* :2056 */
+    case QG_RND_ZERO:    return h + (l > T || (l == T && x < 0));              /* :2086 */
+    case QG_RND_INF:     return h + (l > T || (l == T && x > 0));              /* :2116 */
+    case QG_RND_CONV:    return h + (l > T || (l == T && (h & 1)));            /* :2137-2156 */
+    case QG_TRN_TCPL:    return h;                                             /* :2166 */
+    case QG_TRN_SMGN:    return x < 0 ? -qo_sar(-x, d) : h;                    /* :2189-2199 */
+    default:             return h;
+    }
+}
+
+/* intConvert<I,F,S,OfMode>::convert, QuBLAS.h:2227-2334 */
+static qi qo_overflow(qi x, qfmt f)
+{
+    int W = (int)f.I + (int)f.F;
+    qi maxv = qo_pow2(W) - 1;                  /* ArbiInt<1+W>::maximum() */
+    qi minv = f.S ? -qo_pow2(W) : 0;           /* minimum() or 0 */
+    switch (f.O) {
+    case QG_SAT_TCPL:                                                           /* :2239-2250 */
+        return x > maxv ? maxv : (x < minv ? minv : x);
+    case QG_SAT_ZERO:                                                           /* :2265-2276 */
+        return (x > maxv || x < minv) ? 0 : x;
+    case QG_SAT_SMGN: {                                                         /* :2286-2300 */
+        qi lo = f.S ? -maxv : 0;
+        return x > maxv ? maxv : (x < lo ? lo : x);
+    }
+    case QG_WRP_TCPL:                                                           /* :2308-2332 */
+        if (f.S) {
+            qi mask = qo_pow2(W + 1) - 1;
+            qi m = x & mask;
+            return (m >> W) ? (m | ~mask) : m;
+        }
+        return x & (qo_pow2(W) - 1);
+    default:
+        return x; /* WRP::TCPL_SAT: stub returning its input, :2336-2344 (callers reject it) */
+    }
+}
+
+static inline int qo_same(qfmt a, qfmt b)
+{
+    return a.I == b.I && a.F == b.F && a.S == b.S && a.Q == b.Q && a.O == b.O;
+}
+
+/* converting constructor Qu_s(const Qu_s<from>&), QuBLAS.h:2398-2411: identity when the five
+ * parameters agree, otherwise round with the TARGET's QuMode then overflow with its OfMode. */
+static qi qo_cvt(qi x, qfmt from, qfmt to)
+{
+    if (qo_same(from, to)) return x;
+    return qo_overflow(qo_round(x, (int)from.F - (int)to.F, to.Q), to);
+}
+
+/* Qmul_s::mul, QuBLAS.h:3152-3170: full product, fracConvert<Fa+Fb -> Fr>, intConvert */
+static qi qo_mul(qi a, qfmt fa, qi b, qfmt fb, qfmt r)
+{
+    return qo_overflow(qo_round(a * b, (int)fa.F + (int)fb.F - (int)r.F, r.Q), r);
+}
+
+/* Qadd_s::add / Qsub_s::sub, QuBLAS.h:3185-3203 / :3219-3234: align to max frac, add, convert */
+static qi qo_addsub(qi a, qfmt fa, qi b, qfmt fb, qfmt r, int sub)
+{
+    int fm = fa.F > fb.F ? fa.F : fb.F;
+    qi x = qo_shl(a, fm - fa.F), y = qo_shl(b, fm - fb.F);
+    qi s = sub ? x - y : x + y;
+    return qo_overflow(qo_round(s, fm - (int)r.F, r.Q), r);
+}
+
+/* format of the value entering the tree, per part */
+static qfmt qo_prod_fmt(const qgemul_desc* d, int part)
+{
+    if (!d->is_complex) return d->mul[QG_MUL_REAL];
+    if (d->cmul == QG_CMUL_TF) return d->mul[part ? QG_T_IM : QG_T_RE];
+    return d->mul[part ? QG_B_IM : QG_B_RE];
+}
+
+/* one (possibly complex) product: x = A'[i,k] = (a, b), y = B[k,j] = (c, dd) */
+static void qo_product(const qgemul_desc* d, const qi x[2], const qi y[2], qi out[2])
+{
+    const qfmt* m = d->mul;
+    if (!d->is_complex) {
+        out[0] = qo_mul(x[0], d->a[0], y[0], d->b[0], m[QG_MUL_REAL]);
+        out[1] = 0;
+        return;
+    }
+    qi a = x[0], b = x[1], c = y[0], dd = y[1];
+    qfmt fa = d->a[0], fb = d->a[1], fc = d->b[0], fd = d->b[1];
+    if (d->cmul == QG_CMUL_TF) { /* QuBLAS.h:3524-3529 */
+        qi ab = qo_addsub(a, fa, b, fb, m[QG_T_AB], 0);
+        qi cd = qo_addsub(c, fc, dd, fd, m[QG_T_CD], 0);
+        qi ba = qo_addsub(b, fb, a, fa, m[QG_T_BA], 1);
+        qi A = qo_mul(ab, m[QG_T_AB], c, fc, m[QG_T_A]);
+        qi B = qo_mul(cd, m[QG_T_CD], b, fb, m[QG_T_B]);
+        qi C = qo_mul(ba, m[QG_T_BA], dd, fd, m[QG_T_C]);
+        out[0] = qo_addsub(A, m[QG_T_A], B, m[QG_T_B], m[QG_T_RE], 1);
+        out[1] = qo_addsub(B, m[QG_T_B], C, m[QG_T_C], m[QG_T_IM], 1);
+    } else { /* BasicComplexMul, QuBLAS.h:3439-3440 */
+        qi ac = qo_mul(a, fa, c, fc, m[QG_B_AC]);
+        qi bd = qo_mul(b, fb, dd, fd, m[QG_B_BD]);
+        qi ad = qo_mul(a, fa, dd, fd, m[QG_B_AD]);
+        qi bc = qo_mul(b, fb, c, fc, m[QG_B_BC]);
+        out[0] = qo_addsub(ac, m[QG_B_AC], bd, m[QG_B_BD], m[QG_B_RE], 1);
+        out[1] = qo_addsub(ad, m[QG_B_AD], bc, m[QG_B_BC], m[QG_B_IM], 0);
+    }
+}
+
+/*
+ * Reducer::reduce_impl (vector overload), QuBLAS.h:4960-4984, one part of the value.
+ * buf holds len values in format `fin`; returns the root and writes its format to *fout.
+ * Level l: pairs are added into level_add[l] then stored into the level buffer of type level[l]
+ * (:4966, :4974); an odd leftover is copied with the converting constructor (:4977-4980);
+ * a length-1 input is returned unconverted (:4967-4970).
+ */
+static qi qo_tree(qi* buf, int64_t len, qfmt fin, const qfmt* level_add, const qfmt* level,
+                  qfmt* fout)
+{
+    int l = 0;
+    qfmt cur = fin;
+    while (len > 1) {
+        qfmt fa = level_add[l], fl = level[l];
+        int64_t half = len / 2;
+        for (int64_t t = 0; t < half; ++t)
+            buf[t] = qo_cvt(qo_addsub(buf[2 * t], cur, buf[2 * t + 1], cur, fa, 0), fa, fl);
+        if (len & 1) buf[half] = qo_cvt(buf[len - 1], cur, fl);
+        len = (len + 1) / 2;
+        cur = fl;
+        ++l;
+    }
+    *fout = cur;
+    return buf[0];
+}
+
+/* ---- host ("reference") element layout: ArbiInt<N<=32> is int32_t, <=64 int64_t
+ *      (QuBLAS.h:353); a complex element is struct { real; imag; } (:2512-2513) ---- */
+static int qo_sbytes(qfmt f) { return (1 + (int)f.I + (int)f.F) <= 32 ? 4 : 8; }
+
+typedef struct { int size, off[2], sb[2]; } qo_layout;
+
+static qo_layout qo_elem_layout(const qfmt f[2], int is_complex)
+{
+    qo_layout L;
+    L.sb[0] = qo_sbytes(f[0]);
+    L.off[0] = 0;
+    if (!is_complex) { L.sb[1] = 0; L.off[1] = 0; L.size = L.sb[0]; return L; }
+    L.sb[1] = qo_sbytes(f[1]);
+    int al = L.sb[0] > L.sb[1] ? L.sb[0] : L.sb[1];
+    L.off[1] = (L.sb[0] + L.sb[1] - 1) / L.sb[1] * L.sb[1];
+    L.size = (L.off[1] + L.sb[1] + al - 1) / al * al;
+    return L;
+}
+
+static inline qi qo_load(const char* p, int sb)
+{
+    if (sb == 4) { int32_t v; memcpy(&v, p, 4); return v; }
+    int64_t v; memcpy(&v, p, 8); return v;
+}
+static inline void qo_store(char* p, int sb, qi x)
+{
+    if (sb == 4) { int32_t v = (int32_t)x; memcpy(p, &v, 4); }
+    else { int64_t v = (int64_t)x; memcpy(p, &v, 8); }
+}
+
+int qoracle_elem_bytes(const qfmt* f2, int is_complex)
+{
+    return qo_elem_layout(f2, is_complex).size;
+}
+int qoracle_imag_offset(const qfmt* f2, int is_complex)
+{
+    return qo_elem_layout(f2, is_complex).off[1];
+}
+
+static int qo_check(const qgemul_desc* d)
+{
+    if (!d || d->abi != QGEMUL_ABI_VERSION) return QG_EINVAL;
+    if (d->M < 0 || d->N < 0 || d->K < 1) return QG_EINVAL;
+    int64_t len = d->K; uint32_t n = 0;
+    while (len > 1) { len = (len + 1) / 2; ++n; }
+    if (n != d->n_levels || n > QG_MAX_LEVELS) return QG_EINVAL;
+    return QG_OK;
+}
+
+typedef struct {
+    const qgemul_desc* d;
+    char* C; const char* A; const char* B;
+    int64_t lda, ldb, ldc;
+    int64_t row0, row1, col0, col1;
+    int tid, nthreads;
+    int status;
+} qo_job;
+
+static void* qo_worker(void* arg)
+{
+    qo_job* j = (qo_job*)arg;
+    const qgemul_desc* d = j->d;
+    const int parts = d->is_complex ? 2 : 1;
+    qo_layout LA = qo_elem_layout(d->a, d->is_complex);
+    qo_layout LB = qo_elem_layout(d->b, d->is_complex);
+    qo_layout LC = qo_elem_layout(d->c, d->is_complex);
+    const int64_t K = d->K;
+    qi* buf[2];
+    buf[0] = (qi*)malloc(sizeof(qi) * (size_t)K);
+    buf[1] = (qi*)malloc(sizeof(qi) * (size_t)K);
+    if (!buf[0] || !buf[1]) { j->status = QG_EINVAL; free(buf[0]); free(buf[1]); return 0; }
+    for (int64_t col = j->col0 + j->tid; col < j->col1; col += j->nthreads) {
+        for (int64_t row = j->row0; row < j->row1; ++row) {
+            for (int64_t k = 0; k < K; ++k) {
+                /* A'[i,k]: A is dim<M,K> (element i + k*lda) or, transposed, dim<K,M> (k + i*lda) */
+                int64_t ia = d->transA ? (k + row * j->lda) : (row + k * j->lda);
+                int64_t ib = k + col * j->ldb;
+                const char* pa = j->A + ia * LA.size;
+                const char* pb = j->B + ib * LB.size;
+                qi x[2] = {0, 0}, y[2] = {0, 0}, p[2];
+                for (int q = 0; q < parts; ++q) {
+                    x[q] = qo_load(pa + LA.off[q], LA.sb[q]);
+                    y[q] = qo_load(pb + LB.off[q], LB.sb[q]);
+                }
+                qo_product(d, x, y, p);
+                buf[0][k] = p[0];
+                buf[1][k] = p[1];
+            }
+            char* pc = j->C + (row + col * j->ldc) * LC.size;
+            for (int q = 0; q < parts; ++q) {
+                qfmt fr;
+                qi r = qo_tree(buf[q], K, qo_prod_fmt(d, q), d->level_add[q], d->level[q], &fr);
+                qo_store(pc + LC.off[q], LC.sb[q], qo_cvt(r, fr, d->c[q]));
+            }
+        }
+    }
+    free(buf[0]); free(buf[1]);
+    return 0;
+}
+
+/*
+ * The GEMM restatement.  Host pointers in reference layout, leading dimensions in elements
+ * (0 = tight).  Only the block rows [row0,row1) x cols [col0,col1) of C is computed and written
+ * (row1/col1 <= 0 mean "to the end"), so large configurations can be sampled.
+ */
+int qoracle_gemm(const qgemul_desc* d, void* C, const void* A, const void* B, int64_t lda,
+                 int64_t ldb, int64_t ldc, int64_t row0, int64_t row1, int64_t col0, int64_t col1,
+                 int nthreads)
+{
+    int st = qo_check(d);
+    if (st) return st;
+    if (!C || !A || !B) return QG_EINVAL;
+    if (row1 <= 0) row1 = d->M;
+    if (col1 <= 0) col1 = d->N;
+    if (row0 < 0 || row1 > d->M || col0 < 0 || col1 > d->N) return QG_EINVAL;
+    if (!lda) lda = d->transA ? d->K : d->M;
+    if (!ldb) ldb = d->K;
+    if (!ldc) ldc = d->M;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    qo_job jobs[256];
+    pthread_t th[256];
+    for (int t = 0; t < nthreads; ++t) {
+        jobs[t] = (qo_job){d, (char*)C, (const char*)A, (const char*)B, lda, ldb, ldc,
+                           row0, row1, col0, col1, t, nthreads, 0};
+        if (nthreads == 1) qo_worker(&jobs[t]);
+        else pthread_create(&th[t], 0, qo_worker, &jobs[t]);
+    }
+    for (int t = 0; t < nthreads; ++t) {
+        if (nthreads > 1) pthread_join(th[t], 0);
+        if (jobs[t].status) st = jobs[t].status;
+    }
+    return st;
+}
+
+/* ---- scalar entry points for the known-answer tests (values as int64 raw integers) ---- */
+int64_t qoracle_convert(int64_t x, qfmt from, qfmt to) { return (int64_t)qo_cvt(x, from, to); }
+/* source wider than 64 bits (the reference tests' 141-bit High_t): value = hi*2^64 + lo */
+int64_t qoracle_convert128(int64_t hi, uint64_t lo, qfmt from, qfmt to)
+{
+    qi x = (qi)(((qu)(uint64_t)hi << 64) | (qu)lo);
+    return (int64_t)qo_cvt(x, from, to);
+}
+int64_t qoracle_round(int64_t x, int d, int mode) { return (int64_t)qo_round(x, d, mode); }
+int64_t qoracle_overflow(int64_t x, qfmt f) { return (int64_t)qo_overflow(x, f); }
+int64_t qoracle_mul(int64_t a, qfmt fa, int64_t b, qfmt fb, qfmt r)
+{
+    return (int64_t)qo_mul(a, fa, b, fb, r);
+}
+int64_t qoracle_add(int64_t a, qfmt fa, int64_t b, qfmt fb, qfmt r, int sub)
+{
+    return (int64_t)qo_addsub(a, fa, b, fb, r, sub);
+}
+/* Qreduce over `len` real values of format fin with per-level formats (level_add == level) */
+int64_t qoracle_reduce(const int64_t* v, int64_t len, qfmt fin, const qfmt* level, int nlev)
+{
+    qi* buf = (qi*)malloc(sizeof(qi) * (size_t)(len > 0 ? len : 1));
+    qfmt lv[QG_MAX_LEVELS];
+    for (int l = 0; l < QG_MAX_LEVELS; ++l) lv[l] = nlev ? level[l < nlev ? l : nlev - 1] : fin;
+    for (int64_t t = 0; t < len; ++t) buf[t] = v[t];
+    qfmt fo;
+    qi r = qo_tree(buf, len, fin, lv, lv, &fo);
+    free(buf);
+    return (int64_t)r;
+}
+/* one complex product through the descriptor's mul[] slots */
+void qoracle_cproduct(const qgemul_desc* d, const int64_t x[2], const int64_t y[2], int64_t out[2])
+{
+    qi xx[2] = {x[0], x[1]}, yy[2] = {y[0], y[1]}, p[2];
+    qo_product(d, xx, yy, p);
+    out[0] = (int64_t)p[0];
+    out[1] = (int64_t)p[1];
+}
+
+/*
+ * Synthetic operands: raw value of host element e, part p is drawn from the
+ * counter-based generator below, so host and device produce identical tensors without sharing
+ * state.  dist 0: uniform over the whole representable range, as Qu::fill() does
+ * (QuBLAS.h:526-536); dist 1: |raw| < 2^(W/2) ("small", keeps narrow accumulators unsaturated).
+ */
+static inline uint64_t qo_rand(uint64_t seed, uint64_t idx)
+{
+    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+int64_t qoracle_synth(qfmt f, uint64_t seed, int dist, uint64_t elem, int part)
+{
+    int W = (int)f.I + (int)f.F;
+    int b = dist == 1 ? W / 2 : W;
+    int bits = b + (f.S ? 1 : 0);
+    if (bits <= 0) return 0;
+    uint64_t r = qo_rand(seed, elem * 2 + (uint64_t)part);
+    uint64_t v = bits >= 64 ? r : (r >> (64 - bits));
+    int64_t lo = f.S ? -((int64_t)1 << b) : 0;
+    return lo + (int64_t)v;
+}
+
+/* fill a tight host-layout tensor of n elements */
+void qoracle_fill(const qfmt* f2, int is_complex, uint64_t seed, int dist, int64_t n, void* out)
+{
+    qo_layout L = qo_elem_layout(f2, is_complex);
+    char* p = (char*)out;
+    for (int64_t e = 0; e < n; ++e, p += L.size) {
+        if (L.size > L.sb[0] + L.sb[1]) memset(p, 0, (size_t)L.size);
+        for (int q = 0; q < (is_complex ? 2 : 1); ++q)
+            qo_store(p + L.off[q], L.sb[q], qoracle_synth(f2[q], seed, dist, (uint64_t)e, q));
+    }
+}

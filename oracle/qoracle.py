@@ -1,0 +1,106 @@
+"""ctypes loader for oracle/liboracle.so — TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the
+engine package (qublas_amd) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from qublas_amd.desc import (Qcomplex, Qu, elem_parts, host_layout, qfmt,  # noqa: E402
+                             qgemul_desc)
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "qoracle.c")
+    hdr = os.path.join(_ROOT, "include", "qgemul.h")
+    stale = (not os.path.exists(so)) or any(
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(so) for p in (src, hdr))
+    if force or stale:
+        subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", "-o", so, src, "-lpthread"])
+    return so
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.qoracle_gemm.restype = C.c_int
+        L.qoracle_gemm.argtypes = [C.POINTER(qgemul_desc), C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                   C.c_int64, C.c_int64, C.c_int]
+        L.qoracle_convert.restype = C.c_int64
+        L.qoracle_convert.argtypes = [C.c_int64, qfmt, qfmt]
+        L.qoracle_round.restype = C.c_int64
+        L.qoracle_round.argtypes = [C.c_int64, C.c_int, C.c_int]
+        L.qoracle_overflow.restype = C.c_int64
+        L.qoracle_overflow.argtypes = [C.c_int64, qfmt]
+        L.qoracle_mul.restype = C.c_int64
+        L.qoracle_mul.argtypes = [C.c_int64, qfmt, C.c_int64, qfmt, qfmt]
+        L.qoracle_add.restype = C.c_int64
+        L.qoracle_add.argtypes = [C.c_int64, qfmt, C.c_int64, qfmt, qfmt, C.c_int]
+        L.qoracle_reduce.restype = C.c_int64
+        L.qoracle_reduce.argtypes = [C.POINTER(C.c_int64), C.c_int64, qfmt, C.POINTER(qfmt), C.c_int]
+        L.qoracle_convert128.restype = C.c_int64
+        L.qoracle_convert128.argtypes = [C.c_int64, C.c_uint64, qfmt, qfmt]
+        L.qoracle_synth.restype = C.c_int64
+        L.qoracle_synth.argtypes = [qfmt, C.c_uint64, C.c_int, C.c_uint64, C.c_int]
+        L.qoracle_fill.restype = None
+        L.qoracle_fill.argtypes = [C.POINTER(qfmt), C.c_int, C.c_uint64, C.c_int, C.c_int64, C.c_void_p]
+        L.qoracle_elem_bytes.restype = C.c_int
+        L.qoracle_elem_bytes.argtypes = [C.POINTER(qfmt), C.c_int]
+        L.qoracle_imag_offset.restype = C.c_int
+        L.qoracle_imag_offset.argtypes = [C.POINTER(qfmt), C.c_int]
+        _lib = L
+    return _lib
+
+
+def host_dtype(e) -> np.dtype:
+    """numpy dtype of one host-layout element (structured for complex)."""
+    size, off, (sr, si) = host_layout(e)
+    if not isinstance(e, Qcomplex):
+        return np.dtype("<i4" if sr == 4 else "<i8")
+    return np.dtype({"names": ["re", "im"], "formats": ["<i4" if sr == 4 else "<i8", "<i4" if si == 4 else "<i8"],
+                     "offsets": [0, off], "itemsize": size})
+
+
+def _f2(e):
+    r, i = elem_parts(e)
+    arr = (qfmt * 2)(r.c(), i.c())
+    return arr
+
+
+def fill(e, n: int, seed: int, dist: int = 0) -> np.ndarray:
+    """Synthetic tight host tensor of n elements (same generator as the engine's fill kernel)."""
+    out = np.zeros(n, dtype=host_dtype(e))
+    lib().qoracle_fill(_f2(e), int(isinstance(e, Qcomplex)), seed, dist, n, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def gemm(desc: qgemul_desc, A: np.ndarray, B: np.ndarray, c_elem, *, lda=0, ldb=0, ldc=0,
+         rows=(0, 0), cols=(0, 0), nthreads: int = 1, out: np.ndarray | None = None) -> np.ndarray:
+    """Run the CPU restatement.  A, B: contiguous host-layout arrays (column-major flattening)."""
+    M, N = desc.M, desc.N
+    ld = ldc or M
+    if out is None:
+        out = np.zeros(ld * N, dtype=host_dtype(c_elem))
+    A = np.ascontiguousarray(A)
+    B = np.ascontiguousarray(B)
+    st = lib().qoracle_gemm(C.byref(desc), out.ctypes.data_as(C.c_void_p), A.ctypes.data_as(C.c_void_p),
+                            B.ctypes.data_as(C.c_void_p), lda, ldb, ldc, rows[0], rows[1], cols[0], cols[1], nthreads)
+    if st != 0:
+        raise RuntimeError(f"qoracle_gemm failed: {st}")
+    return out

@@ -1,0 +1,205 @@
+// ref_cases_scalar.cpp — TEST INFRASTRUCTURE: scalar truth tables produced by the reference header
+// itself (converting constructor, Qmul, Qadd/Qsub, Qreduce), swept exhaustively over small source
+// formats.  The reference's own tests cover only 40 rounding cases (test/TRN, test/RND) and no
+// overflow mode, Qmul, Qadd or Qreduce at all, so these tables are what pins
+// oracle/qoracle.c for those primitives.
+#include "ref_driver.hpp"
+
+#include <cstdlib>
+
+using namespace refdrv;
+
+template <class From, class To>
+static void cvt_table(FILE* out, int64_t lo, int64_t hi, int64_t step = 1)
+{
+    std::fprintf(out, "{\"kind\":\"cvt\",\"from\":%s,\"to\":%s,\"lo\":%lld,\"hi\":%lld,\"step\":%lld,\"y\":[", fmt_json<From>().c_str(), fmt_json<To>().c_str(),
+                 (long long)lo, (long long)hi, (long long)step);
+    bool first = true;
+    for (int64_t x = lo; x <= hi; x += step) {
+        From f;
+        f.data.data = x;
+        To t = f;
+        std::fprintf(out, "%s%lld", first ? "" : ",", (long long)t.data.data);
+        first = false;
+    }
+    std::fprintf(out, "]}\n");
+}
+
+template <class From, class Q, class O>
+static void cvt_targets(FILE* out, int64_t lo, int64_t hi, int64_t step = 1)
+{
+    cvt_table<From, Qu<intBits<3>, fracBits<2>, isSigned<true>, QuMode<Q>, OfMode<O>>>(out, lo, hi, step);
+    cvt_table<From, Qu<intBits<3>, fracBits<2>, isSigned<false>, QuMode<Q>, OfMode<O>>>(out, lo, hi, step);
+    cvt_table<From, Qu<intBits<1>, fracBits<4>, isSigned<true>, QuMode<Q>, OfMode<O>>>(out, lo, hi, step);
+    cvt_table<From, Qu<intBits<5>, fracBits<0>, isSigned<true>, QuMode<Q>, OfMode<O>>>(out, lo, hi, step);
+    cvt_table<From, Qu<intBits<6>, fracBits<-2>, isSigned<true>, QuMode<Q>, OfMode<O>>>(out, lo, hi, step);
+    cvt_table<From, Qu<intBits<2>, fracBits<7>, isSigned<true>, QuMode<Q>, OfMode<O>>>(out, lo, hi, step);
+    cvt_table<From, Qu<intBits<0>, fracBits<3>, isSigned<false>, QuMode<Q>, OfMode<O>>>(out, lo, hi, step);
+}
+
+template <class From, class O>
+static void cvt_modes(FILE* out, int64_t lo, int64_t hi, int64_t step = 1)
+{
+    cvt_targets<From, RND::POS_INF, O>(out, lo, hi, step);
+    cvt_targets<From, RND::NEG_INF, O>(out, lo, hi, step);
+    cvt_targets<From, RND::ZERO, O>(out, lo, hi, step);
+    cvt_targets<From, RND::INF, O>(out, lo, hi, step);
+    cvt_targets<From, RND::CONV, O>(out, lo, hi, step);
+    cvt_targets<From, TRN::TCPL, O>(out, lo, hi, step);
+    cvt_targets<From, TRN::SMGN, O>(out, lo, hi, step);
+}
+
+template <class From>
+static void cvt_all(FILE* out, int64_t lo, int64_t hi, int64_t step = 1)
+{
+    cvt_modes<From, SAT::TCPL>(out, lo, hi, step);
+    cvt_modes<From, SAT::ZERO>(out, lo, hi, step);
+    cvt_modes<From, SAT::SMGN>(out, lo, hi, step);
+    cvt_modes<From, WRP::TCPL>(out, lo, hi, step);
+}
+
+// Qmul / Qadd / Qsub with a tag list: prints the RESOLVED result format and a product table
+template <class TA, class TB, class... Tags>
+static void mul_table(FILE* out, const char* tagname)
+{
+    using R = decltype(Qmul<Tags...>(std::declval<TA>(), std::declval<TB>()));
+    constexpr int Wa = TA::intB + TA::fracB, Wb = TB::intB + TB::fracB;
+    int64_t alo = TA::isS ? -(1ll << Wa) : 0, ahi = (1ll << Wa) - 1;
+    int64_t blo = TB::isS ? -(1ll << Wb) : 0, bhi = (1ll << Wb) - 1;
+    std::fprintf(out, "{\"kind\":\"mul\",\"tags\":\"%s\",\"fa\":%s,\"fb\":%s,\"fr\":%s,\"y\":[", tagname, fmt_json<TA>().c_str(), fmt_json<TB>().c_str(), fmt_json<R>().c_str());
+    bool first = true;
+    for (int64_t a = alo; a <= ahi; ++a)
+        for (int64_t b = blo; b <= bhi; ++b) {
+            TA x; TB y;
+            x.data.data = a; y.data.data = b;
+            auto r = Qmul<Tags...>(x, y);
+            std::fprintf(out, "%s%lld", first ? "" : ",", (long long)r.data.data);
+            first = false;
+        }
+    std::fprintf(out, "]}\n");
+}
+
+template <bool SUB, class TA, class TB, class... Tags>
+static void add_table(FILE* out, const char* tagname)
+{
+    using R = std::conditional_t<SUB, decltype(Qsub<Tags...>(std::declval<TA>(), std::declval<TB>())), decltype(Qadd<Tags...>(std::declval<TA>(), std::declval<TB>()))>;
+    constexpr int Wa = TA::intB + TA::fracB, Wb = TB::intB + TB::fracB;
+    int64_t alo = TA::isS ? -(1ll << Wa) : 0, ahi = (1ll << Wa) - 1;
+    int64_t blo = TB::isS ? -(1ll << Wb) : 0, bhi = (1ll << Wb) - 1;
+    std::fprintf(out, "{\"kind\":\"%s\",\"tags\":\"%s\",\"fa\":%s,\"fb\":%s,\"fr\":%s,\"y\":[", SUB ? "sub" : "add", tagname, fmt_json<TA>().c_str(), fmt_json<TB>().c_str(),
+                 fmt_json<R>().c_str());
+    bool first = true;
+    for (int64_t a = alo; a <= ahi; ++a)
+        for (int64_t b = blo; b <= bhi; ++b) {
+            TA x; TB y;
+            x.data.data = a; y.data.data = b;
+            int64_t r;
+            if constexpr (SUB) r = Qsub<Tags...>(x, y).data.data;
+            else r = Qadd<Tags...>(x, y).data.data;
+            std::fprintf(out, "%s%lld", first ? "" : ",", (long long)r);
+            first = false;
+        }
+    std::fprintf(out, "]}\n");
+}
+
+// Qreduce over a vector of length LEN filled from the synthetic generator, several seeds
+template <class T, size_t LEN, class... Levels>
+static void reduce_table(FILE* out, const char* name)
+{
+    std::string lv = "[";
+    ((lv += (lv.size() > 1 ? "," : "") + fmt_json<Levels>()), ...);
+    lv += "]";
+    std::fprintf(out, "{\"kind\":\"reduce\",\"name\":\"%s\",\"fin\":%s,\"levels\":%s,\"len\":%zu,\"dist\":0,\"seeds\":[1,2,3,4,5,6,7,8],\"y\":[", name, fmt_json<T>().c_str(),
+                 lv.c_str(), LEN);
+    for (uint64_t seed = 1; seed <= 8; ++seed) {
+        Qu_s<dim<LEN>, T> v;
+        for (size_t i = 0; i < LEN; ++i) v[i].data.data = synth<T>(seed, 0, i, 0);
+        auto r = Qreduce<Levels...>(v);
+        using R = decltype(r);
+        std::fprintf(out, "%s[%lld,%s]", seed > 1 ? "," : "", (long long)r.data.data, fmt_json<R>().c_str());
+    }
+    std::fprintf(out, "]}\n");
+}
+
+int main(int argc, char** argv)
+{
+    int part = argc > 1 ? std::atoi(argv[1]) : 0;
+    FILE* out = stdout;
+    using s35 = Qu<intBits<3>, fracBits<5>>;                   // 9-bit signed source, exhaustive
+    using u26 = Qu<intBits<2>, fracBits<6>, isSigned<false>>;  // 8-bit unsigned source, exhaustive
+    using s1010 = Qu<intBits<10>, fracBits<10>>;               // the reference tests' Low_t width
+    using s3030 = Qu<intBits<30>, fracBits<30>>;               // the reference tests' Mid_t width
+    switch (part) {
+    case 0:
+        cvt_all<s35>(out, -256, 255);
+        break;
+    case 1:
+        cvt_all<u26>(out, 0, 255);
+        cvt_all<s1010>(out, -(1 << 20), (1 << 20) - 1, 4099); // strided sweep of the 21-bit source
+        break;
+    case 2:
+        cvt_all<s3030>(out, -(1ll << 60), (1ll << 60) - 1, (1ll << 52) + 12345678901ll); // strided sweep of the 61-bit source
+        break;
+    case 3: {
+        using a = Qu<intBits<2>, fracBits<3>>;                                             // 6 bits signed
+        using b = Qu<intBits<3>, fracBits<1>, isSigned<false>>;                            // 4 bits unsigned
+        using c = Qu<intBits<1>, fracBits<4>, QuMode<RND::CONV>, OfMode<SAT::ZERO>>;       // other modes
+        using d = Qu<intBits<4>, fracBits<-1>>;                                            // negative frac
+        mul_table<a, a>(out, "default");
+        mul_table<a, b>(out, "default");
+        mul_table<a, c>(out, "default");     // modes differ -> defaults
+        mul_table<c, c>(out, "default");     // modes agree -> kept
+        mul_table<a, d>(out, "default");
+        mul_table<a, a, FullPrec>(out, "FullPrec"); // min*min overflows by one LSB
+        mul_table<a, b, FullPrec>(out, "FullPrec");
+        mul_table<a, a, intBits<5>, fracBits<6>>(out, "int5_frac6");
+        mul_table<a, a, fracBits<1>, QuMode<RND::POS_INF>>(out, "frac1_POS_INF");
+        mul_table<a, a, fracBits<1>, QuMode<RND::NEG_INF>>(out, "frac1_NEG_INF");
+        mul_table<a, a, fracBits<2>, QuMode<RND::ZERO>, OfMode<SAT::SMGN>>(out, "frac2_ZERO_SMGN");
+        mul_table<a, a, fracBits<2>, QuMode<RND::INF>, OfMode<WRP::TCPL>>(out, "frac2_INF_WRP");
+        mul_table<a, a, fracBits<3>, QuMode<RND::CONV>, OfMode<SAT::ZERO>>(out, "frac3_CONV_ZERO");
+        mul_table<a, a, fracBits<2>, QuMode<TRN::SMGN>, isSigned<false>>(out, "frac2_SMGN_unsigned");
+        mul_table<a, b, c>(out, "fulltype_c");
+        mul_table<b, b, OfMode<WRP::TCPL>, intBits<2>>(out, "unsigned_wrap_int2");
+        add_table<false, a, a>(out, "default");
+        add_table<false, a, b>(out, "default");
+        add_table<false, a, c>(out, "default");
+        add_table<false, a, d>(out, "default");
+        add_table<false, a, a, FullPrec>(out, "FullPrec");
+        add_table<false, a, b, c>(out, "fulltype_c");
+        add_table<false, a, a, fracBits<1>, QuMode<RND::CONV>, OfMode<SAT::SMGN>>(out, "frac1_CONV_SMGN");
+        add_table<false, a, d, fracBits<1>, QuMode<TRN::SMGN>, OfMode<WRP::TCPL>, intBits<3>>(out, "frac1_SMGN_WRP_int3");
+        add_table<true, a, a>(out, "default");
+        add_table<true, a, b>(out, "default");
+        add_table<true, b, a, isSigned<false>>(out, "unsigned");
+        add_table<true, a, d, fracBits<0>, QuMode<RND::ZERO>, OfMode<SAT::ZERO>>(out, "frac0_ZERO_ZERO");
+        add_table<true, b, b, OfMode<WRP::TCPL>>(out, "unsigned_wrap");
+        break;
+    }
+    case 4: {
+        using e = Qu<intBits<4>, fracBits<3>>;
+        using z = Qu<intBits<8>, fracBits<8>, isSigned<true>, QuMode<TRN::TCPL>, OfMode<SAT::ZERO>>;
+        using nar = Qu<intBits<5>, fracBits<2>, QuMode<RND::CONV>, OfMode<SAT::SMGN>>;
+        using wide = Qu<intBits<12>, fracBits<5>, QuMode<RND::ZERO>>;
+        reduce_table<e, 1>(out, "len1_default");
+        reduce_table<e, 1, nar>(out, "len1_nar");
+        reduce_table<e, 2, nar>(out, "len2_nar");
+        reduce_table<e, 3, nar, wide>(out, "len3_nar_wide");
+        reduce_table<e, 4, nar, wide>(out, "len4_nar_wide");
+        reduce_table<e, 5, nar, wide>(out, "len5_nar_wide");
+        reduce_table<e, 6, nar, wide>(out, "len6_nar_wide");
+        reduce_table<e, 7, wide, nar>(out, "len7_wide_nar");
+        reduce_table<e, 8>(out, "len8_default");
+        reduce_table<e, 16, wide>(out, "len16_wide");
+        reduce_table<z, 16>(out, "len16_z_default");
+        reduce_table<z, 512>(out, "len512_z_default");
+        reduce_table<e, 512, nar, wide>(out, "len512_nar_wide");
+        reduce_table<e, 1000, wide, nar>(out, "len1000_wide_nar");
+        reduce_table<e, 1000>(out, "len1000_default");
+        break;
+    }
+    default:
+        return 2;
+    }
+    return 0;
+}

@@ -1,0 +1,364 @@
+"""Descriptor lowering in Python — a mirror of include/qgemul_lower.hpp used by the tests and the
+benchmark harness to build `qgemul_desc` structures (include/qgemul.h) without a C++ compile.
+
+It restates the reference's compile-time result-type rules:
+  * defaults                       /root/reference/include/QuBLAS.h:2355-2359
+  * MulMerger / AddMerger          QuBLAS.h:3107-3120, :3125-3139
+  * a full Qu type used as tag     QuBLAS.h:3097-3099 (unwrapped into its five tags)
+  * BasicComplexMul / TFComplexMul QuBLAS.h:3426-3445, :3510-3534 (incl. the crossed cdbT/badT use
+                                   and the never-honoured baT)
+  * Reducer level types            QuBLAS.h:4906-4921, :4960-4984
+The C++ header is the product-side lowering; tests/test_lowering.py checks both against the formats
+the reference's own types report (tests/golden/ref_gemm_*.jsonl, written by oracle/ref_driver.hpp).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field, replace
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+QGEMUL_ABI_VERSION = 1
+QG_MAX_LEVELS = 40
+
+
+class RND:
+    POS_INF, NEG_INF, ZERO, INF, CONV = 0, 1, 2, 3, 4
+
+
+class TRN:
+    TCPL, SMGN = 5, 6
+
+
+class SAT:
+    TCPL, ZERO, SMGN = 0, 1, 2
+
+
+class WRP:
+    TCPL, TCPL_SAT = 3, 4
+
+
+QU_MODES = {"RND::POS_INF": 0, "RND::NEG_INF": 1, "RND::ZERO": 2, "RND::INF": 3, "RND::CONV": 4,
+            "TRN::TCPL": 5, "TRN::SMGN": 6}
+OF_MODES = {"SAT::TCPL": 0, "SAT::ZERO": 1, "SAT::SMGN": 2, "WRP::TCPL": 3}
+
+CMUL_NONE, CMUL_BASIC, CMUL_TF = 0, 1, 2
+CLASS_LINEAR, CLASS_TREE = 1, 2
+
+
+class qfmt(C.Structure):
+    _fields_ = [("I", C.c_int16), ("F", C.c_int16), ("S", C.c_uint8), ("Q", C.c_uint8),
+                ("O", C.c_uint8), ("pad", C.c_uint8)]
+
+
+class qgemul_desc(C.Structure):
+    _fields_ = [("abi", C.c_uint32), ("transA", C.c_uint8), ("is_complex", C.c_uint8),
+                ("cmul", C.c_uint8), ("reserved", C.c_uint8),
+                ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
+                ("a", qfmt * 2), ("b", qfmt * 2), ("c", qfmt * 2),
+                ("mul", qfmt * 8),
+                ("n_levels", C.c_uint32), ("reserved2", C.c_uint32),
+                ("level_add", (qfmt * QG_MAX_LEVELS) * 2),
+                ("level", (qfmt * QG_MAX_LEVELS) * 2)]
+
+
+class qgemul_opts(C.Structure):
+    _fields_ = [("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64),
+                ("device", C.c_int32), ("flags", C.c_uint32)]
+
+
+class qgemul_info(C.Structure):
+    _fields_ = [("cls", C.c_int32), ("supported", C.c_int32), ("max_bits", C.c_int32),
+                ("in_bits", C.c_int32 * 2), ("limbs", C.c_int32 * 2), ("kernel", C.c_int32),
+                ("host_elem_bytes", C.c_int32 * 3), ("host_imag_off", C.c_int32 * 3),
+                ("packed_bytes", C.c_int64 * 3), ("ops", C.c_double), ("reason", C.c_char * 96)]
+
+
+@dataclass(frozen=True)
+class Qu:
+    """A scalar fixed-point format: Qu<intBits<I>, fracBits<F>, isSigned<S>, QuMode<Q>, OfMode<O>>
+    with the reference's defaults (QuBLAS.h:2355-2359)."""
+    intBits: int = 8
+    fracBits: int = 8
+    isSigned: bool = True
+    QuMode: int = TRN.TCPL
+    OfMode: int = SAT.TCPL
+
+    @property
+    def W(self) -> int:
+        return self.intBits + self.fracBits
+
+    @property
+    def storage_bits(self) -> int:
+        return 1 + self.W  # always a sign bit, QuBLAS.h:2384-2385
+
+    @property
+    def host_bytes(self) -> int:
+        return 4 if self.storage_bits <= 32 else 8  # ArbiInt<N>::data_t, QuBLAS.h:353
+
+    @property
+    def raw_min(self) -> int:
+        return -(1 << self.W) if self.isSigned else 0
+
+    @property
+    def raw_max(self) -> int:
+        return (1 << self.W) - 1
+
+    def as_tuple(self) -> Tuple[int, int, int, int, int]:
+        return (self.intBits, self.fracBits, int(self.isSigned), self.QuMode, self.OfMode)
+
+    def c(self) -> qfmt:
+        return qfmt(self.intBits, self.fracBits, int(self.isSigned), self.QuMode, self.OfMode, 0)
+
+    @staticmethod
+    def from_tuple(t: Sequence[int]) -> "Qu":
+        return Qu(int(t[0]), int(t[1]), bool(t[2]), int(t[3]), int(t[4]))
+
+
+@dataclass(frozen=True)
+class Qcomplex:
+    real: Qu
+    imag: Qu
+
+
+Elem = Union[Qu, Qcomplex]
+
+
+@dataclass(frozen=True)
+class Tags:
+    """A loose tag list `<intBits<..>, fracBits<..>, isSigned<..>, QuMode<..>, OfMode<..>, FullPrec>`;
+    None = tag absent.  `Tags.of(Qu(...))` is a full type used as tag (all five present)."""
+    intBits: Optional[int] = None
+    fracBits: Optional[int] = None
+    isSigned: Optional[bool] = None
+    QuMode: Optional[int] = None
+    OfMode: Optional[int] = None
+    FullPrec: bool = False
+
+    @staticmethod
+    def of(q: Qu) -> "Tags":
+        return Tags(q.intBits, q.fracBits, q.isSigned, q.QuMode, q.OfMode, False)
+
+
+TagLike = Union[Tags, Qu, None]
+
+
+def _tags(t: TagLike) -> Tags:
+    if t is None:
+        return Tags()
+    if isinstance(t, Qu):
+        return Tags.of(t)
+    return t
+
+
+def _common(x, y, default):
+    return x if x == y else default
+
+
+def mul_merge(a: Qu, b: Qu, t: TagLike = None) -> Qu:
+    """MulMerger::resType, QuBLAS.h:3107-3120."""
+    t = _tags(t)
+    fp = t.FullPrec
+    return Qu(
+        t.intBits if t.intBits is not None else (a.intBits + b.intBits if fp else max(a.intBits, b.intBits)),
+        t.fracBits if t.fracBits is not None else (a.fracBits + b.fracBits if fp else max(a.fracBits, b.fracBits)),
+        t.isSigned if t.isSigned is not None else (a.isSigned or b.isSigned),
+        t.QuMode if t.QuMode is not None else _common(a.QuMode, b.QuMode, TRN.TCPL),
+        t.OfMode if t.OfMode is not None else _common(a.OfMode, b.OfMode, SAT.TCPL),
+    )
+
+
+def add_merge(a: Qu, b: Qu, t: TagLike = None) -> Qu:
+    """AddMerger::resType, QuBLAS.h:3125-3139 (also used by Qsub, :3214)."""
+    t = _tags(t)
+    fp = t.FullPrec
+    return Qu(
+        t.intBits if t.intBits is not None else (max(a.intBits, b.intBits) + 1 if fp else max(a.intBits, b.intBits)),
+        t.fracBits if t.fracBits is not None else max(a.fracBits, b.fracBits),
+        t.isSigned if t.isSigned is not None else (a.isSigned or b.isSigned),
+        t.QuMode if t.QuMode is not None else _common(a.QuMode, b.QuMode, TRN.TCPL),
+        t.OfMode if t.OfMode is not None else _common(a.OfMode, b.OfMode, SAT.TCPL),
+    )
+
+
+@dataclass(frozen=True)
+class BasicComplexMul:
+    """BasicComplexMul<acT<>, bdT<>, adT<>, bcT<>, acbdT<>, adbcT<>, loose tags…>.
+    A sub-op without its own tag sees the wrapper's loose tags (its default is xT<toArgs…>,
+    whose ::list is the whole argument list, QuBLAS.h:3429-3435 + :164-170)."""
+    acT: TagLike = None
+    bdT: TagLike = None
+    adT: TagLike = None
+    bcT: TagLike = None
+    acbdT: TagLike = None
+    adbcT: TagLike = None
+    loose: TagLike = None
+
+
+@dataclass(frozen=True)
+class TFComplexMul:
+    """TFComplexMul<abT<>, cdT<>, baT<>, abcT<>, cdbT<>, badT<>, ABT<>, BCT<>, loose tags…>."""
+    abT: TagLike = None
+    cdT: TagLike = None
+    baT: TagLike = None   # accepted and ignored, exactly like the reference (QuBLAS.h:3515)
+    abcT: TagLike = None
+    cdbT: TagLike = None
+    badT: TagLike = None
+    ABT: TagLike = None
+    BCT: TagLike = None
+    loose: TagLike = None
+
+
+MulArgs = Union[Tags, Qu, BasicComplexMul, TFComplexMul, None]
+
+
+def _pick(own: TagLike, loose: TagLike) -> Tags:
+    return _tags(own) if own is not None else _tags(loose)
+
+
+def complex_mul_slots(x: Qcomplex, y: Qcomplex, m: MulArgs) -> Tuple[int, List[Qu]]:
+    """Resolved result formats of every sub-operation, in the slot order of include/qgemul.h."""
+    a, b, c, d = x.real, x.imag, y.real, y.imag
+    zero = Qu(0, 0, False, 0, 0)
+    if m is None:
+        m = BasicComplexMul()  # Qmul(c1, c2) without arguments, QuBLAS.h:3422-3424
+    if isinstance(m, (Tags, Qu)):
+        raise ValueError("complex Qgemul needs BasicComplexMul/TFComplexMul (or no) QgemulMulArgs")
+    if isinstance(m, BasicComplexMul):
+        ac = mul_merge(a, c, _pick(m.acT, m.loose))
+        bd = mul_merge(b, d, _pick(m.bdT, m.loose))
+        ad = mul_merge(a, d, _pick(m.adT, m.loose))
+        bc = mul_merge(b, c, _pick(m.bcT, m.loose))
+        re = add_merge(ac, bd, _pick(m.acbdT, m.loose))
+        im = add_merge(ad, bc, _pick(m.adbcT, m.loose))
+        return CMUL_BASIC, [ac, bd, ad, bc, re, im, zero, zero]
+    ab = add_merge(a, b, _pick(m.abT, m.loose))
+    cd = add_merge(c, d, _pick(m.cdT, m.loose))
+    ba = add_merge(b, a, None)                      # quirk 2: always the default merge
+    A = mul_merge(ab, c, _pick(m.abcT, m.loose))
+    B = mul_merge(cd, b, _pick(m.badT, m.loose))    # quirk 1: B is quantised with badT
+    Cc = mul_merge(ba, d, _pick(m.cdbT, m.loose))   # quirk 1: C is quantised with cdbT
+    re = add_merge(A, B, _pick(m.ABT, m.loose))
+    im = add_merge(B, Cc, _pick(m.BCT, m.loose))
+    return CMUL_TF, [ab, cd, ba, A, B, Cc, re, im]
+
+
+def n_levels_for(K: int) -> int:
+    n = 0
+    while K > 1:
+        K = (K + 1) // 2
+        n += 1
+    return n
+
+
+def lower(A: Elem, B: Elem, Cc: Elem, M: int, N: int, K: int, *,
+          add_args: Optional[Sequence[Elem]] = None, mul_args: MulArgs = None,
+          transposed_a: bool = False) -> qgemul_desc:
+    """Lower one Qgemul<QgemulAddArgs<add_args…>, QgemulMulArgs<mul_args>, QgemulTransposedA<t>>
+    call on element types (A, B, C) and runtime sizes to the C-ABI descriptor."""
+    cx = isinstance(A, Qcomplex)
+    if cx != isinstance(B, Qcomplex) or cx != isinstance(Cc, Qcomplex):
+        raise ValueError("mixed real/complex operands are outside the Qgemul path (SURVEY.md §2)")
+    if K < 1 or M < 0 or N < 0:
+        raise ValueError("bad shape")
+    d = qgemul_desc()
+    d.abi = QGEMUL_ABI_VERSION
+    d.transA = int(bool(transposed_a))
+    d.is_complex = int(cx)
+    d.M, d.N, d.K = M, N, K
+    nl = n_levels_for(K)
+    if nl > QG_MAX_LEVELS:
+        raise ValueError("K too large")
+    d.n_levels = nl
+    levels = list(add_args) if add_args else []
+    if not cx:
+        d.a[0] = d.a[1] = A.c()
+        d.b[0] = d.b[1] = B.c()
+        d.c[0] = d.c[1] = Cc.c()
+        if isinstance(mul_args, (BasicComplexMul, TFComplexMul)):
+            raise ValueError("complex multiplier tags on a real Qgemul")
+        prod = mul_merge(A, B, mul_args)
+        d.cmul = CMUL_NONE
+        d.mul[0] = prod.c()
+        prev = prod
+        for l in range(nl):
+            if levels:
+                t = levels[min(l, len(levels) - 1)]
+                if not isinstance(t, Qu):
+                    raise ValueError("a real Qgemul needs real level types")
+            else:
+                t = prev  # Qadd<nullptr_t>: default merge of two equal types = that type
+            d.level_add[0][l] = d.level_add[1][l] = t.c()
+            d.level[0][l] = d.level[1][l] = t.c()
+            prev = t
+    else:
+        d.a[0], d.a[1] = A.real.c(), A.imag.c()
+        d.b[0], d.b[1] = B.real.c(), B.imag.c()
+        d.c[0], d.c[1] = Cc.real.c(), Cc.imag.c()
+        cmul, slots = complex_mul_slots(A, B, mul_args)
+        d.cmul = cmul
+        for i, s in enumerate(slots):
+            d.mul[i] = s.c()
+        prev = (slots[6], slots[7]) if cmul == CMUL_TF else (slots[4], slots[5])
+        for l in range(nl):
+            if levels:
+                t = levels[min(l, len(levels) - 1)]
+                if not isinstance(t, Qcomplex):
+                    raise ValueError("a complex Qgemul needs complex level types (QuBLAS.h:4966)")
+                buf = (t.real, t.imag)
+            else:
+                buf = prev
+            for p in range(2):
+                # a complex type passed as Qadd tag is ignored: the add is the default merge of the
+                # incoming format, the level buffer then converts
+                d.level_add[p][l] = add_merge(prev[p], prev[p], None).c()
+                d.level[p][l] = buf[p].c()
+            prev = buf
+    return d
+
+
+def desc_to_dict(d: qgemul_desc) -> Dict:
+    """Same shape as the JSON records oracle/ref_driver.hpp prints."""
+    f = lambda q: [q.I, q.F, q.S, q.Q, q.O]
+    nl = d.n_levels
+    return {
+        "M": d.M, "N": d.N, "K": d.K, "transA": d.transA, "is_complex": d.is_complex, "cmul": d.cmul,
+        "a": [f(d.a[0]), f(d.a[1])], "b": [f(d.b[0]), f(d.b[1])], "c": [f(d.c[0]), f(d.c[1])],
+        "mul": [f(d.mul[i]) for i in range(8)], "n_levels": nl,
+        "level_add": [[f(d.level_add[0][l]), f(d.level_add[1][l])] for l in range(nl)],
+        "level": [[f(d.level[0][l]), f(d.level[1][l])] for l in range(nl)],
+    }
+
+
+def desc_from_dict(j: Dict) -> qgemul_desc:
+    """Build a descriptor straight from a golden record (formats as the reference resolved them)."""
+    d = qgemul_desc()
+    d.abi = QGEMUL_ABI_VERSION
+    d.transA, d.is_complex, d.cmul = j["transA"], j["is_complex"], j["cmul"]
+    d.M, d.N, d.K = j["M"], j["N"], j["K"]
+    mk = lambda t: qfmt(t[0], t[1], t[2], t[3], t[4], 0)
+    for p in range(2):
+        d.a[p], d.b[p], d.c[p] = mk(j["a"][p]), mk(j["b"][p]), mk(j["c"][p])
+    for i in range(8):
+        d.mul[i] = mk(j["mul"][i])
+    d.n_levels = j["n_levels"]
+    for l in range(d.n_levels):
+        for p in range(2):
+            d.level_add[p][l] = mk(j["level_add"][l][p])
+            d.level[p][l] = mk(j["level"][l][p])
+    return d
+
+
+def elem_parts(e: Elem) -> Tuple[Qu, Qu]:
+    return (e.real, e.imag) if isinstance(e, Qcomplex) else (e, e)
+
+
+def host_layout(e: Elem) -> Tuple[int, int, Tuple[int, int]]:
+    """(element bytes, byte offset of .imag, (bytes of real, bytes of imag)) of the reference's
+    host element: int32/int64 per part, a complex element is struct {real; imag;} (QuBLAS.h:2512-2513)."""
+    if not isinstance(e, Qcomplex):
+        return e.host_bytes, 0, (e.host_bytes, 0)
+    sr, si = e.real.host_bytes, e.imag.host_bytes
+    off = (sr + si - 1) // si * si
+    al = max(sr, si)
+    size = (off + si + al - 1) // al * al
+    return size, off, (sr, si)

@@ -1,0 +1,81 @@
+"""Readers for tests/golden/*.  Fixtures are data only (formats, raw integers, seeds)."""
+import glob
+import gzip
+import json
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _records(path):
+    with gzip.open(path, "rt") as f:
+        txt = f.read()
+    dec = json.JSONDecoder()
+    i, n = 0, len(txt)
+    while i < n:
+        while i < n and txt[i].isspace():
+            i += 1
+        if i >= n:
+            break
+        obj, i = dec.raw_decode(txt, i)
+        yield obj
+
+
+def gemm_cases(kind="real"):
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLD, f"ref_gemm_{kind}_*.jsonl.gz"))):
+        out.extend(_records(p))
+    return out
+
+
+def scalar_tables(part=None):
+    pat = f"ref_scalar_{part}.jsonl.gz" if part is not None else "ref_scalar_*.jsonl.gz"
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLD, pat))):
+        out.extend(_records(p))
+    return out
+
+
+def rounding_kat():
+    with open(os.path.join(GOLD, "ref_rounding_kat.json")) as f:
+        return json.load(f)["cases"]
+
+
+def case_elems(j):
+    """(A elem, B elem, C elem) of a golden GEMM record as qublas_amd.desc types."""
+    from qublas_amd.desc import Qcomplex, Qu
+    mk = lambda p: Qcomplex(Qu.from_tuple(p[0]), Qu.from_tuple(p[1])) if j["is_complex"] else Qu.from_tuple(p[0])
+    return mk(j["a"]), mk(j["b"]), mk(j["c"])
+
+
+def case_inputs(j, qoracle):
+    """Host-layout A and B arrays of a golden GEMM record (explicit values or generator seeds)."""
+    ea, eb, _ = case_elems(j)
+    M, N, K = j["M"], j["N"], j["K"]
+    inp = j["inputs"]
+    if "seedA" in inp:
+        return qoracle.fill(ea, M * K, inp["seedA"], inp["dist"]), qoracle.fill(eb, K * N, inp["seedB"], inp["dist"])
+
+    def explicit(vals, e, n):
+        arr = np.zeros(n, dtype=qoracle.host_dtype(e))
+        v = np.asarray(vals, dtype=np.int64)
+        if j["is_complex"]:
+            arr["re"], arr["im"] = v[0::2], v[1::2]
+        else:
+            arr[:] = v
+        return arr
+    return explicit(inp["A"], ea, M * K), explicit(inp["B"], eb, K * N)
+
+
+def case_expected(j, qoracle):
+    _, _, ec = case_elems(j)
+    n = j["M"] * j["N"]
+    arr = np.zeros(n, dtype=qoracle.host_dtype(ec))
+    v = np.asarray(j["C"], dtype=np.int64)
+    if j["is_complex"]:
+        arr["re"], arr["im"] = v[0::2], v[1::2]
+    else:
+        arr[:] = v
+    return arr
