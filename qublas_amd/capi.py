@@ -1,0 +1,182 @@
+"""ctypes binding of libqugemm.so — the C-ABI of include/qgemul.h.
+
+This is plumbing for tests and the benchmark harness; the product boundary is the C-ABI itself
+and the C++23 header include/QuBLAS_amd.h that lowers the reference's tag API onto it.
+The library has no CPU arithmetic path: loading fails loudly if it has not been built, and every
+compute call fails with QG_ENOGPU when no gfx950 device is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .desc import (Qcomplex, Qu, host_layout, qgemul_desc, qgemul_info, qgemul_opts)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqugemm.so")
+
+QG_OK, QG_EINVAL, QG_EUNSUPPORTED, QG_EHIP, QG_ERCCL, QG_ERANGE, QG_ENOGPU = 0, -1, -2, -3, -4, -5, -6
+OPT_FORCE_TREE, OPT_CHECK_RANGE = 1, 2
+OPERAND_A, OPERAND_B, OPERAND_C = 0, 1, 2
+KERNEL_NAMES = {0: "none", 1: "mfma_i8", 2: "mfma_i8_limb", 3: "tree_i32", 4: "tree_i64", 5: "tree_cplx"}
+
+EXPORTS = [
+    "qgemul_classify", "qgemul_strerror", "qgemul_abi_version", "qgemul_last_hip_error", "qgemul_run",
+    "qgemul_ctx_create", "qgemul_ctx_destroy", "qgemul_ctx_sync", "qgemul_ctx_stream",
+    "qgemul_plan_create", "qgemul_plan_destroy", "qgemul_plan_info",
+    "qgemul_dev_alloc", "qgemul_dev_free", "qgemul_memcpy_h2d", "qgemul_memcpy_d2h",
+    "qgemul_pack", "qgemul_unpack_c", "qgemul_execute", "qgemul_fill_packed", "qgemul_time_execute",
+]
+
+_lib = None
+
+
+class QgemulError(RuntimeError):
+    def __init__(self, status: int, what: str = ""):
+        self.status = status
+        msg = lib().qgemul_strerror(status).decode()
+        if status == QG_EHIP:
+            msg += f" (hipError {lib().qgemul_last_hip_error()})"
+        super().__init__(f"{what}: {msg}" if what else msg)
+
+
+def lib() -> C.CDLL:
+    """Load the engine.  Raises if the library is missing: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not built: run `python -m qublas_amd.build` (hipcc, gfx950). "
+                              "The engine has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        vp, i64, u32, u64 = C.c_void_p, C.c_int64, C.c_uint32, C.c_uint64
+        pd = C.POINTER(qgemul_desc)
+        L.qgemul_classify.argtypes = [pd, u32, C.POINTER(qgemul_info)]
+        L.qgemul_strerror.restype = C.c_char_p
+        L.qgemul_strerror.argtypes = [C.c_int]
+        L.qgemul_abi_version.restype = u32
+        L.qgemul_run.argtypes = [pd, vp, vp, vp, C.POINTER(qgemul_opts)]
+        L.qgemul_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.qgemul_ctx_destroy.argtypes = [vp]
+        L.qgemul_ctx_destroy.restype = None
+        L.qgemul_ctx_sync.argtypes = [vp]
+        L.qgemul_ctx_stream.argtypes = [vp]
+        L.qgemul_ctx_stream.restype = vp
+        L.qgemul_plan_create.argtypes = [vp, pd, u32, C.POINTER(vp)]
+        L.qgemul_plan_destroy.argtypes = [vp]
+        L.qgemul_plan_destroy.restype = None
+        L.qgemul_plan_info.argtypes = [vp, C.POINTER(qgemul_info)]
+        L.qgemul_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+        L.qgemul_dev_free.argtypes = [vp, vp]
+        L.qgemul_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+        L.qgemul_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+        L.qgemul_pack.argtypes = [vp, C.c_int, vp, i64, vp]
+        L.qgemul_unpack_c.argtypes = [vp, vp, vp, i64]
+        L.qgemul_execute.argtypes = [vp, vp, vp, vp]
+        L.qgemul_fill_packed.argtypes = [vp, C.c_int, u64, C.c_int, vp]
+        L.qgemul_time_execute.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        _lib = L
+    return _lib
+
+
+def _chk(st: int, what: str = ""):
+    if st != QG_OK:
+        raise QgemulError(st, what)
+
+
+def classify(desc: qgemul_desc, flags: int = 0) -> qgemul_info:
+    info = qgemul_info()
+    _chk(lib().qgemul_classify(C.byref(desc), flags, C.byref(info)), "qgemul_classify")
+    return info
+
+
+def classify_status(desc: qgemul_desc, flags: int = 0):
+    info = qgemul_info()
+    st = lib().qgemul_classify(C.byref(desc), flags, C.byref(info))
+    return st, info
+
+
+def run(desc: qgemul_desc, C_out: np.ndarray, A: np.ndarray, B: np.ndarray, *, lda: int = 0, ldb: int = 0,
+        ldc: int = 0, device: int = -1, flags: int = 0) -> np.ndarray:
+    """qgemul_run on host-layout numpy buffers (see oracle.qoracle.host_dtype for the element dtype)."""
+    A = np.ascontiguousarray(A)
+    B = np.ascontiguousarray(B)
+    assert C_out.flags["C_CONTIGUOUS"]
+    o = qgemul_opts(lda, ldb, ldc, device, flags)
+    _chk(lib().qgemul_run(C.byref(desc), C_out.ctypes.data_as(C.c_void_p), A.ctypes.data_as(C.c_void_p),
+                          B.ctypes.data_as(C.c_void_p), C.byref(o)), "qgemul_run")
+    return C_out
+
+
+class Context:
+    def __init__(self, device: int = -1):
+        self.h = C.c_void_p()
+        _chk(lib().qgemul_ctx_create(device, C.byref(self.h)), "qgemul_ctx_create")
+
+    def close(self):
+        if self.h:
+            lib().qgemul_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def sync(self):
+        _chk(lib().qgemul_ctx_sync(self.h), "qgemul_ctx_sync")
+
+    @property
+    def stream(self) -> int:
+        return lib().qgemul_ctx_stream(self.h)
+
+    def alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        _chk(lib().qgemul_dev_alloc(self.h, nbytes, C.byref(p)), "qgemul_dev_alloc")
+        return p.value
+
+    def free(self, ptr: int):
+        _chk(lib().qgemul_dev_free(self.h, C.c_void_p(ptr)), "qgemul_dev_free")
+
+    def h2d(self, dst: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        _chk(lib().qgemul_memcpy_h2d(self.h, C.c_void_p(dst), arr.ctypes.data_as(C.c_void_p), arr.nbytes), "h2d")
+
+    def d2h(self, arr: np.ndarray, src: int):
+        _chk(lib().qgemul_memcpy_d2h(self.h, arr.ctypes.data_as(C.c_void_p), C.c_void_p(src), arr.nbytes), "d2h")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class Plan:
+    def __init__(self, ctx: Context, desc: qgemul_desc, flags: int = 0):
+        self.ctx = ctx
+        self.desc = desc
+        self.h = C.c_void_p()
+        _chk(lib().qgemul_plan_create(ctx.h, C.byref(desc), flags, C.byref(self.h)), "qgemul_plan_create")
+        self.info = qgemul_info()
+        _chk(lib().qgemul_plan_info(self.h, C.byref(self.info)), "qgemul_plan_info")
+
+    def close(self):
+        if self.h:
+            lib().qgemul_plan_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def pack(self, operand: int, src_dev: int, packed_dev: int, ld: int = 0):
+        _chk(lib().qgemul_pack(self.h, operand, C.c_void_p(src_dev), ld, C.c_void_p(packed_dev)), "qgemul_pack")
+
+    def fill(self, operand: int, seed: int, dist: int, packed_dev: int):
+        _chk(lib().qgemul_fill_packed(self.h, operand, seed, dist, C.c_void_p(packed_dev)), "qgemul_fill_packed")
+
+    def execute(self, pC: int, pA: int, pB: int):
+        _chk(lib().qgemul_execute(self.h, C.c_void_p(pC), C.c_void_p(pA), C.c_void_p(pB)), "qgemul_execute")
+
+    def unpack_c(self, pC: int, dst_dev: int, ld: int = 0):
+        _chk(lib().qgemul_unpack_c(self.h, C.c_void_p(pC), C.c_void_p(dst_dev), ld), "qgemul_unpack_c")
+
+    def time_execute(self, pC: int, pA: int, pB: int, warmup: int, iters: int) -> float:
+        ms = C.c_float()
+        _chk(lib().qgemul_time_execute(self.h, C.c_void_p(pC), C.c_void_p(pA), C.c_void_p(pB), warmup, iters,
+                                       C.byref(ms)), "qgemul_time_execute")
+        return ms.value

@@ -1,0 +1,451 @@
+// qg_api.hip — the C-ABI of include/qgemul.h: contexts, plans, packing, execution.
+//
+// There is deliberately no CPU arithmetic path in this library: without a gfx950 device every
+// compute entry point returns QG_ENOGPU.  (The CPU restatement lives in oracle/ and is test
+// infrastructure only.)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+
+#include "../../include/qgemul.h"
+#include "qg_kernels.h"
+#include "qg_plan.h"
+
+static thread_local int g_last_hip = 0;
+
+#define QG_HIP(expr)                         \
+    do {                                     \
+        hipError_t e_ = (expr);              \
+        if (e_ != hipSuccess) {              \
+            g_last_hip = (int)e_;            \
+            return QG_EHIP;                  \
+        }                                    \
+    } while (0)
+
+struct qgemul_ctx {
+    int device;
+    hipStream_t stream;
+    int* flag_dev;
+};
+
+struct qgemul_plan {
+    qgemul_ctx* ctx;
+    qgemul_desc desc;
+    uint32_t flags;
+    QAnalysis an;
+    qgemul_info info;
+    int LA, LB;
+    QPackedGeom pa, pb;
+    QCGeom pc;
+    QHostElem ha, hb, hc;
+    QTreeTable* dev_table;
+};
+
+static int pow2_bytes(int storage_bits)
+{
+    int b = (storage_bits + 7) / 8;
+    int c = 1;
+    while (c < b) c *= 2;
+    return c;
+}
+
+static int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// fill info + geometry for a descriptor; no GPU access
+static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qgemul_info* info, int* pLA, int* pLB,
+                         QPackedGeom* pa, QPackedGeom* pb, QCGeom* pc, QHostElem* ha, QHostElem* hb, QHostElem* hc)
+{
+    qg_analyze(d, an);
+    memset(info, 0, sizeof *info);
+    snprintf(info->reason, sizeof info->reason, "%s", an->reason);
+    if (an->status != QG_OK) {
+        info->supported = 0;
+        return an->status;
+    }
+    const int parts = d->is_complex ? 2 : 1;
+    *ha = qg_host_elem(d->a, d->is_complex);
+    *hb = qg_host_elem(d->b, d->is_complex);
+    *hc = qg_host_elem(d->c, d->is_complex);
+    info->cls = an->cls;
+    info->max_bits = an->max_bits;
+    info->supported = 1;
+    auto sbits = [&](const qfmt* f) {
+        int m = 0;
+        for (int p = 0; p < parts; ++p) {
+            int b = 1 + (int)f[p].I + (int)f[p].F;
+            if (b > m) m = b;
+        }
+        return m;
+    };
+    info->in_bits[0] = sbits(d->a);
+    info->in_bits[1] = sbits(d->b);
+    info->host_elem_bytes[0] = ha->size;
+    info->host_elem_bytes[1] = hb->size;
+    info->host_elem_bytes[2] = hc->size;
+    info->host_imag_off[0] = ha->off[1];
+    info->host_imag_off[1] = hb->off[1];
+    info->host_imag_off[2] = hc->off[1];
+    const double mnk = (double)d->M * (double)d->N * (double)d->K;
+    info->ops = !d->is_complex ? 2.0 * mnk : (d->cmul == QG_CMUL_TF ? 6.0 * mnk : 8.0 * mnk);
+
+    int LA = 0, LB = 0, kernel = QG_KERNEL_NONE;
+    if (an->linear_ok && !(flags & QG_OPT_FORCE_TREE)) {
+        LA = qg_limbs_for(d->a[0]);
+        LB = qg_limbs_for(d->b[0]);
+        const int mn = LA < LB ? LA : LB;
+        if (qg_mfma_bk(LA, LB) && (int64_t)mn * d->K <= (1ll << 17) - 1)
+            kernel = (LA == 1 && LB == 1) ? QG_KERNEL_MFMA_I8 : QG_KERNEL_MFMA_I8_LIMB;
+        else {
+            LA = LB = 0;
+            snprintf(info->reason, sizeof info->reason, "linear class, but limbs/K outside the MFMA kernel's exact range: tree kernel");
+        }
+    }
+    pc->M = d->M;
+    pc->N = d->N;
+    pc->parts = parts;
+    pc->cbytes = pow2_bytes(sbits(d->c));
+    pc->ldc = d->M;
+    pc->elem_bytes = hc->size;
+    for (int p = 0; p < 2; ++p) { pc->off[p] = hc->off[p]; pc->sb[p] = hc->sb[p]; }
+    if (kernel != QG_KERNEL_NONE) {
+        const int bk = qg_mfma_bk(LA, LB);
+        *pa = QPackedGeom{round_up(d->M, QG_MFMA_TM), round_up(d->K, bk), 1, LA};
+        *pb = QPackedGeom{round_up(d->N, QG_MFMA_TN), round_up(d->K, bk), 1, LB};
+        pc->Mp = pa->rows_p;
+        pc->Np = pb->rows_p;
+    } else {
+        kernel = d->is_complex ? QG_KERNEL_TREE_CPLX : QG_KERNEL_TREE_I64;
+        *pa = QPackedGeom{d->M, d->K, info->in_bits[0] <= 32 ? 4 : 8, 0};
+        *pb = QPackedGeom{d->N, d->K, info->in_bits[1] <= 32 ? 4 : 8, 0};
+        pc->Mp = d->M;
+        pc->Np = d->N;
+    }
+    info->kernel = kernel;
+    info->limbs[0] = LA;
+    info->limbs[1] = LB;
+    info->packed_bytes[0] = (int64_t)parts * (pa->limbs ? pa->limbs : 1) * pa->rows_p * pa->K_p * pa->cbytes;
+    info->packed_bytes[1] = (int64_t)parts * (pb->limbs ? pb->limbs : 1) * pb->rows_p * pb->K_p * pb->cbytes;
+    info->packed_bytes[2] = (int64_t)parts * pc->Mp * pc->Np * pc->cbytes;
+    *pLA = LA;
+    *pLB = LB;
+    return QG_OK;
+}
+
+extern "C" {
+
+uint32_t qgemul_abi_version(void) { return QGEMUL_ABI_VERSION; }
+int qgemul_last_hip_error(void) { return g_last_hip; }
+
+const char* qgemul_strerror(int st)
+{
+    switch (st) {
+    case QG_OK: return "ok";
+    case QG_EINVAL: return "invalid descriptor or argument";
+    case QG_EUNSUPPORTED: return "descriptor outside the engine's supported range";
+    case QG_EHIP: return "HIP runtime error";
+    case QG_ERCCL: return "RCCL error";
+    case QG_ERANGE: return "input raw value outside its declared format";
+    case QG_ENOGPU: return "no gfx950 device: the engine has no CPU fallback";
+    default: return "unknown status";
+    }
+}
+
+int qgemul_classify(const qgemul_desc* d, uint32_t opt_flags, qgemul_info* out)
+{
+    if (!d || !out) return QG_EINVAL;
+    QAnalysis* an = new (std::nothrow) QAnalysis;
+    if (!an) return QG_EINVAL;
+    int LA, LB;
+    QPackedGeom pa, pb;
+    QCGeom pc;
+    QHostElem ha, hb, hc;
+    int st = plan_geometry(d, opt_flags, an, out, &LA, &LB, &pa, &pb, &pc, &ha, &hb, &hc);
+    delete an;
+    return st;
+}
+
+int qgemul_ctx_create(int device, qgemul_ctx** out)
+{
+    if (!out) return QG_EINVAL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return QG_ENOGPU;
+    if (device < 0) QG_HIP(hipGetDevice(&device));
+    if (device >= n) return QG_EINVAL;
+    QG_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    QG_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return QG_ENOGPU; // kernels exist for gfx950 only
+    qgemul_ctx* c = (qgemul_ctx*)calloc(1, sizeof *c);
+    if (!c) return QG_EINVAL;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { free(c); return QG_EHIP; }
+    if (hipMalloc((void**)&c->flag_dev, 64) != hipSuccess) { hipStreamDestroy(c->stream); free(c); return QG_EHIP; }
+    hipMemsetAsync(c->flag_dev, 0, 64, c->stream);
+    *out = c;
+    return QG_OK;
+}
+
+void qgemul_ctx_destroy(qgemul_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    hipFree(c->flag_dev);
+    hipStreamDestroy(c->stream);
+    free(c);
+}
+
+int qgemul_ctx_sync(qgemul_ctx* c)
+{
+    if (!c) return QG_EINVAL;
+    QG_HIP(hipStreamSynchronize(c->stream));
+    return QG_OK;
+}
+
+void* qgemul_ctx_stream(qgemul_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int qgemul_dev_alloc(qgemul_ctx* c, size_t bytes, void** out)
+{
+    if (!c || !out) return QG_EINVAL;
+    QG_HIP(hipSetDevice(c->device));
+    QG_HIP(hipMalloc(out, bytes ? bytes : 16));
+    return QG_OK;
+}
+int qgemul_dev_free(qgemul_ctx* c, void* p)
+{
+    if (!c) return QG_EINVAL;
+    QG_HIP(hipStreamSynchronize(c->stream));
+    QG_HIP(hipFree(p));
+    return QG_OK;
+}
+int qgemul_memcpy_h2d(qgemul_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c) return QG_EINVAL;
+    if (!bytes) return QG_OK;
+    QG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    QG_HIP(hipStreamSynchronize(c->stream));
+    return QG_OK;
+}
+int qgemul_memcpy_d2h(qgemul_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c) return QG_EINVAL;
+    if (!bytes) return QG_OK;
+    QG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    QG_HIP(hipStreamSynchronize(c->stream));
+    return QG_OK;
+}
+
+int qgemul_plan_create(qgemul_ctx* c, const qgemul_desc* d, uint32_t opt_flags, qgemul_plan** out)
+{
+    if (!c || !d || !out) return QG_EINVAL;
+    qgemul_plan* p = new (std::nothrow) qgemul_plan;
+    if (!p) return QG_EINVAL;
+    memset(p, 0, sizeof *p);
+    p->ctx = c;
+    p->desc = *d;
+    p->flags = opt_flags;
+    int st = plan_geometry(d, opt_flags, &p->an, &p->info, &p->LA, &p->LB, &p->pa, &p->pb, &p->pc, &p->ha, &p->hb, &p->hc);
+    if (st != QG_OK) { delete p; return st; }
+    if (hipSetDevice(c->device) != hipSuccess || hipMalloc((void**)&p->dev_table, sizeof(QTreeTable)) != hipSuccess) {
+        delete p;
+        return QG_EHIP;
+    }
+    if (hipMemcpyAsync(p->dev_table, &p->an.tree, sizeof(QTreeTable), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+        hipFree(p->dev_table);
+        delete p;
+        return QG_EHIP;
+    }
+    *out = p;
+    return QG_OK;
+}
+
+void qgemul_plan_destroy(qgemul_plan* p)
+{
+    if (!p) return;
+    hipStreamSynchronize(p->ctx->stream);
+    hipFree(p->dev_table);
+    delete p;
+}
+
+int qgemul_plan_info(const qgemul_plan* p, qgemul_info* out)
+{
+    if (!p || !out) return QG_EINVAL;
+    *out = p->info;
+    return QG_OK;
+}
+
+static QOperandGeom operand_geom(const qgemul_plan* p, int operand, int64_t ld)
+{
+    const qgemul_desc& d = p->desc;
+    QOperandGeom g;
+    memset(&g, 0, sizeof g);
+    const QHostElem& h = operand == QG_OPERAND_A ? p->ha : p->hb;
+    const qfmt* f = operand == QG_OPERAND_A ? d.a : d.b;
+    g.K = d.K;
+    g.parts = d.is_complex ? 2 : 1;
+    g.elem_bytes = h.size;
+    for (int q = 0; q < 2; ++q) {
+        g.off[q] = h.off[q];
+        g.sb[q] = h.sb[q];
+        g.W[q] = (int)f[q].I + (int)f[q].F;
+        g.S[q] = f[q].S;
+    }
+    if (operand == QG_OPERAND_A) {
+        g.rows = d.M;
+        if (d.transA) { g.rs = ld ? ld : d.K; g.ks = 1; }   // A declared dim<K,M>: (i,k) at k + i*ld
+        else { g.rs = 1; g.ks = ld ? ld : d.M; }            // A declared dim<M,K>: (i,k) at i + k*ld
+    } else {
+        g.rows = d.N;
+        g.rs = ld ? ld : d.K;                                // B declared dim<K,N>: (k,j) at k + j*ld
+        g.ks = 1;
+    }
+    return g;
+}
+
+int qgemul_pack(qgemul_plan* p, int operand, const void* src_dev, int64_t ld, void* packed_dev)
+{
+    if (!p || !src_dev || !packed_dev || (operand != QG_OPERAND_A && operand != QG_OPERAND_B)) return QG_EINVAL;
+    QOperandGeom g = operand_geom(p, operand, ld);
+    const QPackedGeom& pg = operand == QG_OPERAND_A ? p->pa : p->pb;
+    const int check = (p->flags & QG_OPT_CHECK_RANGE) ? 1 : 0;
+    if (check) QG_HIP(hipMemsetAsync(p->ctx->flag_dev, 0, 4, p->ctx->stream));
+    QG_HIP(qg_launch_pack(g, pg, src_dev, packed_dev, check, p->ctx->flag_dev, p->ctx->stream));
+    if (check) {
+        int flag = 0;
+        QG_HIP(hipMemcpyAsync(&flag, p->ctx->flag_dev, 4, hipMemcpyDeviceToHost, p->ctx->stream));
+        QG_HIP(hipStreamSynchronize(p->ctx->stream));
+        if (flag) return QG_ERANGE;
+    }
+    return QG_OK;
+}
+
+int qgemul_fill_packed(qgemul_plan* p, int operand, uint64_t seed, int dist, void* packed_dev)
+{
+    if (!p || !packed_dev || (operand != QG_OPERAND_A && operand != QG_OPERAND_B)) return QG_EINVAL;
+    QOperandGeom g = operand_geom(p, operand, 0);
+    const QPackedGeom& pg = operand == QG_OPERAND_A ? p->pa : p->pb;
+    QG_HIP(qg_launch_fill(g, pg, seed, dist, packed_dev, p->ctx->stream));
+    return QG_OK;
+}
+
+int qgemul_unpack_c(qgemul_plan* p, const void* packed_dev, void* dst_dev, int64_t ld)
+{
+    if (!p || !packed_dev || !dst_dev) return QG_EINVAL;
+    QCGeom c = p->pc;
+    c.ldc = ld ? ld : p->desc.M;
+    QG_HIP(qg_launch_unpack_c(c, packed_dev, dst_dev, p->ctx->stream));
+    return QG_OK;
+}
+
+int qgemul_execute(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB)
+{
+    if (!p || !packedC || !packedA || !packedB) return QG_EINVAL;
+    if (p->desc.M == 0 || p->desc.N == 0) return QG_OK;
+    hipStream_t st = p->ctx->stream;
+    switch (p->info.kernel) {
+    case QG_KERNEL_MFMA_I8:
+    case QG_KERNEL_MFMA_I8_LIMB: {
+        QMfmaArgs a;
+        a.A = (const int8_t*)packedA;
+        a.B = (const int8_t*)packedB;
+        a.C = packedC;
+        a.Mp = p->pa.rows_p;
+        a.Np = p->pb.rows_p;
+        a.Kp = p->pa.K_p;
+        a.cbytes = p->pc.cbytes;
+        a.to_c = p->an.lin.to_c[0];
+        QG_HIP(qg_launch_mfma(p->LA, p->LB, a, st));
+        return QG_OK;
+    }
+    case QG_KERNEL_TREE_I32:
+    case QG_KERNEL_TREE_I64:
+    case QG_KERNEL_TREE_CPLX:
+        QG_HIP(qg_launch_tree_generic(p->dev_table, p->desc.is_complex ? 2 : 1, packedA, packedB, packedC, p->desc.M, p->desc.N,
+                                      p->desc.K, p->pa, p->pb, p->pc, st));
+        return QG_OK;
+    default:
+        return QG_EUNSUPPORTED;
+    }
+}
+
+int qgemul_time_execute(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB, int warmup, int iters,
+                        float* avg_ms)
+{
+    if (!p || !avg_ms || iters < 1) return QG_EINVAL;
+    hipStream_t st = p->ctx->stream;
+    for (int i = 0; i < warmup; ++i) {
+        int s = qgemul_execute(p, packedC, packedA, packedB);
+        if (s) return s;
+    }
+    hipEvent_t e0, e1;
+    QG_HIP(hipEventCreate(&e0));
+    QG_HIP(hipEventCreate(&e1));
+    QG_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) {
+        int s = qgemul_execute(p, packedC, packedA, packedB);
+        if (s) return s;
+    }
+    QG_HIP(hipEventRecord(e1, st));
+    QG_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    QG_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *avg_ms = ms / (float)iters;
+    return QG_OK;
+}
+
+int qgemul_run(const qgemul_desc* d, void* C, const void* A, const void* B, const qgemul_opts* o)
+{
+    if (!d || !C || !A || !B) return QG_EINVAL;
+    qgemul_opts opts;
+    memset(&opts, 0, sizeof opts);
+    opts.device = -1;
+    if (o) opts = *o;
+    // validate before touching the device so that descriptor errors are reported without a GPU
+    {
+        qgemul_info info;
+        int st = qgemul_classify(d, opts.flags, &info);
+        if (st != QG_OK) return st;
+    }
+    if (d->M == 0 || d->N == 0) return QG_OK;
+    qgemul_ctx* ctx = nullptr;
+    int st = qgemul_ctx_create(opts.device, &ctx);
+    if (st != QG_OK) return st;
+    qgemul_plan* p = nullptr;
+    void *dA = nullptr, *dB = nullptr, *dC = nullptr, *pA = nullptr, *pB = nullptr, *pC = nullptr;
+    do {
+        st = qgemul_plan_create(ctx, d, opts.flags, &p);
+        if (st) break;
+        const int64_t lda = opts.lda ? opts.lda : (d->transA ? d->K : d->M);
+        const int64_t ldb = opts.ldb ? opts.ldb : d->K;
+        const int64_t ldc = opts.ldc ? opts.ldc : d->M;
+        if (lda < (d->transA ? d->K : d->M) || ldb < d->K || ldc < d->M) { st = QG_EINVAL; break; }
+        const size_t bytesA = (size_t)(((d->transA ? d->M : d->K) - 1) * lda + (d->transA ? d->K : d->M)) * p->ha.size;
+        const size_t bytesB = (size_t)((d->N - 1) * ldb + d->K) * p->hb.size;
+        const size_t bytesC = (size_t)((d->N - 1) * ldc + d->M) * p->hc.size;
+        if ((st = qgemul_dev_alloc(ctx, bytesA, &dA)) || (st = qgemul_dev_alloc(ctx, bytesB, &dB)) ||
+            (st = qgemul_dev_alloc(ctx, bytesC, &dC)) || (st = qgemul_dev_alloc(ctx, (size_t)p->info.packed_bytes[0], &pA)) ||
+            (st = qgemul_dev_alloc(ctx, (size_t)p->info.packed_bytes[1], &pB)) ||
+            (st = qgemul_dev_alloc(ctx, (size_t)p->info.packed_bytes[2], &pC)))
+            break;
+        if ((st = qgemul_memcpy_h2d(ctx, dA, A, bytesA)) || (st = qgemul_memcpy_h2d(ctx, dB, B, bytesB))) break;
+        // the caller's C may have padding between columns (ldc > M): keep those bytes as they are
+        if (ldc != d->M && (st = qgemul_memcpy_h2d(ctx, dC, C, bytesC))) break;
+        if ((st = qgemul_pack(p, QG_OPERAND_A, dA, lda, pA)) || (st = qgemul_pack(p, QG_OPERAND_B, dB, ldb, pB))) break;
+        if ((st = qgemul_execute(p, pC, pA, pB))) break;
+        if ((st = qgemul_unpack_c(p, pC, dC, ldc))) break;
+        if ((st = qgemul_memcpy_d2h(ctx, C, dC, bytesC))) break;
+    } while (0);
+    if (ctx) hipStreamSynchronize(ctx->stream);
+    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(pA); hipFree(pB); hipFree(pC);
+    qgemul_plan_destroy(p);
+    qgemul_ctx_destroy(ctx);
+    return st;
+}
+
+} // extern "C"

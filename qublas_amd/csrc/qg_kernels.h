@@ -1,0 +1,57 @@
+// qg_kernels.h — launch interface between the C-ABI layer (qg_api.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qg_plan.h"
+
+// geometry of one operand in host (reference) layout as seen by pack / fill / unpack kernels
+struct QOperandGeom {
+    int64_t rows, K;        // logical rows (M for A, N for B) and reduction length
+    int64_t rs, ks;         // host element index of (r,k) = r*rs + k*ks   (column-major tensors)
+    int32_t elem_bytes;     // host element size (complex: whole struct)
+    int32_t off[2], sb[2];  // byte offset / byte width (4|8) of each part inside the element
+    int32_t parts;          // 1 real, 2 complex
+    int32_t W[2], S[2];     // format of each part (range check, synthetic fill)
+};
+
+// packed (device-private) layouts
+//   tree  : [part][rows_p][K_p] containers of cbytes (4|8), K contiguous
+//   limbs : [part][limb][rows_p][K_p] int8 balanced base-256 digits, K contiguous
+struct QPackedGeom {
+    int64_t rows_p, K_p;    // padded extents
+    int32_t cbytes;         // container bytes (tree layout), 1 for limb layout
+    int32_t limbs;          // 0 = tree layout, >0 = limb layout
+};
+
+struct QCGeom {
+    int64_t M, N, Mp, Np;   // logical / padded extents of packed C, row-major [part][Mp][Np]
+    int32_t cbytes;         // 1|2|4|8 container
+    int32_t parts;
+    int64_t ldc;            // host leading dimension (elements)
+    int32_t elem_bytes, off[2], sb[2];
+};
+
+hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const void* src, void* dst, int check_range,
+                          int* range_flag, hipStream_t st);
+hipError_t qg_launch_fill(const QOperandGeom& g, const QPackedGeom& p, uint64_t seed, int dist, void* dst, hipStream_t st);
+hipError_t qg_launch_unpack_c(const QCGeom& c, const void* packed, void* dst, hipStream_t st);
+
+// exact tree evaluation, any descriptor (real / complex, any K), 64-bit arithmetic
+hipError_t qg_launch_tree_generic(const QTreeTable* dev_table, int parts, const void* A, const void* B, void* C, int64_t M,
+                                  int64_t N, int64_t K, const QPackedGeom& pa, const QPackedGeom& pb, const QCGeom& pc,
+                                  hipStream_t st);
+
+// linear class on int8 MFMA with LA x LB limbs; returns hipErrorInvalidValue if no instantiation
+struct QMfmaArgs {
+    const int8_t* A;  // [LA][Mp][Kp]
+    const int8_t* B;  // [LB][Np][Kp]
+    void* C;          // [Mp][Np] containers
+    int64_t Mp, Np, Kp;
+    int32_t cbytes;
+    QStep to_c;
+};
+hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st);
+// tile sizes the MFMA path pads to
+enum { QG_MFMA_TM = 128, QG_MFMA_TN = 128 };
+int qg_mfma_bk(int LA, int LB); // k-tile in bytes for a limb combination (0 = unsupported)

@@ -1,0 +1,223 @@
+// qg_mfma.hip — the linear class ("class L") on the gfx950 matrix cores.
+//
+// When every intermediate conversion of the reference expression is provably the identity, the
+// whole tree equals the exact integer dot product and ONE round + overflow into C's format is
+// the entire epilogue (converting constructor, /root/reference/include/QuBLAS.h:2398-2411).  The dot product runs on
+// v_mfma_i32_32x32x32_i8.  Operands wider than 8 storage bits are split on the host-facing pack
+// step into balanced base-256 int8 limbs (x = sum_l d_l * 256^l, d_l in [-128,127]); the kernel
+// then issues LA*LB MFMAs per k-step into LA+LB-1 int32 accumulators, one per limb weight, and
+// recombines them in 64-bit in the epilogue.  int32 accumulation is exact: |d*d'| <= 2^14 and
+// the planner bounds K * min(LA,LB) <= 2^17.
+//
+// Tiling (wave64, CDNA4): 128x128 output tile per 256-thread workgroup, 2x2 waves of 64x64, each
+// wave 2x2 MFMA tiles of 32x32.  A and B k-tiles are copied HBM -> LDS with
+// global_load_lds_dwordx4 (16 B per lane, no VGPR round trip) into a double-buffered LDS image
+// whose 16-byte chunks are XOR-swizzled on the SOURCE address (the LDS-DMA destination is
+// lane-linear) so that the ds_read_b128 fragment reads are bank-conflict free.
+#include <hip/hip_runtime.h>
+
+#include "qg_kernels.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+#define QG_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define QG_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+constexpr int TM = QG_MFMA_TM, TN = QG_MFMA_TN;
+
+// LDS image of one k-tile: rows of BK bytes; chunk c (16 B) of row r is stored at slot c ^ swz(r).
+// swz(r) = (r / rows_per_bank_row) % chunks_per_row makes the 16 lanes of every ds_read_b128 group
+// of a 32x32x32 fragment read (rows l&31, one chunk column) land on 16 distinct 16-byte bank slots.
+template <int BK>
+__device__ __forceinline__ int swz(int r)
+{
+    constexpr int CPR = BK / 16;   // chunks per row
+    constexpr int RPB = 256 / BK;  // rows per 256-byte bank row
+    return (r / RPB) % CPR;
+}
+
+__device__ __forceinline__ void store_c(char* C, int64_t idx, int cbytes, int64_t v)
+{
+    switch (cbytes) {
+    case 1: ((int8_t*)C)[idx] = (int8_t)v; break;
+    case 2: ((int16_t*)C)[idx] = (int16_t)v; break;
+    case 4: ((int32_t*)C)[idx] = (int32_t)v; break;
+    default: ((int64_t*)C)[idx] = v; break;
+    }
+}
+
+template <int LA, int LB, int BK>
+__global__ __launch_bounds__(256) void k_mfma(QMfmaArgs g)
+{
+    constexpr int NW = LA + LB - 1;            // limb weights
+    constexpr int ROWS = LA * TM + LB * TN;    // LDS rows per stage
+    constexpr int STAGE = ROWS * BK;           // bytes per stage
+    constexpr int PIECES = STAGE / 1024;       // 1-KiB LDS-DMA pieces per stage
+    constexpr int RPP = 1024 / BK;             // rows per piece
+    constexpr int CPR = BK / 16;
+    constexpr int KSTEPS = BK / 32;            // MFMA k-steps per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware tile order: consecutive block ids go to different XCDs, so give each XCD a
+    // contiguous run of tiles, walked in column-major groups of 8 tile-rows for L2 reuse.
+    const int tiles_m = (int)(g.Mp / TM), tiles_n = (int)(g.Np / TN);
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+    }
+    constexpr int GM = 8;
+    const int grp = bid / (GM * tiles_n);
+    const int first_m = grp * GM;
+    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int tile_m = first_m + (bid % (GM * tiles_n)) % gsz;
+    const int tile_n = (bid % (GM * tiles_n)) / gsz;
+
+    const int8_t* Ag = g.A + (int64_t)tile_m * TM * g.Kp;
+    const int8_t* Bg = g.B + (int64_t)tile_n * TN * g.Kp;
+    const int64_t planeA = g.Mp * g.Kp, planeB = g.Np * g.Kp;
+
+    // per-lane source geometry of the LDS-DMA pieces this wave issues: piece p covers LDS rows
+    // [p*RPP, (p+1)*RPP); lane i fills slot (i % CPR) of row p*RPP + i/CPR
+    const int prow = lane / CPR, pslot = lane % CPR;
+
+    auto issue = [&](int stage, int kt) {
+        char* sbase = smem + stage * STAGE;
+#pragma unroll
+        for (int pi = 0; pi < PIECES / 4; ++pi) {
+            const int p = wave + 4 * pi;            // wave-uniform piece id
+            const int R = p * RPP + prow;           // LDS row of this lane
+            const int8_t* src;
+            int rl;
+            if (R < LA * TM) {
+                const int limb = R / TM;
+                rl = R % TM;
+                src = Ag + limb * planeA + (int64_t)rl * g.Kp;
+            } else {
+                const int R2 = R - LA * TM;
+                const int limb = R2 / TN;
+                rl = R2 % TN;
+                src = Bg + limb * planeB + (int64_t)rl * g.Kp;
+            }
+            const int chunk = pslot ^ swz<BK>(rl);
+            src += (int64_t)kt * BK + chunk * 16;
+            __builtin_amdgcn_global_load_lds(QG_GLOBAL_PTR(src), QG_LDS_PTR(sbase + p * 1024), 16, 0, 0);
+        }
+    };
+
+    v16i acc[NW][2][2];
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[w][i][j][e] = 0;
+
+    const int nk = (int)(g.Kp / BK);
+    const int fr = lane & 31, fh = lane >> 5;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) issue(cur ^ 1, kt + 1);
+        const char* sA = smem + cur * STAGE;
+        const char* sB = sA + LA * TM * BK;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            v4i a[LA][2], b[LB][2];
+            const int c = 2 * ks + fh;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ra = wm * 64 + i * 32 + fr;
+                const int rb = wn * 64 + i * 32 + fr;
+#pragma unroll
+                for (int l = 0; l < LA; ++l)
+                    a[l][i] = *(const v4i*)(sA + (l * TM + ra) * BK + ((c ^ swz<BK>(ra)) * 16));
+#pragma unroll
+                for (int l = 0; l < LB; ++l)
+                    b[l][i] = *(const v4i*)(sB + (l * TN + rb) * BK + ((c ^ swz<BK>(rb)) * 16));
+            }
+#pragma unroll
+            for (int la = 0; la < LA; ++la)
+#pragma unroll
+                for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[la + lb][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[la][i], b[lb][j], acc[la + lb][i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue: recombine limb weights in 64-bit, one round + overflow into C, store the container.
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
+    const QStep st = g.to_c;
+    char* C = (char*)g.C;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int64_t s = 0;
+#pragma unroll
+                for (int w = NW - 1; w >= 0; --w) s = s * 256 + (int64_t)acc[w][i][j][e];
+                const int64_t row = (int64_t)tile_m * TM + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                const int64_t col = (int64_t)tile_n * TN + wn * 64 + j * 32 + fr;
+                store_c(C, row * g.Np + col, g.cbytes, qg_step<int64_t>(s, st));
+            }
+}
+
+template <int LA, int LB, int BK>
+hipError_t launch(const QMfmaArgs& a, hipStream_t st)
+{
+    constexpr int STAGE = (LA * TM + LB * TN) * BK;
+    static_assert(STAGE % 4096 == 0, "stage must be a whole number of pieces per wave");
+    const int lds = 2 * STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_mfma<LA, LB, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int64_t blocks = (a.Mp / TM) * (a.Np / TN);
+    if (blocks <= 0) return hipSuccess;
+    if (blocks > 0x7fffffffll || a.Kp % BK || a.Mp % TM || a.Np % TN) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_mfma<LA, LB, BK>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+} // namespace
+
+int qg_mfma_bk(int LA, int LB)
+{
+    if (LA < 1 || LB < 1 || LA > 3 || LB > 3) return 0;
+    return (LA == 1 && LB == 1) ? 128 : 64;
+}
+
+hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
+{
+    switch (LA * 10 + LB) {
+    case 11: return launch<1, 1, 128>(a, st);
+    case 12: return launch<1, 2, 64>(a, st);
+    case 21: return launch<2, 1, 64>(a, st);
+    case 22: return launch<2, 2, 64>(a, st);
+    case 13: return launch<1, 3, 64>(a, st);
+    case 31: return launch<3, 1, 64>(a, st);
+    case 23: return launch<2, 3, 64>(a, st);
+    case 32: return launch<3, 2, 64>(a, st);
+    case 33: return launch<3, 3, 64>(a, st);
+    default: return hipErrorInvalidValue;
+    }
+}

@@ -1,0 +1,153 @@
+// qg_pack.hip — layout kernels (gfx950): reference-layout tensors <-> device-private packed
+// operands, synthetic operand generation, packed C -> reference layout.
+//
+// Reference layout (what Qu<dim<…>,T>::data.data() holds): column-major array of int32/int64
+// raw values, complex = struct {real; imag;}  (/root/reference/include/QuBLAS.h:2680-2692,
+// :353, :2512-2513).  All of these are HBM-bound byte movers; they are not on the timed path
+// (operands are packed once and stay resident), so they are written for coalescing, not more.
+#include <hip/hip_runtime.h>
+
+#include "qg_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ int64_t load_host_part(const char* src, int64_t e, int elem_bytes, int off, int sb)
+{
+    const char* p = src + e * elem_bytes + off;
+    return sb == 4 ? (int64_t)(*(const int32_t*)p) : *(const int64_t*)p;
+}
+
+__device__ __forceinline__ void store_container(char* dst, int64_t idx, int cbytes, int64_t v)
+{
+    switch (cbytes) {
+    case 1: ((int8_t*)dst)[idx] = (int8_t)v; break;
+    case 2: ((int16_t*)dst)[idx] = (int16_t)v; break;
+    case 4: ((int32_t*)dst)[idx] = (int32_t)v; break;
+    default: ((int64_t*)dst)[idx] = v; break;
+    }
+}
+
+__device__ __forceinline__ int64_t load_container(const char* src, int64_t idx, int cbytes)
+{
+    switch (cbytes) {
+    case 1: return ((const int8_t*)src)[idx];
+    case 2: return ((const int16_t*)src)[idx];
+    case 4: return ((const int32_t*)src)[idx];
+    default: return ((const int64_t*)src)[idx];
+    }
+}
+
+// write one logical value (r,k,part) into the packed operand
+__device__ __forceinline__ void put_packed(const QPackedGeom& p, char* dst, int part, int64_t r, int64_t k, int64_t v)
+{
+    if (p.limbs == 0) {
+        store_container(dst, ((int64_t)part * p.rows_p + r) * p.K_p + k, p.cbytes, v);
+    } else {
+        for (int l = 0; l < p.limbs; ++l) {
+            int64_t d = (int64_t)(int8_t)(v & 0xff); // balanced digit in [-128,127]
+            ((int8_t*)dst)[(((int64_t)part * p.limbs + l) * p.rows_p + r) * p.K_p + k] = (int8_t)d;
+            v = (v - d) >> 8;
+        }
+    }
+}
+
+// tile = 64 (k) x 64 (r); 256 threads.  The fast host axis is r when g.rs == 1 (non-transposed A)
+// and k otherwise; global reads follow the fast host axis, packed writes always follow k.
+__global__ __launch_bounds__(256) void k_pack(QOperandGeom g, QPackedGeom p, const char* __restrict__ src, char* __restrict__ dst,
+                                              int check, int* flag, int fill, uint64_t seed, int dist)
+{
+    __shared__ int64_t tile[64][65];
+    const int64_t kt = (p.K_p + 63) / 64, rt = (p.rows_p + 63) / 64;
+    int64_t b = blockIdx.x;
+    const int64_t tk = b % kt; b /= kt;
+    const int64_t tr = b % rt; b /= rt;
+    const int part = (int)b;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6; // 64 x 4
+    const bool r_fast = (g.rs == 1 && g.ks != 1);
+    const int W = g.W[part], S = g.S[part];
+    const int64_t lo = S ? -((int64_t)1 << W) : 0, hi = ((int64_t)1 << W) - 1;
+    bool bad = false;
+    for (int i = ty; i < 64; i += 4) {
+        // (a,b) = (fast index, slow index) inside the tile
+        int64_t r = tr * 64 + (r_fast ? tx : i);
+        int64_t k = tk * 64 + (r_fast ? i : tx);
+        int64_t v = 0;
+        if (r < g.rows && k < g.K) {
+            if (fill) {
+                // tight host linear index of the element, as a host-side fill of the tensor would see it
+                v = qg_synth(W, S, seed, dist, (uint64_t)(r * g.rs + k * g.ks), part);
+            } else {
+                v = load_host_part(src, r * g.rs + k * g.ks, g.elem_bytes, g.off[part], g.sb[part]);
+                if (check && (v < lo || v > hi)) bad = true;
+            }
+        }
+        if (r_fast) tile[i][tx] = v;  // tile[k_local][r_local]
+        else tile[tx][i] = v;         // tile[k_local][r_local] with tx = k_local
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        int64_t r = tr * 64 + i, k = tk * 64 + tx;
+        if (r < p.rows_p && k < p.K_p) put_packed(p, dst, part, r, k, tile[tx][i]);
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
+// packed C [part][Mp][Np] (n contiguous) -> host column-major (i contiguous)
+__global__ __launch_bounds__(256) void k_unpack_c(QCGeom c, const char* __restrict__ packed, char* __restrict__ dst)
+{
+    __shared__ int64_t tile[64][65];
+    const int64_t nt = (c.N + 63) / 64, mt = (c.M + 63) / 64;
+    int64_t b = blockIdx.x;
+    const int64_t tn = b % nt; b /= nt;
+    const int64_t tm = b % mt; b /= mt;
+    const int part = (int)b;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        int64_t m = tm * 64 + i, n = tn * 64 + tx;
+        int64_t v = 0;
+        if (m < c.M && n < c.N) v = load_container(packed, ((int64_t)part * c.Mp + m) * c.Np + n, c.cbytes);
+        tile[i][tx] = v; // tile[m_local][n_local]
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        int64_t m = tm * 64 + tx, n = tn * 64 + i;
+        if (m < c.M && n < c.N) {
+            char* q = dst + (m + n * c.ldc) * c.elem_bytes + c.off[part];
+            int64_t v = tile[tx][i];
+            if (c.sb[part] == 4) *(int32_t*)q = (int32_t)v;
+            else *(int64_t*)q = v;
+        }
+    }
+}
+
+} // namespace
+
+hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const void* src, void* dst, int check_range,
+                          int* range_flag, hipStream_t st)
+{
+    int64_t blocks = ((p.K_p + 63) / 64) * ((p.rows_p + 63) / 64) * g.parts;
+    if (blocks <= 0) return hipSuccess;
+    if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)blocks), dim3(256), 0, st, g, p, (const char*)src, (char*)dst, check_range,
+                       range_flag, 0, 0ull, 0);
+    return hipGetLastError();
+}
+
+hipError_t qg_launch_fill(const QOperandGeom& g, const QPackedGeom& p, uint64_t seed, int dist, void* dst, hipStream_t st)
+{
+    int64_t blocks = ((p.K_p + 63) / 64) * ((p.rows_p + 63) / 64) * g.parts;
+    if (blocks <= 0) return hipSuccess;
+    if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)blocks), dim3(256), 0, st, g, p, (const char*)nullptr, (char*)dst, 0,
+                       (int*)nullptr, 1, seed, dist);
+    return hipGetLastError();
+}
+
+hipError_t qg_launch_unpack_c(const QCGeom& c, const void* packed, void* dst, hipStream_t st)
+{
+    int64_t blocks = ((c.N + 63) / 64) * ((c.M + 63) / 64) * c.parts;
+    if (blocks <= 0) return hipSuccess;
+    if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_unpack_c, dim3((unsigned)blocks), dim3(256), 0, st, c, (const char*)packed, (char*)dst);
+    return hipGetLastError();
+}

@@ -1,0 +1,325 @@
+// qg_plan.cpp — descriptor analysis (host only).  See qg_plan.h.
+#include "qg_plan.h"
+
+#include <stdio.h>
+#include <string.h>
+
+typedef __int128 I128;
+
+namespace {
+
+struct Rng {
+    I128 lo, hi;
+};
+
+int bits_of(I128 v)
+{
+    // signed width of v
+    unsigned __int128 u = v < 0 ? (unsigned __int128)(~v) : (unsigned __int128)v;
+    int n = 0;
+    while (u) { ++n; u >>= 1; }
+    return n + 1;
+}
+
+struct Ctx {
+    QAnalysis* out;
+    bool exact = true;      // every step so far was the identity
+    int max_bits = 1;
+    void fail(int st, const char* why)
+    {
+        if (out->status == QG_OK) {
+            out->status = st;
+            snprintf(out->reason, sizeof out->reason, "%s", why);
+        }
+    }
+    void note(Rng r)
+    {
+        int b = bits_of(r.lo), c = bits_of(r.hi);
+        if (b > max_bits) max_bits = b;
+        if (c > max_bits) max_bits = c;
+    }
+};
+
+bool same(qfmt a, qfmt b) { return a.I == b.I && a.F == b.F && a.S == b.S && a.Q == b.Q && a.O == b.O; }
+
+bool fmt_ok(Ctx& c, qfmt f)
+{
+    int W = (int)f.I + (int)f.F;
+    if (W < 0) { c.fail(QG_EINVAL, "intBits + fracBits < 0"); return false; }
+    if (f.Q > QG_TRN_SMGN) { c.fail(QG_EINVAL, "unknown QuMode code"); return false; }
+    if (f.O == QG_WRP_TCPL_SAT) { c.fail(QG_EUNSUPPORTED, "WRP::TCPL_SAT is a stub in the reference"); return false; }
+    if (f.O > QG_WRP_TCPL_SAT) { c.fail(QG_EINVAL, "unknown OfMode code"); return false; }
+    if (W > 61) { c.fail(QG_EUNSUPPORTED, "format wider than 62 storage bits"); return false; }
+    return true;
+}
+
+Rng fmt_range(qfmt f)
+{
+    int W = (int)f.I + (int)f.F;
+    Rng r;
+    r.hi = ((I128)1 << W) - 1;
+    r.lo = f.S ? -((I128)1 << W) : 0;
+    return r;
+}
+
+QStep make_step(int fromF, qfmt to, bool identity)
+{
+    QStep s;
+    memset(&s, 0, sizeof s);
+    s.d = fromF - (int)to.F;
+    s.Q = to.Q;
+    s.O = to.O;
+    s.W = (int)to.I + (int)to.F;
+    s.S = to.S;
+    s.identity = identity ? 1 : 0;
+    s.hi = (int64_t)(((I128)1 << s.W) - 1);
+    s.lo = to.S ? -(int64_t)((I128)1 << s.W) : 0;
+    return s;
+}
+
+// propagate an exact interval (raw values at frac fromF) through round + overflow into `to`
+Rng through(Ctx& c, Rng in, int fromF, qfmt to, bool identity)
+{
+    c.note(in);
+    if (identity) return in;
+    int d = fromF - (int)to.F;
+    Rng r = in;
+    if (d <= 0) {
+        if (-d > 100) { c.fail(QG_EUNSUPPORTED, "left shift beyond 100 bits"); return in; }
+        r.lo = in.lo * ((I128)1 << -d);
+        r.hi = in.hi * ((I128)1 << -d);
+        c.note(r);
+    } else {
+        if (d > 61) { c.fail(QG_EUNSUPPORTED, "rounding shift beyond 61 bits"); return in; }
+        if ((d == 32 || d == 64) && to.Q <= QG_RND_CONV)
+            c.fail(QG_EUNSUPPORTED, "RND over a 32/64-bit shift: reference result is an ArbiInt<32>::allOnes artefact");
+        c.exact = false;
+        r.lo = in.lo >> d;
+        r.hi = (in.hi >> d) + 1;
+    }
+    Rng R = fmt_range(to);
+    Rng Re = R;
+    if (to.O == QG_SAT_SMGN) Re.lo = to.S ? -R.hi : 0;
+    if (r.lo >= Re.lo && r.hi <= Re.hi) return r; // overflow handling is the identity
+    c.exact = false;
+    switch (to.O) {
+    case QG_SAT_TCPL:
+    case QG_SAT_SMGN:
+        if (r.lo < Re.lo) r.lo = Re.lo;
+        if (r.hi > Re.hi) r.hi = Re.hi;
+        if (r.lo > Re.hi) r.lo = Re.hi;
+        if (r.hi < Re.lo) r.hi = Re.lo;
+        return r;
+    case QG_SAT_ZERO: {
+        Rng q = r;
+        if (q.lo < Re.lo) q.lo = Re.lo;
+        if (q.hi > Re.hi) q.hi = Re.hi;
+        if (q.lo > 0) q.lo = 0;
+        if (q.hi < 0) q.hi = 0;
+        if (q.lo > q.hi) { q.lo = 0; q.hi = 0; }
+        return q;
+    }
+    default:
+        return R; // wrap: anything representable
+    }
+}
+
+Rng mul_rng(Rng a, Rng b)
+{
+    I128 p[4] = {a.lo * b.lo, a.lo * b.hi, a.hi * b.lo, a.hi * b.hi};
+    Rng r = {p[0], p[0]};
+    for (int i = 1; i < 4; ++i) {
+        if (p[i] < r.lo) r.lo = p[i];
+        if (p[i] > r.hi) r.hi = p[i];
+    }
+    return r;
+}
+
+struct Val {
+    Rng r;
+    qfmt f;
+};
+
+Val do_mul(Ctx& c, Val a, Val b, qfmt res, QNode* node)
+{
+    node->sa = node->sb = 0;
+    node->q = make_step((int)a.f.F + (int)b.f.F, res, false);
+    Val v;
+    v.f = res;
+    v.r = through(c, mul_rng(a.r, b.r), (int)a.f.F + (int)b.f.F, res, false);
+    return v;
+}
+
+Val do_addsub(Ctx& c, Val a, Val b, qfmt res, bool sub, QNode* node)
+{
+    int fm = a.f.F > b.f.F ? a.f.F : b.f.F;
+    node->sa = fm - a.f.F;
+    node->sb = fm - b.f.F;
+    node->q = make_step(fm, res, false);
+    Rng x = {a.r.lo * ((I128)1 << node->sa), a.r.hi * ((I128)1 << node->sa)};
+    Rng y = {b.r.lo * ((I128)1 << node->sb), b.r.hi * ((I128)1 << node->sb)};
+    c.note(x);
+    c.note(y);
+    Rng s = sub ? Rng{x.lo - y.hi, x.hi - y.lo} : Rng{x.lo + y.lo, x.hi + y.hi};
+    Val v;
+    v.f = res;
+    v.r = through(c, s, fm, res, false);
+    return v;
+}
+
+Val do_cvt(Ctx& c, Val a, qfmt to, QStep* st)
+{
+    bool id = same(a.f, to);
+    *st = make_step((int)a.f.F, to, id);
+    Val v;
+    v.f = to;
+    v.r = through(c, a.r, (int)a.f.F, to, id);
+    return v;
+}
+
+} // namespace
+
+QHostElem qg_host_elem(const qfmt f[2], int is_complex)
+{
+    QHostElem L;
+    auto sb = [](qfmt q) { return (1 + (int)q.I + (int)q.F) <= 32 ? 4 : 8; };
+    L.sb[0] = sb(f[0]);
+    L.off[0] = 0;
+    if (!is_complex) {
+        L.sb[1] = 0;
+        L.off[1] = 0;
+        L.size = L.sb[0];
+        return L;
+    }
+    L.sb[1] = sb(f[1]);
+    int al = L.sb[0] > L.sb[1] ? L.sb[0] : L.sb[1];
+    L.off[1] = (L.sb[0] + L.sb[1] - 1) / L.sb[1] * L.sb[1];
+    L.size = (L.off[1] + L.sb[1] + al - 1) / al * al;
+    return L;
+}
+
+int qg_limbs_for(qfmt f)
+{
+    // balanced base-256 digits d in [-128,127]; the remainder after peeling n-1 digits is
+    // floor((x + 128) / 256) applied n-1 times, monotone in x, so the extremes decide
+    Rng r = fmt_range(f);
+    for (int n = 1; n <= 8; ++n) {
+        I128 lo = r.lo, hi = r.hi;
+        for (int i = 1; i < n; ++i) {
+            lo = (lo + 128) >> 8;
+            hi = (hi + 128) >> 8;
+        }
+        if (lo >= -128 && hi <= 127) return n;
+    }
+    return 9;
+}
+
+void qg_analyze(const qgemul_desc* d, QAnalysis* out)
+{
+    memset(out, 0, sizeof *out);
+    out->status = QG_OK;
+    Ctx c;
+    c.out = out;
+    if (!d || d->abi != QGEMUL_ABI_VERSION) { c.fail(QG_EINVAL, "null descriptor or ABI mismatch"); return; }
+    if (d->M < 0 || d->N < 0 || d->K < 1) { c.fail(QG_EINVAL, "bad M/N/K"); return; }
+    if (d->M > (1ll << 31) || d->N > (1ll << 31) || d->K > (1ll << 31)) { c.fail(QG_EUNSUPPORTED, "dimension beyond 2^31"); return; }
+    {
+        int64_t len = d->K;
+        uint32_t n = 0;
+        while (len > 1) { len = (len + 1) / 2; ++n; }
+        if (n != d->n_levels || n > QG_MAX_LEVELS) { c.fail(QG_EINVAL, "n_levels != ceil(log2 K)"); return; }
+    }
+    const int cx = d->is_complex ? 1 : 0;
+    const int parts = cx ? 2 : 1;
+    if (cx && d->cmul != QG_CMUL_BASIC && d->cmul != QG_CMUL_TF) { c.fail(QG_EINVAL, "complex descriptor without cmul"); return; }
+    if (!cx && d->cmul != QG_CMUL_NONE) { c.fail(QG_EINVAL, "real descriptor with cmul"); return; }
+
+    QTreeTable& T = out->tree;
+    T.is_complex = cx;
+    T.cmul = d->cmul;
+    T.n_levels = (int)d->n_levels;
+    T.parts = parts;
+
+    for (int p = 0; p < parts; ++p)
+        if (!fmt_ok(c, d->a[p]) || !fmt_ok(c, d->b[p]) || !fmt_ok(c, d->c[p])) return;
+    const int nslots = !cx ? 1 : (d->cmul == QG_CMUL_TF ? 8 : 6);
+    for (int i = 0; i < nslots; ++i)
+        if (!fmt_ok(c, d->mul[i])) return;
+    for (int p = 0; p < parts; ++p)
+        for (uint32_t l = 0; l < d->n_levels; ++l)
+            if (!fmt_ok(c, d->level_add[p][l]) || !fmt_ok(c, d->level[p][l])) return;
+
+    // ---- the product ----
+    Val prod[2];
+    const qfmt* m = d->mul;
+    if (!cx) {
+        Val a = {fmt_range(d->a[0]), d->a[0]}, b = {fmt_range(d->b[0]), d->b[0]};
+        prod[0] = do_mul(c, a, b, m[QG_MUL_REAL], &T.mul[0]);
+        prod[1] = prod[0];
+        // the exact dot product, for the linear class
+        Rng pr = mul_rng(a.r, b.r);
+        Rng dot = {pr.lo * d->K, pr.hi * d->K};
+        out->dot_bits = bits_of(dot.lo) > bits_of(dot.hi) ? bits_of(dot.lo) : bits_of(dot.hi);
+    } else {
+        Val a = {fmt_range(d->a[0]), d->a[0]}, b = {fmt_range(d->a[1]), d->a[1]};
+        Val cc = {fmt_range(d->b[0]), d->b[0]}, dd = {fmt_range(d->b[1]), d->b[1]};
+        if (d->cmul == QG_CMUL_TF) {
+            Val ab = do_addsub(c, a, b, m[QG_T_AB], false, &T.mul[QG_T_AB]);
+            Val cd = do_addsub(c, cc, dd, m[QG_T_CD], false, &T.mul[QG_T_CD]);
+            Val ba = do_addsub(c, b, a, m[QG_T_BA], true, &T.mul[QG_T_BA]);
+            Val A = do_mul(c, ab, cc, m[QG_T_A], &T.mul[QG_T_A]);
+            Val B = do_mul(c, cd, b, m[QG_T_B], &T.mul[QG_T_B]);
+            Val C = do_mul(c, ba, dd, m[QG_T_C], &T.mul[QG_T_C]);
+            prod[0] = do_addsub(c, A, B, m[QG_T_RE], true, &T.mul[QG_T_RE]);
+            prod[1] = do_addsub(c, B, C, m[QG_T_IM], true, &T.mul[QG_T_IM]);
+        } else {
+            Val ac = do_mul(c, a, cc, m[QG_B_AC], &T.mul[QG_B_AC]);
+            Val bd = do_mul(c, b, dd, m[QG_B_BD], &T.mul[QG_B_BD]);
+            Val ad = do_mul(c, a, dd, m[QG_B_AD], &T.mul[QG_B_AD]);
+            Val bc = do_mul(c, b, cc, m[QG_B_BC], &T.mul[QG_B_BC]);
+            prod[0] = do_addsub(c, ac, bd, m[QG_B_RE], true, &T.mul[QG_B_RE]);
+            prod[1] = do_addsub(c, ad, bc, m[QG_B_IM], false, &T.mul[QG_B_IM]);
+        }
+    }
+
+    // ---- the tree ----
+    for (int p = 0; p < parts; ++p) {
+        Val cur = prod[p];
+        int64_t len = d->K;
+        for (uint32_t l = 0; l < d->n_levels; ++l) {
+            Val s = do_addsub(c, cur, cur, d->level_add[p][l], false, &T.level_add[p][l]);
+            Val st = do_cvt(c, s, d->level[p][l], &T.level_cvt[p][l]);
+            // odd leftover: the converting copy is on the path only when this level has odd length
+            bool was_exact = c.exact;
+            Val lf = do_cvt(c, cur, d->level[p][l], &T.leftover[p][l]);
+            if (!(len & 1)) c.exact = was_exact;
+            else {
+                if (lf.r.lo < st.r.lo) st.r.lo = lf.r.lo;
+                if (lf.r.hi > st.r.hi) st.r.hi = lf.r.hi;
+            }
+            cur = st;
+            len = (len + 1) / 2;
+        }
+        bool tree_exact = c.exact;
+        do_cvt(c, cur, d->c[p], &T.c_cvt[p]);
+        c.exact = tree_exact; // the epilogue is allowed (and expected) to quantise
+        if (!cx) {
+            // linear-class epilogue: D = sum a*b at frac Fa+Fb, one round+overflow into C.
+            // Equal to cvt_C(root) because root = D << (F_root - Fa - Fb) exactly and the root
+            // lies inside the root format's range.
+            int fp = (int)d->a[0].F + (int)d->b[0].F;
+            out->lin.to_c[0] = make_step(fp, d->c[0], false);
+            out->lin.to_c[1] = out->lin.to_c[0];
+            if (out->lin.to_c[0].d > 61 || out->lin.to_c[0].d < -61) c.exact = false;
+        }
+    }
+    if (out->status != QG_OK) return;
+
+    out->max_bits = c.max_bits;
+    if (c.max_bits > 62) { c.fail(QG_EUNSUPPORTED, "an intermediate needs more than 62 bits"); return; }
+    out->linear_ok = (c.exact && !cx) ? 1 : 0;
+    out->cls = out->linear_ok ? QG_CLASS_LINEAR : QG_CLASS_TREE;
+    if (!out->linear_ok)
+        snprintf(out->reason, sizeof out->reason, "%s",
+                 cx ? "complex operands: exact tree evaluation" : "a product or tree node may round or overflow: exact tree evaluation");
+}

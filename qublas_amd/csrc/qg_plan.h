@@ -1,0 +1,45 @@
+// qg_plan.h — host-side analysis of a qgemul_desc: validation, exactness class (SURVEY.md
+// §8-a13), required integer width, kernel choice and the pre-resolved per-node tables the
+// device kernels read.  Pure host code: compiled into libqugemm.so, usable without a GPU.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/qgemul.h"
+#include "qg_ops.h"
+
+// everything a kernel needs about the arithmetic, laid out for device reads (plan-owned buffer)
+struct QTreeTable {
+    int32_t is_complex, cmul, n_levels, parts;
+    QNode mul[8];                         // product sub-ops in qgemul.h slot order
+    QNode level_add[2][QG_MAX_LEVELS];    // pair add of level l (inputs have equal formats)
+    QStep level_cvt[2][QG_MAX_LEVELS];    // store into the level buffer (identity for real GEMMs)
+    QStep leftover[2][QG_MAX_LEVELS];     // odd-leftover copy into level l's buffer
+    QStep c_cvt[2];                       // root -> C, valid when the tree has all n_levels levels
+};
+
+// epilogue of the linear class: exact dot product at frac (Fa+Fb) -> C
+struct QLinearEpilogue {
+    QStep to_c[2];
+};
+
+struct QAnalysis {
+    int status;              // QG_OK / QG_EINVAL / QG_EUNSUPPORTED
+    int cls;                 // QG_CLASS_*
+    int max_bits;            // widest signed intermediate (bits incl. sign)
+    int linear_ok;           // every conversion on the path is provably the identity
+    int dot_bits;            // class L: bits of the exact K-term dot product
+    char reason[96];
+    QTreeTable tree;
+    QLinearEpilogue lin;
+};
+
+void qg_analyze(const qgemul_desc* d, QAnalysis* out);
+
+// host-layout element geometry (int32/int64 per part; complex = struct {real; imag;})
+struct QHostElem {
+    int size, off[2], sb[2];
+};
+QHostElem qg_host_elem(const qfmt f[2], int is_complex);
+
+// int8 limbs needed to hold every raw value of format f as balanced base-256 digits
+int qg_limbs_for(qfmt f);

@@ -1,0 +1,98 @@
+"""CPU-side checks of the C-ABI library (no compute calls): it loads, exports every symbol that
+include/qgemul.h declares, classifies the golden descriptors, and refuses to compute without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import golden_io as G
+from qublas_amd import capi
+from qublas_amd.desc import CLASS_LINEAR, CLASS_TREE, Qu, desc_from_dict, lower, qgemul_desc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "qgemul.h")).read()
+    return sorted(set(re.findall(r"\b(qgemul_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.lib()
+    names = declared_symbols()
+    assert set(names) == set(capi.EXPORTS), set(names) ^ set(capi.EXPORTS)
+    for n in names:
+        assert hasattr(L, n), n
+    assert L.qgemul_abi_version() == 1
+    assert L.qgemul_strerror(0) == b"ok"
+
+
+def test_struct_layout_matches_header():
+    # sizeof(qgemul_desc): 4+4 + 3*8 + 6*8 + 8*8 + 4+4 + 2*2*40*8
+    assert C.sizeof(qgemul_desc) == 8 + 24 + 48 + 64 + 8 + 1280
+
+
+@pytest.mark.parametrize("j", G.gemm_cases("real") + G.gemm_cases("cplx"), ids=lambda j: j["name"])
+def test_classify_golden_descriptors(j):
+    d = desc_from_dict(j)
+    info = capi.classify(d)
+    assert info.supported == 1
+    name = j["name"]
+    if "_L_" in name or name.endswith("classL"):
+        if not j["is_complex"]:
+            assert info.cls == CLASS_LINEAR, (name, info.reason)
+    if "classT" in name or "default" in name:
+        assert info.cls == CLASS_TREE, name
+    assert info.max_bits <= 62
+
+
+def test_classify_limbs_and_kernel():
+    by = {j["name"]: j for j in G.gemm_cases("real")}
+    i = capi.classify(desc_from_dict(by["e43_L_16x16x512_full_wideC"]))
+    assert (i.cls, i.limbs[0], i.limbs[1], i.kernel) == (CLASS_LINEAR, 1, 1, 1)
+    i = capi.classify(desc_from_dict(by["e88z_L_4x4x4096_full"]))
+    assert (i.cls, i.limbs[0], i.limbs[1], i.kernel) == (CLASS_LINEAR, 3, 3, 2)
+    i = capi.classify(desc_from_dict(by["u44_L_8x8x64_full"]))
+    assert (i.cls, i.limbs[0], i.limbs[1], i.kernel) == (CLASS_LINEAR, 2, 2, 2)
+    i = capi.classify(desc_from_dict(by["e88z_L_4x4x4096_full"]), capi.OPT_FORCE_TREE)
+    assert i.kernel == 4
+    # README example / configuration 1: per-product and per-node quantisation -> tree class
+    i = capi.classify(desc_from_dict(by["c1_nn_classT"]))
+    assert i.cls == CLASS_TREE
+
+
+def test_rejections():
+    e = Qu(4, 3)
+    # WRP::TCPL_SAT is a stub in the reference (QuBLAS.h:2336-2344)
+    d = lower(e, e, Qu(4, 3, OfMode=4), 4, 4, 4)
+    st, _ = capi.classify_status(d)
+    assert st == capi.QG_EUNSUPPORTED
+    # a 32-bit rounding shift with an RND mode is a reference width artefact (tests/test_oracle_golden.py)
+    d = lower(Qu(30, 30), Qu(1, 0), Qu(6, -2, QuMode=4), 4, 4, 4, mul_args=Qu(31, 30))
+    st, info = capi.classify_status(d)
+    assert st == capi.QG_EUNSUPPORTED, info.reason
+    # wider than 62 bits
+    d = lower(Qu(30, 30), Qu(30, 30), Qu(8, 8), 4, 4, 4, mul_args=Qu(60, 60))
+    st, _ = capi.classify_status(d)
+    assert st == capi.QG_EUNSUPPORTED
+    d = lower(e, e, e, 4, 4, 4)
+    d.n_levels = 5
+    st, _ = capi.classify_status(d)
+    assert st == capi.QG_EINVAL
+
+
+def test_no_cpu_fallback():
+    """Without a gfx950 device the engine must fail loudly instead of computing on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    e = Qu(4, 3)
+    d = lower(e, e, e, 4, 4, 4)
+    A = np.zeros(16, np.int32)
+    out = np.full(16, 77, np.int32)
+    with pytest.raises(capi.QgemulError) as ei:
+        capi.run(d, out, A, A)
+    assert ei.value.status == capi.QG_ENOGPU
+    assert (out == 77).all()
