@@ -1,0 +1,443 @@
+// QuBLAS_amd.h — standalone C++23 host header for the MI355X fixed-point GEMM engine.
+//
+// It keeps the spelling of the reference library's tag API for the Qgemul path
+//   Qu<intBits<>, fracBits<>, isSigned<>, QuMode<RND::…|TRN::…>, OfMode<SAT::…|WRP::…>>,
+//   Qu<dim<…>, T>, Qcomplex<R, I>, TypeList<…>, FullPrec,
+//   BasicComplexMul<acT<>,bdT<>,adT<>,bcT<>,acbdT<>,adbcT<>>, TFComplexMul<abT<>,…,BCT<>>,
+//   Qgemul<QgemulAddArgs<…>, QgemulMulArgs<…>, QgemulTransposedA<…>>(C, A, B)
+// (reference: /root/reference/readme.md:22-87, tags /root/reference/include/QuBLAS.h:1986-1999, :2209-2225, :2346-2359)
+// but is written from scratch around a different idea: formats are constexpr VALUES (struct Fmt),
+// tag packs are parsed once into a constexpr TagSet, and the merger rules (QuBLAS.h:3107-3139)
+// are ordinary constexpr functions.  K, M, N are runtime fields of the descriptor, so compile
+// time does not grow with the reduction length (the reference's Reducer instantiates a template
+// per level and per element, QuBLAS.h:4960-4984).
+//
+// The header does no fixed-point arithmetic beyond constructing values from doubles; Qgemul
+// lowers to a qgemul_desc (include/qgemul.h) and calls libqugemm.so, which runs on gfx950 only.
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "qgemul.h"
+
+namespace QuBLAS_amd {
+
+// ------------------------------------------------------------------ tags
+template <typename... Ts> struct TypeList { static constexpr size_t size = sizeof...(Ts); };
+
+struct RND {
+    struct POS_INF { static constexpr int value = QG_RND_POS_INF; };
+    struct NEG_INF { static constexpr int value = QG_RND_NEG_INF; };
+    struct ZERO { static constexpr int value = QG_RND_ZERO; };
+    struct INF { static constexpr int value = QG_RND_INF; };
+    struct CONV { static constexpr int value = QG_RND_CONV; };
+};
+struct TRN {
+    struct TCPL { static constexpr int value = QG_TRN_TCPL; };
+    struct SMGN { static constexpr int value = QG_TRN_SMGN; };
+};
+struct SAT {
+    struct TCPL { static constexpr int value = QG_SAT_TCPL; };
+    struct ZERO { static constexpr int value = QG_SAT_ZERO; };
+    struct SMGN { static constexpr int value = QG_SAT_SMGN; };
+};
+struct WRP {
+    struct TCPL { static constexpr int value = QG_WRP_TCPL; };
+    template <auto N> struct TCPL_SAT { static constexpr int value = QG_WRP_TCPL_SAT; };
+};
+
+template <int V> struct intBits {};
+template <int V> struct fracBits {};
+template <bool V> struct isSigned {};
+template <typename M> struct QuMode {};
+template <typename M> struct OfMode {};
+struct FullPrec {};
+template <size_t... D> struct dim {
+    static constexpr size_t rank = sizeof...(D);
+    static constexpr size_t elems = (D * ... * 1);
+    static constexpr std::array<size_t, sizeof...(D)> extent = {D...};
+};
+
+// ------------------------------------------------------------------ formats as values
+struct Fmt {
+    int I = 8, F = 8;       // defaults of the reference, QuBLAS.h:2355-2359
+    bool S = true;
+    int Q = QG_TRN_TCPL, O = QG_SAT_TCPL;
+    constexpr bool operator==(const Fmt&) const = default;
+    constexpr qfmt c() const { return qfmt{int16_t(I), int16_t(F), uint8_t(S), uint8_t(Q), uint8_t(O), 0}; }
+};
+
+// a parsed tag pack: which of the five tags (and FullPrec) are present.  The FIRST occurrence of
+// a tag wins, as with the reference's tagExtractor (QuBLAS.h:144-148, :187-190).
+struct TagSet {
+    bool hasI = false, hasF = false, hasS = false, hasQ = false, hasO = false, full = false;
+    int I = 0, F = 0, Q = 0, O = 0;
+    bool S = true;
+};
+
+template <typename... Args> class Qu_s;  // scalar, complex or tensor; specialisations below
+
+namespace detail {
+
+template <class T> struct tag_apply { static constexpr void go(TagSet&) {} };  // unknown tags are ignored
+template <int V> struct tag_apply<intBits<V>> { static constexpr void go(TagSet& t) { if (!t.hasI) { t.hasI = true; t.I = V; } } };
+template <int V> struct tag_apply<fracBits<V>> { static constexpr void go(TagSet& t) { if (!t.hasF) { t.hasF = true; t.F = V; } } };
+template <bool V> struct tag_apply<isSigned<V>> { static constexpr void go(TagSet& t) { if (!t.hasS) { t.hasS = true; t.S = V; } } };
+template <class M> struct tag_apply<QuMode<M>> { static constexpr void go(TagSet& t) { if (!t.hasQ) { t.hasQ = true; t.Q = M::value; } } };
+template <class M> struct tag_apply<OfMode<M>> { static constexpr void go(TagSet& t) { if (!t.hasO) { t.hasO = true; t.O = M::value; } } };
+template <> struct tag_apply<FullPrec> { static constexpr void go(TagSet& t) { t.full = true; } };
+
+template <class T> struct is_scalar_qu : std::false_type {};
+template <int I, int F, bool S, class Q, class O>
+struct is_scalar_qu<Qu_s<intBits<I>, fracBits<F>, isSigned<S>, QuMode<Q>, OfMode<O>>> : std::true_type {};
+
+// parse<Tags…>: loose tags; a TypeList is opened; a full scalar Qu type counts as its five tags
+// ONLY when it is the sole argument (MergerArgsWrapper_s single-argument specialisation,
+// QuBLAS.h:3097-3099) — next to other arguments the reference leaves it wrapped and no tag
+// extractor matches it, so it is ignored here too.
+template <typename... Ts> struct parse {
+    static constexpr TagSet value = [] { TagSet t; (tag_apply<Ts>::go(t), ...); return t; }();
+};
+template <typename... Ts> struct parse<TypeList<Ts...>> : parse<Ts...> {};
+template <int I, int F, bool S, class Q, class O>
+struct parse<Qu_s<intBits<I>, fracBits<F>, isSigned<S>, QuMode<Q>, OfMode<O>>> {
+    static constexpr TagSet value = TagSet{true, true, true, true, true, false, I, F, Q::value, O::value, S};
+};
+
+constexpr int imax(int a, int b) { return a > b ? a : b; }
+
+// MulMerger / AddMerger (QuBLAS.h:3107-3120, :3125-3139)
+constexpr Fmt merge_mul(Fmt a, Fmt b, TagSet t)
+{
+    return Fmt{t.hasI ? t.I : (t.full ? a.I + b.I : imax(a.I, b.I)), t.hasF ? t.F : (t.full ? a.F + b.F : imax(a.F, b.F)),
+               t.hasS ? t.S : (a.S || b.S), t.hasQ ? t.Q : (a.Q == b.Q ? a.Q : int(QG_TRN_TCPL)),
+               t.hasO ? t.O : (a.O == b.O ? a.O : int(QG_SAT_TCPL))};
+}
+constexpr Fmt merge_add(Fmt a, Fmt b, TagSet t)
+{
+    return Fmt{t.hasI ? t.I : (t.full ? imax(a.I, b.I) + 1 : imax(a.I, b.I)), t.hasF ? t.F : imax(a.F, b.F),
+               t.hasS ? t.S : (a.S || b.S), t.hasQ ? t.Q : (a.Q == b.Q ? a.Q : int(QG_TRN_TCPL)),
+               t.hasO ? t.O : (a.O == b.O ? a.O : int(QG_SAT_TCPL))};
+}
+
+// double -> raw with the format's own rounding and overflow (Qu_s(double), QuBLAS.h:2387-2393)
+inline int64_t from_double(double v, Fmt f)
+{
+    if (v == 0.0 || std::isnan(v) || std::isinf(v)) return 0;
+    const double t = std::ldexp(v, f.F);
+    const double h = std::floor(t);
+    const double fr = t - h;  // exact in binary floating point
+    double r = h;
+    switch (f.Q) {
+    case QG_RND_POS_INF: r = h + (fr >= 0.5); break;
+    case QG_RND_NEG_INF: r = h + (fr > 0.5); break;
+    case QG_RND_ZERO: r = h + (fr > 0.5 || (fr == 0.5 && v < 0)); break;
+    case QG_RND_INF: r = h + (fr > 0.5 || (fr == 0.5 && v > 0)); break;
+    case QG_RND_CONV: r = h + (fr > 0.5 || (fr == 0.5 && std::fmod(h, 2.0) != 0.0)); break;
+    case QG_TRN_SMGN: r = std::trunc(t); break;
+    default: break;
+    }
+    const int W = f.I + f.F;
+    const double hi = std::ldexp(1.0, W) - 1, lo = f.S ? -std::ldexp(1.0, W) : 0.0;
+    switch (f.O) {
+    case QG_SAT_TCPL: r = r > hi ? hi : (r < lo ? lo : r); break;
+    case QG_SAT_ZERO: r = (r > hi || r < lo) ? 0.0 : r; break;
+    case QG_SAT_SMGN: { const double l2 = f.S ? -hi : 0.0; r = r > hi ? hi : (r < l2 ? l2 : r); break; }
+    default: {  // WRP::TCPL
+        const double m = std::ldexp(1.0, W + (f.S ? 1 : 0));
+        r = std::fmod(r, m);
+        if (r < 0) r += m;
+        if (f.S && r > hi) r -= m;
+        break;
+    }
+    }
+    return int64_t(r);
+}
+
+} // namespace detail
+
+// ------------------------------------------------------------------ scalar
+template <int I, int F, bool S, class QM, class OM>
+class Qu_s<intBits<I>, fracBits<F>, isSigned<S>, QuMode<QM>, OfMode<OM>> {
+public:
+    static_assert(I + F >= 0, "The total number of bits must be non-negative.");
+    static constexpr int intB = I, fracB = F;
+    static constexpr bool isS = S;
+    static constexpr int QuM = QM::value, OfM = OM::value;
+    static constexpr bool is_complex = false;
+    static constexpr Fmt fmt = Fmt{I, F, S, QM::value, OM::value};
+    // storage: always a sign bit; one int32 up to 32 bits, int64 beyond (ArbiInt<N>, QuBLAS.h:353, :2384-2385)
+    using raw_t = std::conditional_t<(1 + I + F <= 32), int32_t, int64_t>;
+    raw_t data = 0;
+
+    constexpr Qu_s() = default;
+    Qu_s(double v) : data(raw_t(detail::from_double(v, fmt))) {}
+    double toDouble() const { return std::ldexp(double(data), -F); }
+    Qu_s& fill(int64_t raw) { data = raw_t(raw); return *this; }  // raw store, no range check (QuBLAS.h:2447-2452)
+};
+
+template <typename... Args> struct QuInput {
+    static constexpr TagSet t = detail::parse<Args...>::value;
+    static constexpr Fmt f = [] { Fmt d; return Fmt{t.hasI ? t.I : d.I, t.hasF ? t.F : d.F, t.hasS ? t.S : d.S, t.hasQ ? t.Q : d.Q, t.hasO ? t.O : d.O}; }();
+};
+
+namespace detail {
+template <int code> struct qmode_t;
+template <> struct qmode_t<QG_RND_POS_INF> { using type = RND::POS_INF; };
+template <> struct qmode_t<QG_RND_NEG_INF> { using type = RND::NEG_INF; };
+template <> struct qmode_t<QG_RND_ZERO> { using type = RND::ZERO; };
+template <> struct qmode_t<QG_RND_INF> { using type = RND::INF; };
+template <> struct qmode_t<QG_RND_CONV> { using type = RND::CONV; };
+template <> struct qmode_t<QG_TRN_TCPL> { using type = TRN::TCPL; };
+template <> struct qmode_t<QG_TRN_SMGN> { using type = TRN::SMGN; };
+template <int code> struct omode_t;
+template <> struct omode_t<QG_SAT_TCPL> { using type = SAT::TCPL; };
+template <> struct omode_t<QG_SAT_ZERO> { using type = SAT::ZERO; };
+template <> struct omode_t<QG_SAT_SMGN> { using type = SAT::SMGN; };
+template <> struct omode_t<QG_WRP_TCPL> { using type = WRP::TCPL; };
+template <> struct omode_t<QG_WRP_TCPL_SAT> { using type = WRP::TCPL_SAT<0>; };
+
+template <Fmt f>
+using scalar_of = Qu_s<intBits<f.I>, fracBits<f.F>, isSigned<f.S>, QuMode<typename qmode_t<f.Q>::type>, OfMode<typename omode_t<f.O>::type>>;
+
+// Qu<…> front-end: order-free optional tags -> canonical scalar; dim<> first -> tensor; two scalar
+// types -> complex (QuInputHelper, QuBLAS.h:2480-2498, :2607-2617)
+template <typename... Args> struct qu_helper { using type = scalar_of<QuInput<Args...>::f>; };
+template <int I, int F, bool S, class Q, class O>
+struct qu_helper<Qu_s<intBits<I>, fracBits<F>, isSigned<S>, QuMode<Q>, OfMode<O>>> {
+    using type = Qu_s<intBits<I>, fracBits<F>, isSigned<S>, QuMode<Q>, OfMode<O>>;
+};
+template <typename... R, typename... Im> struct qu_helper<Qu_s<R...>, Qu_s<Im...>> { using type = Qu_s<Qu_s<R...>, Qu_s<Im...>>; };
+template <typename... R, typename... Im> struct qu_helper<Qu_s<Qu_s<R...>, Qu_s<Im...>>> { using type = Qu_s<Qu_s<R...>, Qu_s<Im...>>; };
+template <size_t... D, typename... Rest> struct qu_helper<dim<D...>, Rest...> { using type = Qu_s<dim<D...>, typename qu_helper<Rest...>::type>; };
+} // namespace detail
+
+template <typename... Args> using Qu = typename detail::qu_helper<Args...>::type;
+
+// ------------------------------------------------------------------ complex
+template <typename... R, typename... Im>
+class Qu_s<Qu_s<R...>, Qu_s<Im...>> {
+public:
+    using realType = Qu_s<R...>;
+    using imagType = Qu_s<Im...>;
+    static constexpr bool is_complex = true;
+    realType real;
+    imagType imag;
+    constexpr Qu_s() = default;
+    template <class T1, class T2> Qu_s(T1 a, T2 b) : real(a), imag(b) {}
+    template <class T> Qu_s(T a) : real(a), imag(0) {}
+};
+template <class R, class Im> using Qcomplex = Qu_s<R, Im>;
+
+// ------------------------------------------------------------------ tensor (column-major, QuBLAS.h:2680-2692)
+template <size_t... D, typename Elem>
+class Qu_s<dim<D...>, Elem> {
+public:
+    using size = dim<D...>;
+    using elem_t = Elem;
+    static constexpr size_t elemSize = size::elems;
+    std::vector<Elem> data = std::vector<Elem>(elemSize);  // contiguous; data.data() is what the engine reads
+
+    Qu_s() = default;
+    template <class... V>
+        requires(sizeof...(V) == elemSize && sizeof...(V) > 1)
+    Qu_s(V... v) : data{Elem(v)...} {}
+
+    Elem& operator[](size_t i) { return data[i]; }
+    const Elem& operator[](size_t i) const { return data[i]; }
+    template <class... Ix>
+        requires(sizeof...(Ix) == sizeof...(D) && sizeof...(Ix) > 1)
+    Elem& operator[](Ix... ix) { return data[linear(ix...)]; }
+    template <class... Ix>
+        requires(sizeof...(Ix) == sizeof...(D) && sizeof...(Ix) > 1)
+    const Elem& operator[](Ix... ix) const { return data[linear(ix...)]; }
+
+    // uniform raw values over the whole representable range, like Qu::fill() (QuBLAS.h:526-536)
+    Qu_s& fill(uint64_t seed = 1)
+    {
+        std::mt19937_64 g(seed);
+        auto one = [&](auto& s) {
+            using S = std::remove_reference_t<decltype(s)>;
+            const int W = S::intB + S::fracB;
+            const int64_t lo = S::isS ? -(int64_t(1) << W) : 0, hi = (int64_t(1) << W) - 1;
+            s.data = typename S::raw_t(std::uniform_int_distribution<int64_t>(lo, hi)(g));
+        };
+        for (auto& e : data) {
+            if constexpr (Elem::is_complex) { one(e.real); one(e.imag); }
+            else one(e);
+        }
+        return *this;
+    }
+
+private:
+    template <class... Ix> static size_t linear(Ix... ix)
+    {
+        const size_t idx[] = {size_t(ix)...};
+        size_t lin = 0, stride = 1;
+        for (size_t k = 0; k < sizeof...(D); ++k) { lin += idx[k] * stride; stride *= size::extent[k]; }
+        return lin;
+    }
+};
+
+// ------------------------------------------------------------------ complex-multiply wrappers and Qgemul tags
+template <typename... A> struct BasicComplexMul {};
+template <typename... A> struct TFComplexMul {};
+template <typename... A> struct acT {}; template <typename... A> struct bdT {}; template <typename... A> struct adT {};
+template <typename... A> struct bcT {}; template <typename... A> struct acbdT {}; template <typename... A> struct adbcT {};
+template <typename... A> struct abT {}; template <typename... A> struct cdT {}; template <typename... A> struct baT {};
+template <typename... A> struct abcT {}; template <typename... A> struct cdbT {}; template <typename... A> struct badT {};
+template <typename... A> struct ABT {}; template <typename... A> struct BCT {};
+
+template <typename... A> struct QgemulAddArgs {};
+template <typename... A> struct QgemulMulArgs {};
+template <bool V> struct QgemulTransposedA { static constexpr bool value = V; };
+
+namespace detail {
+
+// the tag set a sub-operation sees: its own wrapper's arguments if present (first match), else
+// every argument of the enclosing multiplier (the default `xT<toArgs…>`, QuBLAS.h:3429, :164-170)
+template <template <typename...> class W, typename... All> struct sub_tags {
+    template <typename... Tail> struct search { static constexpr bool found = false; static constexpr TagSet value{}; };
+    template <typename... Own, typename... Tail> struct search<W<Own...>, Tail...> {
+        static constexpr bool found = true;
+        static constexpr TagSet value = parse<Own...>::value;
+    };
+    template <typename T0, typename... Tail> struct search<T0, Tail...> : search<Tail...> {};
+    static constexpr TagSet value = search<All...>::found ? search<All...>::value : parse<All...>::value;
+};
+
+template <class E> constexpr Fmt re_fmt() { if constexpr (E::is_complex) return E::realType::fmt; else return E::fmt; }
+template <class E> constexpr Fmt im_fmt() { if constexpr (E::is_complex) return E::imagType::fmt; else return E::fmt; }
+
+struct Slots { int cmul = QG_CMUL_NONE; Fmt m[8]{}; Fmt prod[2]{}; };
+
+template <class EA, class EB, class MulList> struct slots_of;
+template <class EA, class EB, typename... Tags>
+    requires(!EA::is_complex)
+struct slots_of<EA, EB, TypeList<Tags...>> {
+    static constexpr Slots value = [] { Slots s; s.m[0] = merge_mul(EA::fmt, EB::fmt, parse<Tags...>::value); s.prod[0] = s.prod[1] = s.m[0]; return s; }();
+};
+template <class EA, class EB, typename... Args>
+    requires(EA::is_complex)
+struct slots_of<EA, EB, TypeList<BasicComplexMul<Args...>>> {
+    static constexpr Slots value = [] {
+        constexpr Fmt a = re_fmt<EA>(), b = im_fmt<EA>(), c = re_fmt<EB>(), d = im_fmt<EB>();
+        Slots s; s.cmul = QG_CMUL_BASIC;
+        s.m[QG_B_AC] = merge_mul(a, c, sub_tags<acT, Args...>::value);
+        s.m[QG_B_BD] = merge_mul(b, d, sub_tags<bdT, Args...>::value);
+        s.m[QG_B_AD] = merge_mul(a, d, sub_tags<adT, Args...>::value);
+        s.m[QG_B_BC] = merge_mul(b, c, sub_tags<bcT, Args...>::value);
+        s.m[QG_B_RE] = merge_add(s.m[QG_B_AC], s.m[QG_B_BD], sub_tags<acbdT, Args...>::value);
+        s.m[QG_B_IM] = merge_add(s.m[QG_B_AD], s.m[QG_B_BC], sub_tags<adbcT, Args...>::value);
+        s.prod[0] = s.m[QG_B_RE]; s.prod[1] = s.m[QG_B_IM];
+        return s;
+    }();
+};
+template <class EA, class EB>
+    requires(EA::is_complex)
+struct slots_of<EA, EB, TypeList<>> : slots_of<EA, EB, TypeList<BasicComplexMul<>>> {};  // QuBLAS.h:3422-3424
+template <class EA, class EB, typename... Args>
+    requires(EA::is_complex)
+struct slots_of<EA, EB, TypeList<TFComplexMul<Args...>>> {
+    static constexpr Slots value = [] {
+        constexpr Fmt a = re_fmt<EA>(), b = im_fmt<EA>(), c = re_fmt<EB>(), d = im_fmt<EB>();
+        Slots s; s.cmul = QG_CMUL_TF;
+        s.m[QG_T_AB] = merge_add(a, b, sub_tags<abT, Args...>::value);
+        s.m[QG_T_CD] = merge_add(c, d, sub_tags<cdT, Args...>::value);
+        s.m[QG_T_BA] = merge_add(b, a, TagSet{});                                    // baT is never honoured (QuBLAS.h:3515)
+        s.m[QG_T_A] = merge_mul(s.m[QG_T_AB], c, sub_tags<abcT, Args...>::value);
+        s.m[QG_T_B] = merge_mul(s.m[QG_T_CD], b, sub_tags<badT, Args...>::value);   // B uses badT (QuBLAS.h:3525)
+        s.m[QG_T_C] = merge_mul(s.m[QG_T_BA], d, sub_tags<cdbT, Args...>::value);   // C uses cdbT (QuBLAS.h:3526)
+        s.m[QG_T_RE] = merge_add(s.m[QG_T_A], s.m[QG_T_B], sub_tags<ABT, Args...>::value);
+        s.m[QG_T_IM] = merge_add(s.m[QG_T_B], s.m[QG_T_C], sub_tags<BCT, Args...>::value);
+        s.prod[0] = s.m[QG_T_RE]; s.prod[1] = s.m[QG_T_IM];
+        return s;
+    }();
+};
+
+// level list -> array of (re, im) formats
+template <class List> struct levels_of;
+template <typename... Ls> struct levels_of<TypeList<Ls...>> {
+    static constexpr size_t n = sizeof...(Ls);
+    static constexpr std::array<std::array<Fmt, 2>, (n ? n : 1)> value = [] {
+        std::array<std::array<Fmt, 2>, (n ? n : 1)> v{};
+        size_t i = 0;
+        ((v[i][0] = re_fmt<Ls>(), v[i][1] = im_fmt<Ls>(), ++i), ...);
+        return v;
+    }();
+    static constexpr bool all_complex = (Ls::is_complex && ... && true);
+    static constexpr bool all_real = (!Ls::is_complex && ... && true);
+};
+
+template <class... Tags> struct pick_add { using type = TypeList<>; };
+template <class... L, class... Rest> struct pick_add<QgemulAddArgs<L...>, Rest...> { using type = TypeList<L...>; };
+template <class... L, class... Rest> struct pick_add<QgemulAddArgs<TypeList<L...>>, Rest...> { using type = TypeList<L...>; };
+template <class T, class... Rest> struct pick_add<T, Rest...> : pick_add<Rest...> {};
+template <class... Tags> struct pick_mul { using type = TypeList<>; };
+template <class... L, class... Rest> struct pick_mul<QgemulMulArgs<L...>, Rest...> { using type = TypeList<L...>; };
+template <class T, class... Rest> struct pick_mul<T, Rest...> : pick_mul<Rest...> {};
+template <class... Tags> struct pick_ta { static constexpr bool value = false; };
+template <bool V, class... Rest> struct pick_ta<QgemulTransposedA<V>, Rest...> { static constexpr bool value = V; };
+template <class T, class... Rest> struct pick_ta<T, Rest...> : pick_ta<Rest...> {};
+
+} // namespace detail
+
+// lower a Qgemul call to the C-ABI descriptor (pure host computation, no device access)
+template <typename... Tags, size_t CM, size_t CN, size_t AR, size_t AC, size_t BKd, size_t BN, class EC, class EA, class EB>
+qgemul_desc Qgemul_lower(const Qu_s<dim<CM, CN>, EC>&, const Qu_s<dim<AR, AC>, EA>&, const Qu_s<dim<BKd, BN>, EB>&)
+{
+    using namespace detail;
+    constexpr bool ta = pick_ta<Tags...>::value;
+    constexpr size_t M = ta ? AC : AR, K = ta ? AR : AC;
+    static_assert(M == CM && BN == CN && BKd == K, "Qgemul: C is MxN, A is MxK (KxM when transposed), B is KxN");
+    static_assert(EA::is_complex == EB::is_complex && EA::is_complex == EC::is_complex, "Qgemul: all real or all complex");
+    using add_list = typename pick_add<Tags...>::type;
+    using L = levels_of<add_list>;
+    static_assert(EA::is_complex ? L::all_complex : L::all_real, "Qgemul: level types must be complex for complex operands, real otherwise");
+    constexpr Slots s = slots_of<EA, EB, typename pick_mul<Tags...>::type>::value;
+    qgemul_desc d{};
+    d.abi = QGEMUL_ABI_VERSION;
+    d.transA = ta;
+    d.is_complex = EA::is_complex;
+    d.cmul = uint8_t(s.cmul);
+    d.M = int64_t(M); d.N = int64_t(CN); d.K = int64_t(K);
+    d.a[0] = re_fmt<EA>().c(); d.a[1] = im_fmt<EA>().c();
+    d.b[0] = re_fmt<EB>().c(); d.b[1] = im_fmt<EB>().c();
+    d.c[0] = re_fmt<EC>().c(); d.c[1] = im_fmt<EC>().c();
+    for (int i = 0; i < (s.cmul == QG_CMUL_NONE ? 1 : s.cmul == QG_CMUL_TF ? 8 : 6); ++i) d.mul[i] = s.m[i].c();
+    for (size_t k = K; k > 1; k = (k + 1) / 2) ++d.n_levels;
+    Fmt prev[2] = {s.prod[0], s.prod[1]};
+    for (uint32_t l = 0; l < d.n_levels; ++l) {
+        for (int p = 0; p < 2; ++p) {
+            Fmt buf = prev[p], add = prev[p];
+            if constexpr (L::n > 0) {
+                buf = L::value[l < L::n ? l : L::n - 1][p];
+                // real: Qadd<T_l> yields T_l; complex: the complex tag is ignored, the add is the default
+                // merge of two equal formats (= that format) and the level buffer converts (QuBLAS.h:4966)
+                add = EA::is_complex ? merge_add(prev[p], prev[p], TagSet{}) : buf;
+            }
+            d.level_add[p][l] = add.c();
+            d.level[p][l] = buf.c();
+            prev[p] = buf;
+        }
+    }
+    return d;
+}
+
+// C = A' * B, quantised per product and per tree node exactly as the reference's primitives do
+template <typename... Tags, class TC, class TA, class TB>
+void Qgemul(TC& C, const TA& A, const TB& B)
+{
+    const qgemul_desc d = Qgemul_lower<Tags...>(C, A, B);
+    const int st = qgemul_run(&d, C.data.data(), A.data.data(), B.data.data(), nullptr);
+    if (st != QG_OK) throw std::runtime_error(std::string("Qgemul: ") + qgemul_strerror(st));
+}
+
+} // namespace QuBLAS_amd

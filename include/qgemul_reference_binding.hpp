@@ -1,0 +1,182 @@
+// qgemul_reference_binding.hpp — the stub a QuBLAS maintainer would add to the reference header's
+// "BLAS" section (after Reducer/Qreduce, /root/reference/include/QuBLAS.h:4899-5018) to get the README's
+//     Qgemul<QgemulAddArgs<list>, QgemulMulArgs<type1>, QgemulTransposedA<true>>(m3, m1, m1);
+// (readme.md:84-87) running on an MI355X through libqugemm.so.
+//
+// It must be included AFTER the reference's own QuBLAS.h: it contains no arithmetic and no tag
+// machinery of its own — every result format is obtained from the reference's types by
+// decltype on the reference's own Qmul / Qadd / Qsub front-ends (QuBLAS.h:3980-3999) and on the
+// member typedefs of its complex multipliers (:3429-3435, :3513-3520), so the lowering cannot
+// drift from the header it extends.  What it adds: the three Qgemul tags, the compile-time
+// walk over the tree levels (Reducer::ReducerTypeSelector semantics, :4906-4921, :4966), and one
+// call of the C-ABI entry point with the tensors' contiguous storage (Qu_s<dim<…>,T>::data.data(),
+// column-major, :2680-2713).
+//
+// The repository's standalone header include/QuBLAS_amd.h provides the same Qgemul on its own
+// minimal tag API for users who do not have the reference header.
+#pragma once
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <utility>
+
+#include "qgemul.h"
+
+inline namespace QuBLAS {
+
+template <typename... Args> struct QgemulAddArgs {};
+template <typename... Args> struct QgemulMulArgs {};
+template <bool Value> struct QgemulTransposedA { static constexpr bool value = Value; };
+
+namespace qgemul_detail {
+
+template <class T> constexpr qfmt fmt_of()
+{
+    return qfmt{int16_t(T::intB), int16_t(T::fracB), uint8_t(T::isS), uint8_t(T::QuM), uint8_t(T::OfM), 0};
+}
+template <class T, bool = T::is_complex> struct parts { using re = T; using im = T; };
+template <class T> struct parts<T, true> { using re = typename T::realType; using im = typename T::imagType; };
+
+// ---- optional, order-free Qgemul tags (same convention as every other tag pack in the header)
+template <class... Tags> struct pick_add { using type = TypeList<>; };
+template <class... L, class... Rest> struct pick_add<QgemulAddArgs<L...>, Rest...> { using type = TypeList<L...>; };
+template <class... L, class... Rest> struct pick_add<QgemulAddArgs<TypeList<L...>>, Rest...> { using type = TypeList<L...>; };
+template <class T, class... Rest> struct pick_add<T, Rest...> : pick_add<Rest...> {};
+
+template <class... Tags> struct pick_mul { using type = TypeList<>; };
+template <class... L, class... Rest> struct pick_mul<QgemulMulArgs<L...>, Rest...> { using type = TypeList<L...>; };
+template <class T, class... Rest> struct pick_mul<T, Rest...> : pick_mul<Rest...> {};
+
+template <class... Tags> struct pick_ta { static constexpr bool value = false; };
+template <bool V, class... Rest> struct pick_ta<QgemulTransposedA<V>, Rest...> { static constexpr bool value = V; };
+template <class T, class... Rest> struct pick_ta<T, Rest...> : pick_ta<Rest...> {};
+
+template <class List> struct mul_with;
+template <class... Tags> struct mul_with<TypeList<Tags...>> {
+    template <class X, class Y> static auto go(const X& x, const Y& y) { return Qmul<Tags...>(x, y); }
+};
+
+// ---- product sub-operation formats
+template <class EA, class EB, class MulList> struct slots;
+template <class EA, class EB, class... Tags>
+    requires(!EA::is_complex)
+struct slots<EA, EB, TypeList<Tags...>> {
+    using prod_t = decltype(Qmul<Tags...>(std::declval<EA>(), std::declval<EB>()));
+    static constexpr int cmul = QG_CMUL_NONE;
+    static void fill(qgemul_desc& d) { d.mul[QG_MUL_REAL] = fmt_of<prod_t>(); }
+};
+template <class EA, class EB, class... Args>
+    requires(EA::is_complex)
+struct slots<EA, EB, TypeList<BasicComplexMul<Args...>>> {
+    using S = Qmul_s<EA, EB, BasicComplexMul<Args...>>;
+    using a_t = typename EA::realType; using b_t = typename EA::imagType;
+    using c_t = typename EB::realType; using d_t = typename EB::imagType;
+    using ac_t = decltype(Qmul<typename S::mulACType>(std::declval<a_t>(), std::declval<c_t>()));
+    using bd_t = decltype(Qmul<typename S::mulBDType>(std::declval<b_t>(), std::declval<d_t>()));
+    using ad_t = decltype(Qmul<typename S::mulADType>(std::declval<a_t>(), std::declval<d_t>()));
+    using bc_t = decltype(Qmul<typename S::mulBCType>(std::declval<b_t>(), std::declval<c_t>()));
+    using re_t = decltype(Qsub<typename S::subACBDType>(std::declval<ac_t>(), std::declval<bd_t>()));
+    using im_t = decltype(Qadd<typename S::addADBCType>(std::declval<ad_t>(), std::declval<bc_t>()));
+    using prod_t = Qcomplex<re_t, im_t>;
+    static constexpr int cmul = QG_CMUL_BASIC;
+    static void fill(qgemul_desc& d)
+    {
+        d.mul[QG_B_AC] = fmt_of<ac_t>(); d.mul[QG_B_BD] = fmt_of<bd_t>(); d.mul[QG_B_AD] = fmt_of<ad_t>();
+        d.mul[QG_B_BC] = fmt_of<bc_t>(); d.mul[QG_B_RE] = fmt_of<re_t>(); d.mul[QG_B_IM] = fmt_of<im_t>();
+    }
+};
+template <class EA, class EB>
+    requires(EA::is_complex)
+struct slots<EA, EB, TypeList<>> : slots<EA, EB, TypeList<BasicComplexMul<>>> {}; // QuBLAS.h:3422-3424
+template <class EA, class EB, class... Args>
+    requires(EA::is_complex)
+struct slots<EA, EB, TypeList<TFComplexMul<Args...>>> {
+    using S = Qmul_s<EA, EB, TFComplexMul<Args...>>;
+    using a_t = typename EA::realType; using b_t = typename EA::imagType;
+    using c_t = typename EB::realType; using d_t = typename EB::imagType;
+    using ab_t = decltype(Qadd<typename S::addabType>(std::declval<a_t>(), std::declval<b_t>()));
+    using cd_t = decltype(Qadd<typename S::addcdType>(std::declval<c_t>(), std::declval<d_t>()));
+    using ba_t = decltype(Qsub<typename S::subbaType>(std::declval<b_t>(), std::declval<a_t>()));
+    using A_t = decltype(Qmul<typename S::mulabcType>(std::declval<ab_t>(), std::declval<c_t>()));
+    using B_t = decltype(Qmul<typename S::mulbadType>(std::declval<cd_t>(), std::declval<b_t>()));
+    using C_t = decltype(Qmul<typename S::mulcdbType>(std::declval<ba_t>(), std::declval<d_t>()));
+    using re_t = decltype(Qsub<typename S::subABType>(std::declval<A_t>(), std::declval<B_t>()));
+    using im_t = decltype(Qsub<typename S::subBCType>(std::declval<B_t>(), std::declval<C_t>()));
+    using prod_t = Qcomplex<re_t, im_t>;
+    static constexpr int cmul = QG_CMUL_TF;
+    static void fill(qgemul_desc& d)
+    {
+        d.mul[QG_T_AB] = fmt_of<ab_t>(); d.mul[QG_T_CD] = fmt_of<cd_t>(); d.mul[QG_T_BA] = fmt_of<ba_t>();
+        d.mul[QG_T_A] = fmt_of<A_t>(); d.mul[QG_T_B] = fmt_of<B_t>(); d.mul[QG_T_C] = fmt_of<C_t>();
+        d.mul[QG_T_RE] = fmt_of<re_t>(); d.mul[QG_T_IM] = fmt_of<im_t>();
+    }
+};
+
+// ---- tree levels: type of level l as Reducer selects it, formats of the add and of the buffer.
+// The walk stops early once the buffer type repeats (all further levels are identical), so the
+// template depth is bounded by the length of the level list, not by log2 K.
+template <size_t L, class Prev, class List> struct level_sel;
+template <size_t L, class Prev> struct level_sel<L, Prev, TypeList<>> { using tag = std::nullptr_t; using buf = Prev; };
+template <size_t L, class Prev, class... Ls> struct level_sel<L, Prev, TypeList<Ls...>> {
+    using tag = TypeAt<(L >= sizeof...(Ls) ? sizeof...(Ls) - 1 : L), TypeList<Ls...>>;
+    using buf = tag;
+};
+template <size_t L, class Prev, class List>
+void fill_levels(qgemul_desc& d)
+{
+    using sel = level_sel<L, Prev, List>;
+    using add_t = decltype(Qadd<typename sel::tag>(std::declval<Prev>(), std::declval<Prev>()));
+    using buf_t = typename sel::buf;
+    constexpr size_t n_list = List::size;
+    constexpr bool steady = std::is_same_v<buf_t, Prev> && (L + 1 >= n_list);
+    const uint32_t last = steady ? d.n_levels : L + 1;
+    for (uint32_t l = L; l < last && l < d.n_levels; ++l) {
+        d.level_add[0][l] = fmt_of<typename parts<add_t>::re>();
+        d.level_add[1][l] = fmt_of<typename parts<add_t>::im>();
+        d.level[0][l] = fmt_of<typename parts<buf_t>::re>();
+        d.level[1][l] = fmt_of<typename parts<buf_t>::im>();
+    }
+    if constexpr (!steady && L + 1 < QG_MAX_LEVELS) {
+        if (L + 1 < d.n_levels) fill_levels<L + 1, buf_t, List>(d);
+    }
+}
+
+} // namespace qgemul_detail
+
+// lower a Qgemul call on reference tensor types to the C-ABI descriptor (no device access)
+template <typename... Tags, size_t CM, size_t CN, size_t AR, size_t AC, size_t BK, size_t BN, class EC, class EA, class EB>
+qgemul_desc Qgemul_lower(const Qu_s<dim<CM, CN>, EC>&, const Qu_s<dim<AR, AC>, EA>&, const Qu_s<dim<BK, BN>, EB>&)
+{
+    using namespace qgemul_detail;
+    constexpr bool ta = pick_ta<Tags...>::value;
+    constexpr size_t M = ta ? AC : AR, K = ta ? AR : AC;
+    static_assert(M == CM && BN == CN && BK == K, "Qgemul: C is MxN, A is MxK (KxM when transposed), B is KxN");
+    static_assert(EA::is_complex == EB::is_complex && EA::is_complex == EC::is_complex, "Qgemul: all real or all complex");
+    using mul_list = typename pick_mul<Tags...>::type;
+    using add_list = typename pick_add<Tags...>::type;
+    using S = slots<EA, EB, mul_list>;
+    qgemul_desc d{};
+    d.abi = QGEMUL_ABI_VERSION;
+    d.transA = ta;
+    d.is_complex = EA::is_complex;
+    d.cmul = uint8_t(S::cmul);
+    d.M = int64_t(M); d.N = int64_t(CN); d.K = int64_t(K);
+    d.a[0] = fmt_of<typename parts<EA>::re>(); d.a[1] = fmt_of<typename parts<EA>::im>();
+    d.b[0] = fmt_of<typename parts<EB>::re>(); d.b[1] = fmt_of<typename parts<EB>::im>();
+    d.c[0] = fmt_of<typename parts<EC>::re>(); d.c[1] = fmt_of<typename parts<EC>::im>();
+    S::fill(d);
+    for (size_t k = K; k > 1; k = (k + 1) / 2) ++d.n_levels;
+    if (d.n_levels) fill_levels<0, typename S::prod_t, add_list>(d);
+    return d;
+}
+
+// the README entry point: C = A' * B with per-product and per-tree-node quantisation
+template <typename... Tags, class TC, class TA, class TB>
+void Qgemul(TC& C, const TA& A, const TB& B)
+{
+    const qgemul_desc d = Qgemul_lower<Tags...>(C, A, B);
+    const int st = qgemul_run(&d, C.data.data(), A.data.data(), B.data.data(), nullptr);
+    if (st != QG_OK) throw std::runtime_error(std::string("Qgemul: ") + qgemul_strerror(st));
+}
+
+} // namespace QuBLAS

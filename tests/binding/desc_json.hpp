@@ -1,0 +1,21 @@
+// shared by the header probes: print a qgemul_desc in the same shape as the golden records
+#pragma once
+#include <cstdio>
+#include "qgemul.h"
+
+inline void print_fmt(const qfmt& f) { std::printf("[%d,%d,%d,%d,%d]", f.I, f.F, f.S, f.Q, f.O); }
+inline void print_desc(const char* name, const qgemul_desc& d)
+{
+    std::printf("{\"name\":\"%s\",\"M\":%lld,\"N\":%lld,\"K\":%lld,\"transA\":%d,\"is_complex\":%d,\"cmul\":%d,\"a\":[", name, (long long)d.M,
+                (long long)d.N, (long long)d.K, d.transA, d.is_complex, d.cmul);
+    print_fmt(d.a[0]); std::printf(","); print_fmt(d.a[1]);
+    std::printf("],\"b\":["); print_fmt(d.b[0]); std::printf(","); print_fmt(d.b[1]);
+    std::printf("],\"c\":["); print_fmt(d.c[0]); std::printf(","); print_fmt(d.c[1]);
+    std::printf("],\"mul\":[");
+    for (int i = 0; i < 8; ++i) { if (i) std::printf(","); print_fmt(d.mul[i]); }
+    std::printf("],\"n_levels\":%u,\"level_add\":[", d.n_levels);
+    for (unsigned l = 0; l < d.n_levels; ++l) { if (l) std::printf(","); std::printf("["); print_fmt(d.level_add[0][l]); std::printf(","); print_fmt(d.level_add[1][l]); std::printf("]"); }
+    std::printf("],\"level\":[");
+    for (unsigned l = 0; l < d.n_levels; ++l) { if (l) std::printf(","); std::printf("["); print_fmt(d.level[0][l]); std::printf(","); print_fmt(d.level[1][l]); std::printf("]"); }
+    std::printf("]}\n");
+}

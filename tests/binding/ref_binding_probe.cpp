@@ -1,0 +1,61 @@
+// Compiles the REAL reference header together with include/qgemul_reference_binding.hpp and prints
+// the descriptors the binding lowers for a set of golden cases (names match tests/golden).
+// No device call is made (Qgemul_lower only).  Build container only.
+#include "QuBLAS.h"
+#include "qgemul_reference_binding.hpp"
+#include "desc_json.hpp"
+
+using namespace QuBLAS;
+
+using e88z = Qu<intBits<8>, fracBits<8>, isSigned<true>, QuMode<TRN::TCPL>, OfMode<SAT::ZERO>>;
+using e43 = Qu<intBits<4>, fracBits<3>>;
+using w16 = Qu<intBits<16>, fracBits<3>>;
+
+template <class EC, class EA, class EB, size_t M, size_t N, size_t K, bool TA, class... Tags>
+void probe(const char* name)
+{
+    Qu<dim<M, N>, EC> C;
+    std::conditional_t<TA, Qu<dim<K, M>, EA>, Qu<dim<M, K>, EA>> A;
+    Qu<dim<K, N>, EB> B;
+    print_desc(name, Qgemul_lower<Tags...>(C, A, B));
+}
+
+int main()
+{
+    probe<e88z, e88z, e88z, 4, 4, 4, false, QgemulAddArgs<e88z>, QgemulMulArgs<e88z>>("c1_nn_classT");
+    probe<e88z, e88z, e88z, 4, 4, 4, true, QgemulTransposedA<true>, QgemulMulArgs<e88z>, QgemulAddArgs<TypeList<e88z>>>("c1_tn_classT");
+    probe<e88z, e88z, e88z, 4, 4, 4, false>("c1_nn_default");
+    probe<e88z, e88z, e88z, 4, 4, 4, false, QgemulMulArgs<intBits<17>, fracBits<16>>, QgemulAddArgs<Qu<intBits<29>, fracBits<16>>>>("c1_nn_classL");
+    probe<w16, e43, e43, 33, 17, 128, false, QgemulMulArgs<intBits<9>, fracBits<6>>, QgemulAddArgs<Qu<intBits<19>, fracBits<6>>>>("e43_L_33x17x128_full_wideC");
+    {
+        using t1 = Qu<intBits<6>, fracBits<5>, QuMode<RND::CONV>, OfMode<SAT::SMGN>>;
+        using t2 = Qu<intBits<8>, fracBits<4>, QuMode<RND::ZERO>, OfMode<SAT::TCPL>>;
+        using t3 = Qu<intBits<9>, fracBits<2>, QuMode<TRN::SMGN>, OfMode<SAT::ZERO>>;
+        using pm = Qu<intBits<5>, fracBits<4>, QuMode<RND::INF>, OfMode<SAT::TCPL>>;
+        probe<w16, e43, e43, 8, 8, 64, false, QgemulMulArgs<pm>, QgemulAddArgs<TypeList<t1, t2, t3>>>("e43_levels3_8x8x64_full");
+        probe<w16, e43, e43, 4, 4, 5, false, QgemulAddArgs<t1, t2>>("e43_K5");
+        using type1 = Qu<isSigned<true>, intBits<6>, fracBits<3>, OfMode<SAT::ZERO>>;
+        using type2 = Qu<intBits<6>, fracBits<-3>>;
+        using list = TypeList<type1, type2>;
+        // the README call, verbatim tags (readme.md:84-87)
+        probe<type1, type1, type1, 4, 4, 4, true, QgemulAddArgs<list>, QgemulMulArgs<type1>, QgemulTransposedA<true>>("readme_list_tn_4x4x4");
+    }
+    {
+        using r55 = Qu<intBits<5>, fracBits<5>>;
+        using c55 = Qcomplex<r55, r55>;
+        using rw = Qu<intBits<18>, fracBits<6>, QuMode<RND::POS_INF>, OfMode<SAT::TCPL>>;
+        using cw = Qcomplex<rw, rw>;
+        using tA = Qu<intBits<9>, fracBits<4>, QuMode<RND::CONV>, OfMode<SAT::SMGN>>;
+        using tB = Qu<intBits<7>, fracBits<2>, QuMode<TRN::SMGN>, OfMode<SAT::ZERO>>;
+        using tC = Qu<intBits<10>, fracBits<5>, QuMode<RND::ZERO>, OfMode<WRP::TCPL>>;
+        using tD = Qu<intBits<8>, fracBits<3>, QuMode<RND::INF>, OfMode<SAT::TCPL>>;
+        using TFmix = TFComplexMul<abT<tA>, cdT<tD>, abcT<tC>, cdbT<tB>, badT<tA>, ABT<tD>, BCT<tC>>;
+        probe<cw, c55, c55, 8, 8, 16, false, QgemulMulArgs<TFmix>>("c55_tf_mixedtags_8x8x16_full");
+        using l1 = Qcomplex<Qu<intBits<12>, fracBits<4>, QuMode<RND::CONV>, OfMode<SAT::SMGN>>, Qu<intBits<11>, fracBits<6>, QuMode<TRN::SMGN>, OfMode<SAT::ZERO>>>;
+        using l2 = Qcomplex<Qu<intBits<16>, fracBits<2>, QuMode<RND::ZERO>>, Qu<intBits<16>, fracBits<3>, QuMode<RND::INF>, OfMode<WRP::TCPL>>>;
+        probe<cw, c55, c55, 8, 8, 32, false, QgemulMulArgs<TFComplexMul<>>, QgemulAddArgs<l1, l2>>("c55_tf_levels2_8x8x32_full");
+        probe<cw, c55, c55, 4, 4, 8, false, QgemulMulArgs<BasicComplexMul<intBits<12>, OfMode<SAT::ZERO>, bdT<tB>>>>("c55_basic_loosetags_4x4x8_full");
+        probe<cw, c55, c55, 8, 8, 64, false>("c55_basic_default_8x8x64_full_wideC");
+    }
+    return 0;
+}
