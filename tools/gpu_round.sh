@@ -1,0 +1,32 @@
+#!/bin/bash
+# Runs ON the GPU box (via gpurun): parity tests, the bench line, and rocprofv3 summaries.
+# Everything is written under gpurun_out/ (merged back by gpurun); summaries worth keeping are
+# copied into profiles/ by tools/summarize_profile.py afterwards.
+#   usage: tools/gpu_round.sh <tag> [workload ...]
+set -o pipefail
+TAG=${1:-r01}; shift
+WLS=${@:-c3L}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+echo "== pytest -m gpu" | tee $OUT/progress.log
+timeout -k 10 600 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/progress.log
+tail -3 $OUT/pytest_gpu.log
+echo "== smoke" | tee -a $OUT/progress.log
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/progress.log
+echo "== bench" | tee -a $OUT/progress.log
+timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/progress.log
+cat $OUT/bench.json
+for WL in $WLS; do
+  echo "== rocprofv3 kernel-trace $WL" | tee -a $OUT/progress.log
+  (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_${WL}_trace --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 20 --warmup 2 --no-extra --no-cpu > $OUT/prof_${WL}_trace.log 2>&1); echo "trace rc=$?" | tee -a $OUT/progress.log
+  for PMC in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT" "GRBM_GUI_ACTIVE"; do
+    N=$(echo $PMC | tr ' ' '_' | cut -c1-24)
+    echo "== rocprofv3 pmc $WL $N" | tee -a $OUT/progress.log
+    (cd /tmp && timeout -k 10 600 rocprofv3 --pmc $PMC -d $OUT/prof_${WL}_pmc_$N --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 3 --warmup 1 --no-extra --no-cpu > $OUT/prof_${WL}_pmc_$N.log 2>&1); echo "pmc rc=$?" | tee -a $OUT/progress.log
+  done
+done
+# keep the merged-back payload small: drop rocprof's per-process databases, keep csv
+find $OUT -name "*.db" -delete 2>/dev/null
+du -sh $OUT | tee -a $OUT/progress.log
