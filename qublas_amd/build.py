@@ -34,7 +34,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(objdir, s.rsplit(".", 1)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
                    "-x", "hip", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)

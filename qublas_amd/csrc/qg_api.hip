@@ -37,7 +37,7 @@ struct qgemul_plan {
     uint32_t flags;
     QAnalysis an;
     qgemul_info info;
-    int LA, LB;
+    int LA, LB, variant;
     QPackedGeom pa, pb;
     QCGeom pc;
     QHostElem ha, hb, hc;
@@ -55,7 +55,7 @@ static int pow2_bytes(int storage_bits)
 static int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // fill info + geometry for a descriptor; no GPU access
-static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qgemul_info* info, int* pLA, int* pLB,
+static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qgemul_info* info, int* pLA, int* pLB, int* pVar,
                          QPackedGeom* pa, QPackedGeom* pb, QCGeom* pc, QHostElem* ha, QHostElem* hb, QHostElem* hc)
 {
     qg_analyze(d, an);
@@ -92,11 +92,13 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     info->ops = !d->is_complex ? 2.0 * mnk : (d->cmul == QG_CMUL_TF ? 6.0 * mnk : 8.0 * mnk);
 
     int LA = 0, LB = 0, kernel = QG_KERNEL_NONE;
+    QMfmaCfg cfg = {0, 0, 0, 0};
     if (an->linear_ok && !(flags & QG_OPT_FORCE_TREE)) {
         LA = qg_limbs_for(d->a[0]);
         LB = qg_limbs_for(d->b[0]);
         const int mn = LA < LB ? LA : LB;
-        if (qg_mfma_bk(LA, LB) && (int64_t)mn * d->K <= (1ll << 17) - 1)
+        cfg = qg_mfma_pick(LA, LB, d->M, d->N);
+        if (cfg.variant && (int64_t)mn * d->K <= (1ll << 17) - 1)
             kernel = (LA == 1 && LB == 1) ? QG_KERNEL_MFMA_I8 : QG_KERNEL_MFMA_I8_LIMB;
         else {
             LA = LB = 0;
@@ -111,9 +113,8 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     pc->elem_bytes = hc->size;
     for (int p = 0; p < 2; ++p) { pc->off[p] = hc->off[p]; pc->sb[p] = hc->sb[p]; }
     if (kernel != QG_KERNEL_NONE) {
-        const int bk = qg_mfma_bk(LA, LB);
-        *pa = QPackedGeom{round_up(d->M, QG_MFMA_TM), round_up(d->K, bk), 1, LA};
-        *pb = QPackedGeom{round_up(d->N, QG_MFMA_TN), round_up(d->K, bk), 1, LB};
+        *pa = QPackedGeom{round_up(d->M, cfg.TM), round_up(d->K, cfg.BK), 1, LA};
+        *pb = QPackedGeom{round_up(d->N, cfg.TN), round_up(d->K, cfg.BK), 1, LB};
         pc->Mp = pa->rows_p;
         pc->Np = pb->rows_p;
     } else {
@@ -131,6 +132,7 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     info->packed_bytes[2] = (int64_t)parts * pc->Mp * pc->Np * pc->cbytes;
     *pLA = LA;
     *pLB = LB;
+    *pVar = cfg.variant;
     return QG_OK;
 }
 
@@ -158,11 +160,11 @@ int qgemul_classify(const qgemul_desc* d, uint32_t opt_flags, qgemul_info* out)
     if (!d || !out) return QG_EINVAL;
     QAnalysis* an = new (std::nothrow) QAnalysis;
     if (!an) return QG_EINVAL;
-    int LA, LB;
+    int LA, LB, variant;
     QPackedGeom pa, pb;
     QCGeom pc;
     QHostElem ha, hb, hc;
-    int st = plan_geometry(d, opt_flags, an, out, &LA, &LB, &pa, &pb, &pc, &ha, &hb, &hc);
+    int st = plan_geometry(d, opt_flags, an, out, &LA, &LB, &variant, &pa, &pb, &pc, &ha, &hb, &hc);
     delete an;
     return st;
 }
@@ -247,7 +249,7 @@ int qgemul_plan_create(qgemul_ctx* c, const qgemul_desc* d, uint32_t opt_flags, 
     p->ctx = c;
     p->desc = *d;
     p->flags = opt_flags;
-    int st = plan_geometry(d, opt_flags, &p->an, &p->info, &p->LA, &p->LB, &p->pa, &p->pb, &p->pc, &p->ha, &p->hb, &p->hc);
+    int st = plan_geometry(d, opt_flags, &p->an, &p->info, &p->LA, &p->LB, &p->variant, &p->pa, &p->pb, &p->pc, &p->ha, &p->hb, &p->hc);
     if (st != QG_OK) { delete p; return st; }
     if (hipSetDevice(c->device) != hipSuccess || hipMalloc((void**)&p->dev_table, sizeof(QTreeTable)) != hipSuccess) {
         delete p;
@@ -357,6 +359,7 @@ int qgemul_execute(qgemul_plan* p, void* packedC, const void* packedA, const voi
         a.Np = p->pb.rows_p;
         a.Kp = p->pa.K_p;
         a.cbytes = p->pc.cbytes;
+        a.variant = p->variant;
         a.to_c = p->an.lin.to_c[0];
         QG_HIP(qg_launch_mfma(p->LA, p->LB, a, st));
         return QG_OK;

@@ -42,16 +42,19 @@ hipError_t qg_launch_tree_generic(const QTreeTable* dev_table, int parts, const 
                                   int64_t N, int64_t K, const QPackedGeom& pa, const QPackedGeom& pb, const QCGeom& pc,
                                   hipStream_t st);
 
-// linear class on int8 MFMA with LA x LB limbs; returns hipErrorInvalidValue if no instantiation
+// linear class on int8 MFMA with LA x LB limbs
+struct QMfmaCfg {
+    int variant;    // 0 = no kernel for this limb combination
+    int TM, TN, BK; // output tile and k-tile (bytes) the packed operands are padded to
+};
+QMfmaCfg qg_mfma_pick(int LA, int LB, int64_t M, int64_t N);
 struct QMfmaArgs {
     const int8_t* A;  // [LA][Mp][Kp]
     const int8_t* B;  // [LB][Np][Kp]
     void* C;          // [Mp][Np] containers
     int64_t Mp, Np, Kp;
     int32_t cbytes;
+    int32_t variant;
     QStep to_c;
 };
 hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st);
-// tile sizes the MFMA path pads to
-enum { QG_MFMA_TM = 128, QG_MFMA_TN = 128 };
-int qg_mfma_bk(int LA, int LB); // k-tile in bytes for a limb combination (0 = unsupported)

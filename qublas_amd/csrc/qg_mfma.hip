@@ -9,8 +9,8 @@
 // recombines them in 64-bit in the epilogue.  int32 accumulation is exact: |d*d'| <= 2^14 and
 // the planner bounds K * min(LA,LB) <= 2^17.
 //
-// Tiling (wave64, CDNA4): 128x128 output tile per 256-thread workgroup, 2x2 waves of 64x64, each
-// wave 2x2 MFMA tiles of 32x32.  A and B k-tiles are copied HBM -> LDS with
+// Tiling (wave64, CDNA4): 128x128 or 256x256 output tile per workgroup of 4 or 8 waves, each wave a
+// TI x TJ grid of 32x32 MFMA tiles (template parameters; qg_mfma_pick chooses per shape).  A and B k-tiles are copied HBM -> LDS with
 // global_load_lds_dwordx4 (16 B per lane, no VGPR round trip) into a double-buffered LDS image
 // whose 16-byte chunks are XOR-swizzled on the SOURCE address (the LDS-DMA destination is
 // lane-linear) so that the ds_read_b128 fragment reads are bank-conflict free.
@@ -25,8 +25,6 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 #define QG_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define QG_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-
-constexpr int TM = QG_MFMA_TM, TN = QG_MFMA_TN;
 
 // LDS image of one k-tile: rows of BK bytes; chunk c (16 B) of row r is stored at slot c ^ swz(r).
 // swz(r) = (r / rows_per_bank_row) % chunks_per_row makes the 16 lanes of every ds_read_b128 group
@@ -49,9 +47,13 @@ __device__ __forceinline__ void store_c(char* C, int64_t idx, int cbytes, int64_
     }
 }
 
-template <int LA, int LB, int BK>
-__global__ __launch_bounds__(256) void k_mfma(QMfmaArgs g)
+// LA, LB : int8 limbs per A / B element          BK       : k-tile in bytes
+// WGM x WGN waves per workgroup                  TI x TJ  : 32x32 MFMA tiles per wave
+template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ>
+__global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 {
+    constexpr int TM = WGM * TI * 32, TN = WGN * TJ * 32;
+    constexpr int NWAVES = WGM * WGN;
     constexpr int NW = LA + LB - 1;            // limb weights
     constexpr int ROWS = LA * TM + LB * TN;    // LDS rows per stage
     constexpr int STAGE = ROWS * BK;           // bytes per stage
@@ -59,11 +61,13 @@ __global__ __launch_bounds__(256) void k_mfma(QMfmaArgs g)
     constexpr int RPP = 1024 / BK;             // rows per piece
     constexpr int CPR = BK / 16;
     constexpr int KSTEPS = BK / 32;            // MFMA k-steps per tile
+    static_assert(PIECES % NWAVES == 0, "every wave issues the same number of LDS-DMA pieces");
+    static_assert(TM % RPP == 0 && TN % RPP == 0, "a piece never straddles two operand planes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
 
     // XCD-aware tile order: consecutive block ids go to different XCDs, so give each XCD a
     // contiguous run of tiles, walked in column-major groups of 8 tile-rows for L2 reuse.
@@ -92,8 +96,8 @@ __global__ __launch_bounds__(256) void k_mfma(QMfmaArgs g)
     auto issue = [&](int stage, int kt) {
         char* sbase = smem + stage * STAGE;
 #pragma unroll
-        for (int pi = 0; pi < PIECES / 4; ++pi) {
-            const int p = wave + 4 * pi;            // wave-uniform piece id
+        for (int pi = 0; pi < PIECES / NWAVES; ++pi) {
+            const int p = wave + NWAVES * pi;       // wave-uniform piece id
             const int R = p * RPP + prow;           // LDS row of this lane
             const int8_t* src;
             int rl;
@@ -113,13 +117,13 @@ __global__ __launch_bounds__(256) void k_mfma(QMfmaArgs g)
         }
     };
 
-    v16i acc[NW][2][2];
+    v16i acc[NW][TI][TJ];
 #pragma unroll
     for (int w = 0; w < NW; ++w)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TJ; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[w][i][j][e] = 0;
 
@@ -135,27 +139,30 @@ __global__ __launch_bounds__(256) void k_mfma(QMfmaArgs g)
         const char* sB = sA + LA * TM * BK;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            v4i a[LA][2], b[LB][2];
+            v4i a[LA][TI], b[LB][TJ];
             const int c = 2 * ks + fh;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ra = wm * 64 + i * 32 + fr;
-                const int rb = wn * 64 + i * 32 + fr;
+            for (int i = 0; i < TI; ++i) {
+                const int ra = (wm * TI + i) * 32 + fr;
 #pragma unroll
                 for (int l = 0; l < LA; ++l)
                     a[l][i] = *(const v4i*)(sA + (l * TM + ra) * BK + ((c ^ swz<BK>(ra)) * 16));
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int rb = (wn * TJ + j) * 32 + fr;
 #pragma unroll
                 for (int l = 0; l < LB; ++l)
-                    b[l][i] = *(const v4i*)(sB + (l * TN + rb) * BK + ((c ^ swz<BK>(rb)) * 16));
+                    b[l][j] = *(const v4i*)(sB + (l * TN + rb) * BK + ((c ^ swz<BK>(rb)) * 16));
             }
 #pragma unroll
             for (int la = 0; la < LA; ++la)
 #pragma unroll
                 for (int lb = 0; lb < LB; ++lb)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < TI; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
+                        for (int j = 0; j < TJ; ++j)
                             acc[la + lb][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[la][i], b[lb][j], acc[la + lb][i][j], 0, 0, 0);
         }
     }
@@ -165,59 +172,69 @@ __global__ __launch_bounds__(256) void k_mfma(QMfmaArgs g)
     const QStep st = g.to_c;
     char* C = (char*)g.C;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 int64_t s = 0;
 #pragma unroll
                 for (int w = NW - 1; w >= 0; --w) s = s * 256 + (int64_t)acc[w][i][j][e];
-                const int64_t row = (int64_t)tile_m * TM + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                const int64_t col = (int64_t)tile_n * TN + wn * 64 + j * 32 + fr;
+                const int64_t row = (int64_t)tile_m * TM + (wm * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                const int64_t col = (int64_t)tile_n * TN + (wn * TJ + j) * 32 + fr;
                 store_c(C, row * g.Np + col, g.cbytes, qg_step<int64_t>(s, st));
             }
 }
 
-template <int LA, int LB, int BK>
+template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ>
 hipError_t launch(const QMfmaArgs& a, hipStream_t st)
 {
+    constexpr int TM = WGM * TI * 32, TN = WGN * TJ * 32;
     constexpr int STAGE = (LA * TM + LB * TN) * BK;
-    static_assert(STAGE % 4096 == 0, "stage must be a whole number of pieces per wave");
     const int lds = 2 * STAGE;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mfma<LA, LB, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_mfma<LA, LB, BK, WGM, WGN, TI, TJ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int64_t blocks = (a.Mp / TM) * (a.Np / TN);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll || a.Kp % BK || a.Mp % TM || a.Np % TN) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_mfma<LA, LB, BK>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_mfma<LA, LB, BK, WGM, WGN, TI, TJ>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
     return hipGetLastError();
 }
 
 } // namespace
 
-int qg_mfma_bk(int LA, int LB)
+QMfmaCfg qg_mfma_pick(int LA, int LB, int64_t M, int64_t N)
 {
-    if (LA < 1 || LB < 1 || LA > 3 || LB > 3) return 0;
-    return (LA == 1 && LB == 1) ? 128 : 64;
+    QMfmaCfg c = {0, 0, 0, 0};
+    if (LA < 1 || LB < 1 || LA > 3 || LB > 3) return c;
+    if (LA == 1 && LB == 1) {
+        // 256x256 tiles halve the L2->LDS traffic per MAC; use them once they fill the 256 CUs
+        const int64_t big = ((M + 255) / 256) * ((N + 255) / 256);
+        if (big >= 256) return QMfmaCfg{2, 256, 256, 128};
+        return QMfmaCfg{1, 128, 128, 128};
+    }
+    return QMfmaCfg{3, 128, 128, 64};
 }
 
 hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
 {
+    if (LA == 1 && LB == 1) {
+        if (a.variant == 2) return launch<1, 1, 128, 2, 4, 4, 2>(a, st);
+        return launch<1, 1, 128, 2, 2, 2, 2>(a, st);
+    }
     switch (LA * 10 + LB) {
-    case 11: return launch<1, 1, 128>(a, st);
-    case 12: return launch<1, 2, 64>(a, st);
-    case 21: return launch<2, 1, 64>(a, st);
-    case 22: return launch<2, 2, 64>(a, st);
-    case 13: return launch<1, 3, 64>(a, st);
-    case 31: return launch<3, 1, 64>(a, st);
-    case 23: return launch<2, 3, 64>(a, st);
-    case 32: return launch<3, 2, 64>(a, st);
-    case 33: return launch<3, 3, 64>(a, st);
+    case 12: return launch<1, 2, 64, 2, 4, 2, 1>(a, st);
+    case 21: return launch<2, 1, 64, 2, 4, 2, 1>(a, st);
+    case 22: return launch<2, 2, 64, 2, 4, 2, 1>(a, st);
+    case 13: return launch<1, 3, 64, 2, 4, 2, 1>(a, st);
+    case 31: return launch<3, 1, 64, 2, 4, 2, 1>(a, st);
+    case 23: return launch<2, 3, 64, 2, 4, 2, 1>(a, st);
+    case 32: return launch<3, 2, 64, 2, 4, 2, 1>(a, st);
+    case 33: return launch<3, 3, 64, 2, 4, 2, 1>(a, st);
     default: return hipErrorInvalidValue;
     }
 }
