@@ -65,12 +65,11 @@ def cpu_baseline(variant: str, budget_s: float = 20.0):
     procs_n = max(1, min(ncpu, 32))
     if os.path.exists(exe):
         # calibrate on a tiny block, then size each process's block to ~budget
-        t0 = time.time()
-        out = subprocess.check_output([exe, variant, "0", "4", "64"], text=True)
+        out = subprocess.check_output([exe, variant, "0", "8", "256"], text=True)
         cal = json.loads(out)
-        rate = cal["macs"] / max(cal["seconds"], 1e-6)
-        cols = 1024
-        rows = int(max(1, min(64, rate * budget_s / (cols * cal["K"]))))
+        rate = cal["macs"] / max(cal["seconds"], 1e-6)   # MAC/s of one process, measured alone
+        cols = 4096 if cal["K"] == 4096 else 1024
+        rows = int(max(1, min(4096 // procs_n, rate * budget_s / (cols * cal["K"]))))
         ps = [subprocess.Popen([exe, variant, str(i * rows), str(rows), str(cols)], stdout=subprocess.PIPE, text=True)
               for i in range(procs_n)]
         t0 = time.time()

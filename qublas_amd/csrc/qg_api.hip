@@ -113,16 +113,19 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     pc->elem_bytes = hc->size;
     for (int p = 0; p < 2; ++p) { pc->off[p] = hc->off[p]; pc->sb[p] = hc->sb[p]; }
     if (kernel != QG_KERNEL_NONE) {
-        *pa = QPackedGeom{round_up(d->M, cfg.TM), round_up(d->K, cfg.BK), 1, LA};
-        *pb = QPackedGeom{round_up(d->N, cfg.TN), round_up(d->K, cfg.BK), 1, LB};
+        *pa = QPackedGeom{round_up(d->M, cfg.TM), round_up(d->K, cfg.BK), 1, LA, cfg.TM, cfg.BK};
+        *pb = QPackedGeom{round_up(d->N, cfg.TN), round_up(d->K, cfg.BK), 1, LB, cfg.TN, cfg.BK};
         pc->Mp = pa->rows_p;
         pc->Np = pb->rows_p;
+        pc->tm = cfg.TM;
+        pc->tn = cfg.TN;
     } else {
         kernel = d->is_complex ? QG_KERNEL_TREE_CPLX : QG_KERNEL_TREE_I64;
-        *pa = QPackedGeom{d->M, d->K, info->in_bits[0] <= 32 ? 4 : 8, 0};
-        *pb = QPackedGeom{d->N, d->K, info->in_bits[1] <= 32 ? 4 : 8, 0};
+        *pa = QPackedGeom{d->M, d->K, info->in_bits[0] <= 32 ? 4 : 8, 0, 0, 0};
+        *pb = QPackedGeom{d->N, d->K, info->in_bits[1] <= 32 ? 4 : 8, 0, 0, 0};
         pc->Mp = d->M;
         pc->Np = d->N;
+        pc->tm = pc->tn = 0;
     }
     info->kernel = kernel;
     info->limbs[0] = LA;

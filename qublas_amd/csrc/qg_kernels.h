@@ -17,15 +17,22 @@ struct QOperandGeom {
 
 // packed (device-private) layouts
 //   tree  : [part][rows_p][K_p] containers of cbytes (4|8), K contiguous
-//   limbs : [part][limb][rows_p][K_p] int8 balanced base-256 digits, K contiguous
+//   limbs : int8 balanced base-256 digits, PRE-TILED and PRE-SWIZZLED for the MFMA kernel:
+//           [row tile][k tile][limb][tr rows][bk bytes], where the 16-byte chunk c of row r sits at
+//           slot c ^ ((r / (256/bk)) % (bk/16)).  One (row tile, k tile) block is exactly the LDS
+//           image of that operand for one pipeline stage, so the kernel streams it with lane-linear
+//           LDS-DMA (1 KiB per wave instruction, fully sequential in HBM; no row pitch, hence no
+//           power-of-two-stride channel camping).
 struct QPackedGeom {
     int64_t rows_p, K_p;    // padded extents
     int32_t cbytes;         // container bytes (tree layout), 1 for limb layout
     int32_t limbs;          // 0 = tree layout, >0 = limb layout
+    int32_t tr, bk;         // limb layout: rows per tile, k bytes per tile
 };
 
 struct QCGeom {
-    int64_t M, N, Mp, Np;   // logical / padded extents of packed C, row-major [part][Mp][Np]
+    int64_t M, N, Mp, Np;   // logical / padded extents of packed C
+    int32_t tm, tn;         // 0: row-major [part][Mp][Np]; else tiled [part][Mp/tm][Np/tn][tm][tn]
     int32_t cbytes;         // 1|2|4|8 container
     int32_t parts;
     int64_t ldc;            // host leading dimension (elements)

@@ -49,7 +49,7 @@ __device__ __forceinline__ void store_c(char* C, int64_t idx, int cbytes, int64_
 
 // LA, LB : int8 limbs per A / B element          BK       : k-tile in bytes
 // WGM x WGN waves per workgroup                  TI x TJ  : 32x32 MFMA tiles per wave
-template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ>
+template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE>
 __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 {
     constexpr int TM = WGM * TI * 32, TN = WGN * TJ * 32;
@@ -58,11 +58,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
     constexpr int ROWS = LA * TM + LB * TN;    // LDS rows per stage
     constexpr int STAGE = ROWS * BK;           // bytes per stage
     constexpr int PIECES = STAGE / 1024;       // 1-KiB LDS-DMA pieces per stage
-    constexpr int RPP = 1024 / BK;             // rows per piece
-    constexpr int CPR = BK / 16;
+    constexpr int PPW = PIECES / NWAVES;       // pieces (LDS-DMA instructions) per wave per stage
     constexpr int KSTEPS = BK / 32;            // MFMA k-steps per tile
     static_assert(PIECES % NWAVES == 0, "every wave issues the same number of LDS-DMA pieces");
-    static_assert(TM % RPP == 0 && TN % RPP == 0, "a piece never straddles two operand planes");
+    static_assert(NSTAGE >= 2 && (NSTAGE - 2) * PPW < 64, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -85,34 +84,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
     const int tile_m = first_m + (bid % (GM * tiles_n)) % gsz;
     const int tile_n = (bid % (GM * tiles_n)) / gsz;
 
-    const int8_t* Ag = g.A + (int64_t)tile_m * TM * g.Kp;
-    const int8_t* Bg = g.B + (int64_t)tile_n * TN * g.Kp;
-    const int64_t planeA = g.Mp * g.Kp, planeB = g.Np * g.Kp;
-
-    // per-lane source geometry of the LDS-DMA pieces this wave issues: piece p covers LDS rows
-    // [p*RPP, (p+1)*RPP); lane i fills slot (i % CPR) of row p*RPP + i/CPR
-    const int prow = lane / CPR, pslot = lane % CPR;
+    // operands are pre-tiled: block (row tile, k tile) of A is LA*TM*BK contiguous bytes that are
+    // already the swizzled LDS image; same for B.  A stage is two linear copies.
+    const int nk = (int)(g.Kp / BK);
+    constexpr int A_BYTES = LA * TM * BK, B_BYTES = LB * TN * BK;
+    constexpr int A_PIECES = A_BYTES / 1024;
+    const int8_t* Ag = g.A + (int64_t)tile_m * nk * A_BYTES + lane * 16;
+    const int8_t* Bg = g.B + (int64_t)tile_n * nk * B_BYTES + lane * 16;
 
     auto issue = [&](int stage, int kt) {
         char* sbase = smem + stage * STAGE;
+        const int8_t* a = Ag + (int64_t)kt * A_BYTES;
+        const int8_t* b = Bg + (int64_t)kt * B_BYTES;
 #pragma unroll
-        for (int pi = 0; pi < PIECES / NWAVES; ++pi) {
+        for (int pi = 0; pi < PPW; ++pi) {
             const int p = wave + NWAVES * pi;       // wave-uniform piece id
-            const int R = p * RPP + prow;           // LDS row of this lane
-            const int8_t* src;
-            int rl;
-            if (R < LA * TM) {
-                const int limb = R / TM;
-                rl = R % TM;
-                src = Ag + limb * planeA + (int64_t)rl * g.Kp;
-            } else {
-                const int R2 = R - LA * TM;
-                const int limb = R2 / TN;
-                rl = R2 % TN;
-                src = Bg + limb * planeB + (int64_t)rl * g.Kp;
-            }
-            const int chunk = pslot ^ swz<BK>(rl);
-            src += (int64_t)kt * BK + chunk * 16;
+            const int8_t* src = p < A_PIECES ? a + p * 1024 : b + (p - A_PIECES) * 1024;
             __builtin_amdgcn_global_load_lds(QG_GLOBAL_PTR(src), QG_LDS_PTR(sbase + p * 1024), 16, 0, 0);
         }
     };
@@ -127,14 +114,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[w][i][j][e] = 0;
 
-    const int nk = (int)(g.Kp / BK);
     const int fr = lane & 31, fh = lane >> 5;
-    issue(0, 0);
+    // NSTAGE-deep LDS ring: tiles kt+1 .. kt+NSTAGE-2 stay in flight across the barrier (counted
+    // vmcnt + raw s_barrier; __syncthreads() would drain the LDS-DMA queue with vmcnt(0)).
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nk) issue(s, s);
+    int cur = 0, nxt = NSTAGE - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) issue(cur ^ 1, kt + 1);
+        // tile kt has landed once at most (NSTAGE-2) newer tiles' pieces are outstanding
+        if (kt + NSTAGE - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // the stage being refilled was last read in iteration kt-1, which every wave has finished
+        if (kt + NSTAGE - 1 < nk) issue(nxt, kt + NSTAGE - 1);
         const char* sA = smem + cur * STAGE;
         const char* sB = sA + LA * TM * BK;
 #pragma unroll
@@ -165,12 +159,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
                         for (int j = 0; j < TJ; ++j)
                             acc[la + lb][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[la][i], b[lb][j], acc[la + lb][i][j], 0, 0, 0);
         }
+        cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+        nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
     }
 
     // epilogue: recombine limb weights in 64-bit, one round + overflow into C, store the container.
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
     const QStep st = g.to_c;
     char* C = (char*)g.C;
+    const int64_t tile_base = ((int64_t)tile_m * tiles_n + tile_n) * TM * TN; // packed C is tiled [tile_m][tile_n][TM][TN]
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -180,28 +177,28 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
                 int64_t s = 0;
 #pragma unroll
                 for (int w = NW - 1; w >= 0; --w) s = s * 256 + (int64_t)acc[w][i][j][e];
-                const int64_t row = (int64_t)tile_m * TM + (wm * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                const int64_t col = (int64_t)tile_n * TN + (wn * TJ + j) * 32 + fr;
-                store_c(C, row * g.Np + col, g.cbytes, qg_step<int64_t>(s, st));
+                const int row = (wm * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                const int col = (wn * TJ + j) * 32 + fr;
+                store_c(C, tile_base + row * TN + col, g.cbytes, qg_step<int64_t>(s, st));
             }
 }
 
-template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ>
+template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE>
 hipError_t launch(const QMfmaArgs& a, hipStream_t st)
 {
     constexpr int TM = WGM * TI * 32, TN = WGN * TJ * 32;
     constexpr int STAGE = (LA * TM + LB * TN) * BK;
-    const int lds = 2 * STAGE;
+    const int lds = NSTAGE * STAGE;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mfma<LA, LB, BK, WGM, WGN, TI, TJ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_mfma<LA, LB, BK, WGM, WGN, TI, TJ, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int64_t blocks = (a.Mp / TM) * (a.Np / TN);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll || a.Kp % BK || a.Mp % TM || a.Np % TN) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_mfma<LA, LB, BK, WGM, WGN, TI, TJ>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
+    hipLaunchKernelGGL((k_mfma<LA, LB, BK, WGM, WGN, TI, TJ, NSTAGE>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
     return hipGetLastError();
 }
 
@@ -223,18 +220,18 @@ QMfmaCfg qg_mfma_pick(int LA, int LB, int64_t M, int64_t N)
 hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
 {
     if (LA == 1 && LB == 1) {
-        if (a.variant == 2) return launch<1, 1, 128, 2, 4, 4, 2>(a, st);
-        return launch<1, 1, 128, 2, 2, 2, 2>(a, st);
+        if (a.variant == 2) return launch<1, 1, 128, 2, 4, 4, 2, 2>(a, st);
+        return launch<1, 1, 128, 2, 2, 2, 2, 2>(a, st);
     }
     switch (LA * 10 + LB) {
-    case 12: return launch<1, 2, 64, 2, 4, 2, 1>(a, st);
-    case 21: return launch<2, 1, 64, 2, 4, 2, 1>(a, st);
-    case 22: return launch<2, 2, 64, 2, 4, 2, 1>(a, st);
-    case 13: return launch<1, 3, 64, 2, 4, 2, 1>(a, st);
-    case 31: return launch<3, 1, 64, 2, 4, 2, 1>(a, st);
-    case 23: return launch<2, 3, 64, 2, 4, 2, 1>(a, st);
-    case 32: return launch<3, 2, 64, 2, 4, 2, 1>(a, st);
-    case 33: return launch<3, 3, 64, 2, 4, 2, 1>(a, st);
+    case 12: return launch<1, 2, 64, 2, 4, 2, 1, 3>(a, st);
+    case 21: return launch<2, 1, 64, 2, 4, 2, 1, 3>(a, st);
+    case 22: return launch<2, 2, 64, 2, 4, 2, 1, 3>(a, st);
+    case 13: return launch<1, 3, 64, 2, 4, 2, 1, 3>(a, st);
+    case 31: return launch<3, 1, 64, 2, 4, 2, 1, 3>(a, st);
+    case 23: return launch<2, 3, 64, 2, 4, 2, 1, 3>(a, st);
+    case 32: return launch<3, 2, 64, 2, 4, 2, 1, 3>(a, st);
+    case 33: return launch<3, 3, 64, 2, 4, 2, 1, 3>(a, st);
     default: return hipErrorInvalidValue;
     }
 }

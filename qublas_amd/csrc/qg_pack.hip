@@ -43,9 +43,15 @@ __device__ __forceinline__ void put_packed(const QPackedGeom& p, char* dst, int 
     if (p.limbs == 0) {
         store_container(dst, ((int64_t)part * p.rows_p + r) * p.K_p + k, p.cbytes, v);
     } else {
+        // pre-tiled, pre-swizzled limb planes (see QPackedGeom)
+        const int64_t nk = p.K_p / p.bk;
+        const int rl = (int)(r % p.tr), kl = (int)(k % p.bk);
+        const int cpr = p.bk / 16, rpb = 256 / p.bk;
+        const int slot = (kl / 16) ^ ((rl / rpb) % cpr);
+        const int64_t blk = ((r / p.tr) * nk + k / p.bk) * p.limbs;
         for (int l = 0; l < p.limbs; ++l) {
             int64_t d = (int64_t)(int8_t)(v & 0xff); // balanced digit in [-128,127]
-            ((int8_t*)dst)[(((int64_t)part * p.limbs + l) * p.rows_p + r) * p.K_p + k] = (int8_t)d;
+            ((int8_t*)dst)[((blk + l) * p.tr + rl) * p.bk + slot * 16 + (kl & 15)] = (int8_t)d;
             v = (v - d) >> 8;
         }
     }
@@ -105,7 +111,12 @@ __global__ __launch_bounds__(256) void k_unpack_c(QCGeom c, const char* __restri
     for (int i = ty; i < 64; i += 4) {
         int64_t m = tm * 64 + i, n = tn * 64 + tx;
         int64_t v = 0;
-        if (m < c.M && n < c.N) v = load_container(packed, ((int64_t)part * c.Mp + m) * c.Np + n, c.cbytes);
+        if (m < c.M && n < c.N) {
+            int64_t idx;
+            if (c.tm == 0) idx = ((int64_t)part * c.Mp + m) * c.Np + n;
+            else idx = ((((int64_t)part * (c.Mp / c.tm) + m / c.tm) * (c.Np / c.tn) + n / c.tn) * c.tm + m % c.tm) * c.tn + n % c.tn;
+            v = load_container(packed, idx, c.cbytes);
+        }
         tile[i][tx] = v; // tile[m_local][n_local]
     }
     __syncthreads();
