@@ -115,52 +115,72 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
                 for (int e = 0; e < 16; ++e) acc[w][i][j][e] = 0;
 
     const int fr = lane & 31, fh = lane >> 5;
-    // NSTAGE-deep LDS ring: tiles kt+1 .. kt+NSTAGE-2 stay in flight across the barrier (counted
-    // vmcnt + raw s_barrier; __syncthreads() would drain the LDS-DMA queue with vmcnt(0)).
+    // Software pipeline (needs NSTAGE == 3 stages, KSTEPS even):
+    //   * fragments are double-buffered in registers: while the MFMAs of k-step s run, the
+    //     ds_read_b128s of k-step s+1 are already in flight, so LDS latency is never exposed;
+    //   * ONE barrier per k-tile, placed before the LAST k-step of tile kt: it publishes tile kt+1
+    //     (every wave has waited for its own LDS-DMA pieces of that tile), after which the first
+    //     fragments of tile kt+1 are prefetched and the stage last read in iteration kt-1 is
+    //     refilled with tile kt+2 (raw s_barrier: __syncthreads() would also drain the DMA queue).
+    static_assert(NSTAGE == 3 && KSTEPS % 2 == 0, "pipeline shape");
+    v4i fa[2][LA][TI], fb[2][LB][TJ];
+    auto load_frags = [&](int set, const char* stage_base, int ks) {
+        const char* sA = stage_base;
+        const char* sB = stage_base + LA * TM * BK;
+        const int c = 2 * ks + fh;
 #pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < nk) issue(s, s);
-    int cur = 0, nxt = NSTAGE - 1;
+        for (int i = 0; i < TI; ++i) {
+            const int ra = (wm * TI + i) * 32 + fr;
+#pragma unroll
+            for (int l = 0; l < LA; ++l) fa[set][l][i] = *(const v4i*)(sA + (l * TM + ra) * BK + ((c ^ swz<BK>(ra)) * 16));
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int rb = (wn * TJ + j) * 32 + fr;
+#pragma unroll
+            for (int l = 0; l < LB; ++l) fb[set][l][j] = *(const v4i*)(sB + (l * TN + rb) * BK + ((c ^ swz<BK>(rb)) * 16));
+        }
+    };
+    auto mfmas = [&](int set) {
+#pragma unroll
+        for (int la = 0; la < LA; ++la)
+#pragma unroll
+            for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[la + lb][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[set][la][i], fb[set][lb][j], acc[la + lb][i][j], 0, 0, 0);
+    };
+
+    // prologue: tiles 0 and 1 in flight, tile 0 published, its first fragments loaded
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_frags(0, smem, 0);
+    int cur = 0;  // stage of tile kt
     for (int kt = 0; kt < nk; ++kt) {
-        // tile kt has landed once at most (NSTAGE-2) newer tiles' pieces are outstanding
-        if (kt + NSTAGE - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // the stage being refilled was last read in iteration kt-1, which every wave has finished
-        if (kt + NSTAGE - 1 < nk) issue(nxt, kt + NSTAGE - 1);
-        const char* sA = smem + cur * STAGE;
-        const char* sB = sA + LA * TM * BK;
+        const char* sc = smem + cur * STAGE;
+        const int nx = cur + 1 == NSTAGE ? 0 : cur + 1;   // stage of tile kt+1
+        const int rf = nx + 1 == NSTAGE ? 0 : nx + 1;     // stage to refill with tile kt+2
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            v4i a[LA][TI], b[LB][TJ];
-            const int c = 2 * ks + fh;
-#pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                const int ra = (wm * TI + i) * 32 + fr;
-#pragma unroll
-                for (int l = 0; l < LA; ++l)
-                    a[l][i] = *(const v4i*)(sA + (l * TM + ra) * BK + ((c ^ swz<BK>(ra)) * 16));
+            if (ks + 1 < KSTEPS) {
+                load_frags((ks + 1) & 1, sc, ks + 1);
+            } else {
+                // tile kt+1 was issued one iteration ago: wait for this wave's pieces, then publish
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (kt + 2 < nk) issue(rf, kt + 2);
+                if (kt + 1 < nk) load_frags(0, smem + nx * STAGE, 0);
             }
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                const int rb = (wn * TJ + j) * 32 + fr;
-#pragma unroll
-                for (int l = 0; l < LB; ++l)
-                    b[l][j] = *(const v4i*)(sB + (l * TN + rb) * BK + ((c ^ swz<BK>(rb)) * 16));
-            }
-#pragma unroll
-            for (int la = 0; la < LA; ++la)
-#pragma unroll
-                for (int lb = 0; lb < LB; ++lb)
-#pragma unroll
-                    for (int i = 0; i < TI; ++i)
-#pragma unroll
-                        for (int j = 0; j < TJ; ++j)
-                            acc[la + lb][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[la][i], b[lb][j], acc[la + lb][i][j], 0, 0, 0);
+            mfmas(ks & 1);
         }
-        cur = cur + 1 == NSTAGE ? 0 : cur + 1;
-        nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+        cur = nx;
     }
 
     // epilogue: recombine limb weights in 64-bit, one round + overflow into C, store the container.
@@ -211,8 +231,8 @@ QMfmaCfg qg_mfma_pick(int LA, int LB, int64_t M, int64_t N)
     if (LA == 1 && LB == 1) {
         // 256x256 tiles halve the L2->LDS traffic per MAC; use them once they fill the 256 CUs
         const int64_t big = ((M + 255) / 256) * ((N + 255) / 256);
-        if (big >= 256) return QMfmaCfg{2, 256, 256, 128};
-        return QMfmaCfg{1, 128, 128, 128};
+        if (big >= 256) return QMfmaCfg{2, 256, 256, 64};
+        return QMfmaCfg{1, 128, 128, 64};
     }
     return QMfmaCfg{3, 128, 128, 64};
 }
@@ -220,8 +240,8 @@ QMfmaCfg qg_mfma_pick(int LA, int LB, int64_t M, int64_t N)
 hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
 {
     if (LA == 1 && LB == 1) {
-        if (a.variant == 2) return launch<1, 1, 128, 2, 4, 4, 2, 2>(a, st);
-        return launch<1, 1, 128, 2, 2, 2, 2, 2>(a, st);
+        if (a.variant == 2) return launch<1, 1, 64, 2, 4, 4, 2, 3>(a, st);
+        return launch<1, 1, 64, 2, 2, 2, 2, 3>(a, st);
     }
     switch (LA * 10 + LB) {
     case 12: return launch<1, 2, 64, 2, 4, 2, 1, 3>(a, st);
