@@ -7,7 +7,7 @@ generated on the device by the same counter-based generator the CPU oracle imple
 
   N = 1 : BASELINE.json's metric configuration — 4096^3 Qgemul, int<8,8> signed operands
           (configs[2]).  Primary line: the linear class (QgemulMulArgs<intBits<17>,fracBits<16>>,
-          QgemulAddArgs<Qu<intBits<29>,fracBits<16>>>, C = Qu<intBits<24>,fracBits<8>>) on the
+          QgemulAddArgs<Qu<intBits<29>,fracBits<16>>>, C = Qu<intBits<23>,fracBits<8>>) on the
           int8-limb MFMA kernel; the default-tag tree-class figure for the same operands and the
           configuration-2/4 int<4,3> single-limb figure ride along in "extra".
   N > 1 : the same per-GPU problem row-sharded over M (rank r owns rows [r*4096,(r+1)*4096) of a
@@ -42,8 +42,8 @@ def workloads():
     e43 = Qu(4, 3)
     return {
         # name: (lower kwargs, description)
-        "c3L": dict(a=e88z, b=e88z, c=Qu(24, 8), mul=Tags(17, 16), add=[Qu(29, 16)],
-                    text="4096^3 Qgemul int<8,8> signed, linear class (MulArgs int17/frac16, AddArgs Qu<29,16>), 3x3 int8-limb MFMA"),
+        "c3L": dict(a=e88z, b=e88z, c=Qu(23, 8), mul=Tags(17, 16), add=[Qu(29, 16)],
+                    text="4096^3 Qgemul int<8,8> signed, linear class (MulArgs int17/frac16, AddArgs Qu<29,16>, C Qu<23,8>), 3x3 int8-limb MFMA"),
         "c3T": dict(a=e88z, b=e88z, c=e88z, mul=None, add=None,
                     text="4096^3 Qgemul int<8,8> signed TRN::TCPL/SAT::ZERO, default tags (tree class), exact tree on VALU"),
         "c2L": dict(a=e43, b=e43, c=e43, mul=Tags(9, 6), add=[Qu(21, 6)],

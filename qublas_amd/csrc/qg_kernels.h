@@ -32,7 +32,7 @@ struct QPackedGeom {
 
 struct QCGeom {
     int64_t M, N, Mp, Np;   // logical / padded extents of packed C
-    int32_t tm, tn;         // 0: row-major [part][Mp][Np]; else tiled [part][Mp/tm][Np/tn][tm][tn]
+    int32_t tm, tn;         // 0: row-major [part][Mp][Np]; else tiled [part][Mp/tm][Np/tn][tn cols][tm rows]
     int32_t cbytes;         // 1|2|4|8 container
     int32_t parts;
     int64_t ldc;            // host leading dimension (elements)
@@ -48,6 +48,10 @@ hipError_t qg_launch_unpack_c(const QCGeom& c, const void* packed, void* dst, hi
 hipError_t qg_launch_tree_generic(const QTreeTable* dev_table, int parts, const void* A, const void* B, void* C, int64_t M,
                                   int64_t N, int64_t K, const QPackedGeom& pa, const QPackedGeom& pb, const QCGeom& pc,
                                   hipStream_t st);
+
+// exact tree evaluation, real descriptors with K = 2^p >= 32 and 32-bit intermediates (A, B packed as int32)
+hipError_t qg_launch_tree_fast(const QTreeTable* dev_table, int n_levels, int split_s, int mul24, const void* A, const void* B, void* C,
+                               int64_t M, int64_t N, int64_t K, int cbytes, hipStream_t st);
 
 // linear class on int8 MFMA with LA x LB limbs
 struct QMfmaCfg {

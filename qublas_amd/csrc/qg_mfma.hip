@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include "qg_kernels.h"
+#include "qg_step_all.h"
 
 namespace {
 
@@ -35,16 +36,6 @@ __device__ __forceinline__ int swz(int r)
     constexpr int CPR = BK / 16;   // chunks per row
     constexpr int RPB = 256 / BK;  // rows per 256-byte bank row
     return (r / RPB) % CPR;
-}
-
-__device__ __forceinline__ void store_c(char* C, int64_t idx, int cbytes, int64_t v)
-{
-    switch (cbytes) {
-    case 1: ((int8_t*)C)[idx] = (int8_t)v; break;
-    case 2: ((int16_t*)C)[idx] = (int16_t)v; break;
-    case 4: ((int32_t*)C)[idx] = (int32_t)v; break;
-    default: ((int64_t*)C)[idx] = v; break;
-    }
 }
 
 // LA, LB : int8 limbs per A / B element          BK       : k-tile in bytes
@@ -183,24 +174,59 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
         cur = nx;
     }
 
-    // epilogue: recombine limb weights in 64-bit, one round + overflow into C, store the container.
-    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
+    // epilogue: recombine limb weights, ONE round + overflow into C, store.
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5),
+    // i.e. every lane owns runs of 4 consecutive rows of one column.  Packed C is tiled
+    // [tile_m][tile_n][col][row] (column-major inside the tile, the order of the host tensor), so a
+    // run of 4 rows is one 4/8/16/32-byte store per lane.
     const QStep st = g.to_c;
     char* C = (char*)g.C;
-    const int64_t tile_base = ((int64_t)tile_m * tiles_n + tile_n) * TM * TN; // packed C is tiled [tile_m][tile_n][TM][TN]
+    const int64_t tile_base = ((int64_t)tile_m * tiles_n + tile_n) * TM * TN;
+    using S = std::conditional_t<(NW == 1), int32_t, int64_t>;  // one limb pair: the int32 accumulator is the dot product
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j)
+        for (int j = 0; j < TJ; ++j) {
+            S s[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                int64_t s = 0;
+                S x = (S)acc[NW - 1][i][j][e];
 #pragma unroll
-                for (int w = NW - 1; w >= 0; --w) s = s * 256 + (int64_t)acc[w][i][j][e];
-                const int row = (wm * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                const int col = (wn * TJ + j) * 32 + fr;
-                store_c(C, tile_base + row * TN + col, g.cbytes, qg_step<int64_t>(s, st));
+                for (int w = NW - 2; w >= 0; --w) x = x * 256 + (S)acc[w][i][j][e];
+                s[e] = x;
             }
+            qg_step_all<S, 16>(s, st);
+            const int col = (wn * TJ + j) * 32 + fr;
+            const int row0 = (wm * TI + i) * 32 + 4 * fh;
+            const int64_t base = tile_base + (int64_t)col * TM + row0;
+            switch (g.cbytes) {
+            case 1:
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(uint32_t*)(C + base + 8 * q) = (uint32_t)(s[4 * q] & 0xff) | ((uint32_t)(s[4 * q + 1] & 0xff) << 8) |
+                                                     ((uint32_t)(s[4 * q + 2] & 0xff) << 16) | ((uint32_t)(s[4 * q + 3] & 0xff) << 24);
+                break;
+            case 2:
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(uint2*)(C + (base + 8 * q) * 2) = make_uint2((uint32_t)(s[4 * q] & 0xffff) | ((uint32_t)(s[4 * q + 1] & 0xffff) << 16),
+                                                                 (uint32_t)(s[4 * q + 2] & 0xffff) | ((uint32_t)(s[4 * q + 3] & 0xffff) << 16));
+                break;
+            case 4:
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(int4*)(C + (base + 8 * q) * 4) = make_int4((int)s[4 * q], (int)s[4 * q + 1], (int)s[4 * q + 2], (int)s[4 * q + 3]);
+                break;
+            default:
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int64_t* p = (int64_t*)(C + (base + 8 * q) * 8);
+                    *(longlong2*)p = make_longlong2((int64_t)s[4 * q], (int64_t)s[4 * q + 1]);
+                    *(longlong2*)(p + 2) = make_longlong2((int64_t)s[4 * q + 2], (int64_t)s[4 * q + 3]);
+                }
+                break;
+            }
+        }
 }
 
 template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE>

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_unpack_c(QCGeom c, const char* __restri
         if (m < c.M && n < c.N) {
             int64_t idx;
             if (c.tm == 0) idx = ((int64_t)part * c.Mp + m) * c.Np + n;
-            else idx = ((((int64_t)part * (c.Mp / c.tm) + m / c.tm) * (c.Np / c.tn) + n / c.tn) * c.tm + m % c.tm) * c.tn + n % c.tn;
+            else idx = ((((int64_t)part * (c.Mp / c.tm) + m / c.tm) * (c.Np / c.tn) + n / c.tn) * c.tn + n % c.tn) * c.tm + m % c.tm;
             v = load_container(packed, idx, c.cbytes);
         }
         tile[i][tx] = v; // tile[m_local][n_local]

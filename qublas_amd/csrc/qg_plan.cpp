@@ -25,6 +25,8 @@ struct Ctx {
     QAnalysis* out;
     bool exact = true;      // every step so far was the identity
     int max_bits = 1;
+    int max_bits_np = 1;    // the same, not counting full-precision products before their rounding
+    bool raw_product = false;
     void fail(int st, const char* why)
     {
         if (out->status == QG_OK) {
@@ -35,8 +37,9 @@ struct Ctx {
     void note(Rng r)
     {
         int b = bits_of(r.lo), c = bits_of(r.hi);
+        if (c > b) b = c;
         if (b > max_bits) max_bits = b;
-        if (c > max_bits) max_bits = c;
+        if (!raw_product && b > max_bits_np) max_bits_np = b;
     }
 };
 
@@ -81,6 +84,7 @@ QStep make_step(int fromF, qfmt to, bool identity)
 Rng through(Ctx& c, Rng in, int fromF, qfmt to, bool identity)
 {
     c.note(in);
+    c.raw_product = false;
     if (identity) return in;
     int d = fromF - (int)to.F;
     Rng r = in;
@@ -146,6 +150,7 @@ Val do_mul(Ctx& c, Val a, Val b, qfmt res, QNode* node)
     node->q = make_step((int)a.f.F + (int)b.f.F, res, false);
     Val v;
     v.f = res;
+    c.raw_product = true; // the unrounded product is noted for max_bits only
     v.r = through(c, mul_rng(a.r, b.r), (int)a.f.F + (int)b.f.F, res, false);
     return v;
 }
@@ -316,9 +321,29 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     if (out->status != QG_OK) return;
 
     out->max_bits = c.max_bits;
+    out->max_bits_np = c.max_bits_np;
     if (c.max_bits > 62) { c.fail(QG_EUNSUPPORTED, "an intermediate needs more than 62 bits"); return; }
     out->linear_ok = (c.exact && !cx) ? 1 : 0;
     out->cls = out->linear_ok ? QG_CLASS_LINEAR : QG_CLASS_TREE;
+    // 32-bit tree kernel (qg_tree_fast.hip): real, K a power of two >= 32, every value except the
+    // unrounded product fits 31 bits, and the product is either directly 32-bit or splittable at
+    // its rounding shift
+    out->tree_fast_ok = 0;
+    if (!cx && d->K >= 32 && (d->K & (d->K - 1)) == 0 && d->n_levels <= 16 && c.max_bits_np <= 31) {
+        const int bitsA = 1 + (int)d->a[0].I + (int)d->a[0].F, bitsB = 1 + (int)d->b[0].I + (int)d->b[0].F;
+        const int sh = T.mul[0].q.d;
+        int bh = bitsB - sh;
+        if (bh < 1) bh = 1;
+        if (bitsA + bitsB <= 31) {
+            out->tree_fast_ok = 1;
+            out->split_s = 0;
+            out->mul24_ok = bitsA <= 24 && bitsB <= 24;
+        } else if (sh >= 1 && sh <= 23 && bitsA + bh <= 31 && bitsA + sh <= 31) {
+            out->tree_fast_ok = 1;
+            out->split_s = sh;
+            out->mul24_ok = bitsA <= 24 && bh <= 24;
+        }
+    }
     if (!out->linear_ok)
         snprintf(out->reason, sizeof out->reason, "%s",
                  cx ? "complex operands: exact tree evaluation" : "a product or tree node may round or overflow: exact tree evaluation");

@@ -28,6 +28,10 @@ struct QAnalysis {
     int max_bits;            // widest signed intermediate (bits incl. sign)
     int linear_ok;           // every conversion on the path is provably the identity
     int dot_bits;            // class L: bits of the exact K-term dot product
+    int max_bits_np;         // widest intermediate not counting unrounded products
+    int tree_fast_ok;        // the 32-bit tree kernel applies
+    int split_s;             // > 0: product evaluated split at its rounding shift
+    int mul24_ok;            // multiplies fit v_mul_i32_i24
     char reason[96];
     QTreeTable tree;
     QLinearEpilogue lin;

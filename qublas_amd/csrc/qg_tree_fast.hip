@@ -1,0 +1,341 @@
+// qg_tree_fast.hip — exact tree-order evaluation for the hot real-valued shapes, 32-bit VALU path
+// ("i32 wavefront-MAC", BASELINE.json configuration 3).
+//
+// Same semantics as k_tree_generic (qg_tree.hip): every product is quantised (Qmul,
+// /root/reference/include/QuBLAS.h:3152-3170) and every node of the pairwise tree is quantised (Qadd inside
+// Reducer::reduce_impl, QuBLAS.h:4960-4984) in the reference's order.  What changes is the mapping:
+//   * all values fit 32 bits (the planner proves it), so nodes are v_add + 2..3 VALU ops;
+//   * products wider than 32 bits never materialise: with the product's rounding shift s,
+//     b = bh*2^s + bl (bl unsigned), a*b = (a*bh)*2^s + a*bl, so floor(a*b / 2^s) = a*bh + ((a*bl) >> s)
+//     and the discarded low bits are (a*bl) & (2^s-1) — two 32-bit multiplies, split done once per
+//     staged B element instead of once per MAC;
+//   * each lane owns a 4x2 block of outputs; the tree is streamed as a binary counter whose lower
+//     four levels (16 leaves) are fully unrolled in registers and whose upper levels are a
+//     statically indexed register array, so nothing spills to scratch;
+//   * per-level formats and modes stay runtime values (wave-uniform scalar loads and scalar
+//     branches hoisted around the 8-output loops), so one kernel serves every real descriptor
+//     whose K is a power of two >= 32.
+#include <hip/hip_runtime.h>
+
+#include "qg_kernels.h"
+
+namespace {
+
+constexpr int KC = 32;      // k-chunk staged in LDS
+constexpr int TMB = 64;     // rows of C per block   (16 thread rows x 4)
+constexpr int TNB = 32;     // columns of C per block (16 thread cols x 2)
+constexpr int NOUT = 8;
+constexpr int PITCH = KC + 4;
+
+// round (d > 0) NOUT values in place; x = h*2^d + l is given as (h, l) when SPLIT, else as v itself
+__device__ __forceinline__ void round_all(int (&v)[NOUT], int d, int Q)
+{
+    if (d == 0) return;
+    if (d < 0) {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) v[o] = (int)((unsigned)v[o] << (-d));
+        return;
+    }
+    const int mask = (1 << d) - 1, t = 1 << (d - 1);
+    switch (Q) {
+    case QG_TRN_TCPL:
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) v[o] >>= d;
+        break;
+    case QG_TRN_SMGN:
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) v[o] = (v[o] >> d) + ((v[o] < 0) & ((v[o] & mask) != 0));
+        break;
+    case QG_RND_POS_INF:
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) v[o] = (v[o] >> d) + ((v[o] & mask) >= t);
+        break;
+    case QG_RND_NEG_INF:
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) v[o] = (v[o] >> d) + ((v[o] & mask) > t);
+        break;
+    case QG_RND_ZERO:
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) { const int l = v[o] & mask; v[o] = (v[o] >> d) + ((l > t) | ((l == t) & (v[o] < 0))); }
+        break;
+    case QG_RND_INF:
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) { const int l = v[o] & mask; v[o] = (v[o] >> d) + ((l > t) | ((l == t) & (v[o] > 0))); }
+        break;
+    default: // RND::CONV
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) { const int l = v[o] & mask, h = v[o] >> d; v[o] = h + ((l > t) | ((l == t) & (h & 1))); }
+        break;
+    }
+}
+
+__device__ __forceinline__ void overflow_all(int (&v)[NOUT], const QStep& s)
+{
+    const int lo = (int)s.lo, hi = (int)s.hi;
+    switch (s.O) {
+    case QG_SAT_TCPL:
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) v[o] = min(max(v[o], lo), hi);
+        break;
+    case QG_SAT_ZERO: {
+        const unsigned span = (unsigned)(hi - lo);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) v[o] = ((unsigned)(v[o] - lo) > span) ? 0 : v[o];
+        break;
+    }
+    case QG_SAT_SMGN: {
+        const int l2 = s.S ? -hi : 0;
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) v[o] = min(max(v[o], l2), hi);
+        break;
+    }
+    default: // WRP::TCPL
+        if (s.S) {
+            const int sh = 31 - s.W;
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) v[o] = (int)((unsigned)v[o] << sh) >> sh;
+        } else {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) v[o] &= hi;
+        }
+        break;
+    }
+}
+
+__device__ __forceinline__ void step_all(int (&v)[NOUT], const QStep& s)
+{
+    if (s.identity) return;
+    round_all(v, s.d, s.Q);
+    overflow_all(v, s);
+}
+
+// node of level l: both children have the level's input format (no alignment shift for real GEMMs)
+__device__ __forceinline__ void node_all(int (&v)[NOUT], const int (&x)[NOUT], const QTreeTable* __restrict__ t, int l)
+{
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) v[o] = x[o] + v[o];
+    step_all(v, t->level_add[0][l].q);
+    step_all(v, t->level_cvt[0][l]);
+}
+
+// SPLIT leaf rounding from (h, l): x = h*2^s + l, 0 <= l < 2^s
+__device__ __forceinline__ void round_split_all(int (&h)[NOUT], const int (&l)[NOUT], int s, int Q)
+{
+    const int t = 1 << (s - 1);
+    switch (Q) {
+    case QG_TRN_TCPL: break;
+    case QG_TRN_SMGN:
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) h[o] += (h[o] < 0) & (l[o] != 0);
+        break;
+    case QG_RND_POS_INF:
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) h[o] += (l[o] >= t);
+        break;
+    case QG_RND_NEG_INF:
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) h[o] += (l[o] > t);
+        break;
+    case QG_RND_ZERO:
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) h[o] += (l[o] > t) | ((l[o] == t) & (h[o] < 0));
+        break;
+    case QG_RND_INF:
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) h[o] += (l[o] > t) | ((l[o] == t) & (h[o] >= 0)); // x > 0 <=> h > 0, or h == 0 with l == t > 0
+        break;
+    default:
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) h[o] += (l[o] > t) | ((l[o] == t) & (h[o] & 1));
+        break;
+    }
+}
+
+struct QTreeFastArgs {
+    const QTreeTable* tab;
+    const int32_t* A;   // [M][K]
+    const int32_t* B;   // [N][K]
+    char* C;            // [M][N] containers
+    int64_t M, N, K;
+    int32_t cbytes;
+    int32_t split_s;    // SPLIT: rounding shift of the product (= bits split off B)
+};
+
+template <bool SPLIT, bool MUL24, int MAXL>
+__global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
+{
+    __shared__ __attribute__((aligned(16))) int sA[TMB][PITCH];
+    __shared__ __attribute__((aligned(16))) int sBh[TNB][PITCH];
+    __shared__ __attribute__((aligned(16))) int sBl[SPLIT ? TNB : 1][PITCH];
+    const QTreeTable* __restrict__ tab = g.tab;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int64_t tiles_n = (g.N + TNB - 1) / TNB;
+    const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * TMB, n0 = (int64_t)(blockIdx.x % tiles_n) * TNB;
+    const int nl = tab->n_levels;
+    const int s = g.split_s;
+    const int smask = SPLIT ? ((1 << s) - 1) : 0;
+    const QStep pstep = tab->mul[0].q;
+
+    int low[4][NOUT];
+    int up[MAXL - 4][NOUT];
+    int v[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) v[o] = 0;
+
+    for (int64_t k0 = 0; k0 < g.K; k0 += KC) {
+        __syncthreads();
+        // stage A: 64 rows x 32 k = 512 16-byte chunks, 2 per thread; B: 32 rows -> 256 chunks, 1 per thread
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ch = tid + 256 * c, r = ch >> 3, q = ch & 7;
+            int4 x = make_int4(0, 0, 0, 0);
+            if (m0 + r < g.M) x = *(const int4*)(g.A + (m0 + r) * g.K + k0 + q * 4);
+            *(int4*)&sA[r][q * 4] = x;
+        }
+        {
+            const int r = tid >> 3, q = tid & 7;
+            int4 x = make_int4(0, 0, 0, 0);
+            if (n0 + r < g.N) x = *(const int4*)(g.B + (n0 + r) * g.K + k0 + q * 4);
+            if (SPLIT) {
+                *(int4*)&sBh[r][q * 4] = make_int4(x.x >> s, x.y >> s, x.z >> s, x.w >> s);
+                *(int4*)&sBl[r][q * 4] = make_int4(x.x & smask, x.y & smask, x.z & smask, x.w & smask);
+            } else {
+                *(int4*)&sBh[r][q * 4] = x;
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int kb = 0; kb < KC / 16; ++kb) {
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                int4 a4[4], bh4[2], bl4[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a4[i] = *(const int4*)&sA[ty * 4 + i][kb * 16 + kq * 4];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bh4[j] = *(const int4*)&sBh[tx * 2 + j][kb * 16 + kq * 4];
+                    if (SPLIT) bl4[j] = *(const int4*)&sBl[tx * 2 + j][kb * 16 + kq * 4];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kk = kq * 4 + e; // compile-time leaf index inside the 16-leaf block
+                    int av[4], bhv[2], blv[2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) av[i] = e == 0 ? a4[i].x : e == 1 ? a4[i].y : e == 2 ? a4[i].z : a4[i].w;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        bhv[j] = e == 0 ? bh4[j].x : e == 1 ? bh4[j].y : e == 2 ? bh4[j].z : bh4[j].w;
+                        if (SPLIT) blv[j] = e == 0 ? bl4[j].x : e == 1 ? bl4[j].y : e == 2 ? bl4[j].z : bl4[j].w;
+                    }
+                    // ---- leaves: 8 quantised products
+                    if (SPLIT) {
+                        int lw[NOUT];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const int t = MUL24 ? __mul24(av[i], blv[j]) : av[i] * blv[j];
+                                v[i * 2 + j] = (MUL24 ? __mul24(av[i], bhv[j]) : av[i] * bhv[j]) + (t >> s);
+                                lw[i * 2 + j] = t & smask;
+                            }
+                        round_split_all(v, lw, s, pstep.Q);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) v[i * 2 + j] = MUL24 ? __mul24(av[i], bhv[j]) : av[i] * bhv[j];
+                        round_all(v, pstep.d, pstep.Q);
+                    }
+                    overflow_all(v, pstep);
+                    // ---- lower four levels: binary counter on the compile-time index kk
+                    if ((kk & 1) == 0) {
+#pragma unroll
+                        for (int o = 0; o < NOUT; ++o) low[0][o] = v[o];
+                    } else {
+                        node_all(v, low[0], tab, 0);
+                        if ((kk & 2) == 0) {
+#pragma unroll
+                            for (int o = 0; o < NOUT; ++o) low[1][o] = v[o];
+                        } else {
+                            node_all(v, low[1], tab, 1);
+                            if ((kk & 4) == 0) {
+#pragma unroll
+                                for (int o = 0; o < NOUT; ++o) low[2][o] = v[o];
+                            } else {
+                                node_all(v, low[2], tab, 2);
+                                if ((kk & 8) == 0) {
+#pragma unroll
+                                    for (int o = 0; o < NOUT; ++o) low[3][o] = v[o];
+                                } else {
+                                    node_all(v, low[3], tab, 3);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- upper levels: v is the partial sum of one 16-leaf block (an element of list 4)
+            const unsigned idx = (unsigned)((k0 >> 4) + kb);
+            bool parked = false; // wave-uniform: the carry stopped at a free slot
+#pragma unroll
+            for (int u = 0; u < MAXL - 4; ++u) {
+                if (!parked && 4 + u < nl) {
+                    if (((idx >> u) & 1u) == 0) {
+#pragma unroll
+                        for (int o = 0; o < NOUT; ++o) up[u][o] = v[o];
+                        parked = true;
+                    } else {
+                        node_all(v, up[u], tab, 4 + u);
+                    }
+                }
+            }
+        }
+    }
+    // after the last block the counter has carried through every level: v holds the root
+    step_all(v, tab->c_cvt[0]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t m = m0 + ty * 4 + i, n = n0 + tx * 2 + j;
+            if (m < g.M && n < g.N) {
+                const int64_t idx = m * g.N + n;
+                const int r = v[i * 2 + j];
+                switch (g.cbytes) {
+                case 1: ((int8_t*)g.C)[idx] = (int8_t)r; break;
+                case 2: ((int16_t*)g.C)[idx] = (int16_t)r; break;
+                case 4: ((int32_t*)g.C)[idx] = r; break;
+                default: ((int64_t*)g.C)[idx] = (int64_t)r; break;
+                }
+            }
+        }
+}
+
+} // namespace
+
+template <bool SPLIT, bool MUL24>
+static void launch_tf(int n_levels, dim3 grid, hipStream_t st, const QTreeFastArgs& g)
+{
+    if (n_levels <= 12) hipLaunchKernelGGL((k_tree_fast<SPLIT, MUL24, 12>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((k_tree_fast<SPLIT, MUL24, 16>), grid, dim3(256), 0, st, g);
+}
+
+hipError_t qg_launch_tree_fast(const QTreeTable* dev_table, int n_levels, int split_s, int mul24, const void* A, const void* B, void* C,
+                               int64_t M, int64_t N, int64_t K, int cbytes, hipStream_t st)
+{
+    if (K % KC != 0 || n_levels < 5 || n_levels > 16) return hipErrorInvalidValue;
+    QTreeFastArgs g{dev_table, (const int32_t*)A, (const int32_t*)B, (char*)C, M, N, K, cbytes, split_s};
+    const int64_t blocks = ((M + TMB - 1) / TMB) * ((N + TNB - 1) / TNB);
+    if (blocks <= 0) return hipSuccess;
+    if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
+    dim3 grid((unsigned)blocks);
+    if (split_s > 0) {
+        if (mul24) launch_tf<true, true>(n_levels, grid, st, g);
+        else launch_tf<true, false>(n_levels, grid, st, g);
+    } else {
+        if (mul24) launch_tf<false, true>(n_levels, grid, st, g);
+        else launch_tf<false, false>(n_levels, grid, st, g);
+    }
+    return hipGetLastError();
+}

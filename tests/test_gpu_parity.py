@@ -130,8 +130,40 @@ def test_tree_kernel_any_k(oracle, K):
 def test_config1_and_config3_semantics_tree(oracle):
     """Configuration 1/3 semantics (int<8,8>, TCPL, SAT::ZERO, default tags: tree class) at a size the
     oracle finishes quickly; the 4x4x4 known answer itself is in the golden set."""
-    c = _vs_oracle(oracle, E88Z, E88Z, E88Z, 96, 80, 4096, dist=1, expect_kernel="tree_i64")
+    c = _vs_oracle(oracle, E88Z, E88Z, E88Z, 96, 80, 4096, dist=1, expect_kernel="tree_i32")
     assert float(np.mean(c == 0)) < 0.9
+    c2 = _vs_oracle(oracle, E88Z, E88Z, E88Z, 96, 80, 4096, dist=1, flags=capi.OPT_GENERIC_TREE, expect_kernel="tree_i64")
+    assert np.array_equal(c, c2)
+    _vs_oracle(oracle, E88Z, E88Z, E88Z, 70, 50, 4096, dist=0, expect_kernel="tree_i32")
+
+
+FAST_TREE_CASES = [
+    # (A, B, C, mul tags, level list, K, dist, what)
+    (Qu(8, 8, True, TRN.TCPL, SAT.ZERO), Qu(8, 8, True, TRN.TCPL, SAT.ZERO), Qu(8, 8, True, TRN.TCPL, SAT.ZERO), None, None, 64, 1, "split mul24 TCPL/ZERO"),
+    (Qu(8, 10), Qu(8, 10), Qu(12, 10), Tags(fracBits=10, QuMode=RND.CONV), [Qu(12, 10, True, RND.CONV, SAT.SMGN)], 256, 1, "split mul24 CONV"),
+    (Qu(8, 10), Qu(8, 10), Qu(12, 6), Tags(fracBits=10, QuMode=RND.POS_INF, OfMode=SAT.ZERO), [Qu(10, 8, True, RND.NEG_INF), Qu(12, 6, True, RND.ZERO)], 128, 1, "split POS_INF"),
+    (Qu(8, 10), Qu(8, 10), Qu(12, 6), Tags(fracBits=10, QuMode=RND.INF), [Qu(10, 9, True, RND.INF, WRP.TCPL)], 64, 0, "split INF + wrap levels"),
+    (Qu(8, 10), Qu(8, 10), Qu(12, 6), Tags(fracBits=10, QuMode=RND.ZERO), [Qu(14, 10, True, TRN.SMGN)], 64, 1, "split ZERO"),
+    (Qu(8, 10), Qu(8, 10), Qu(12, 6), Tags(fracBits=10, QuMode=TRN.SMGN), None, 64, 1, "split SMGN"),
+    (Qu(8, 10), Qu(8, 10), Qu(12, 6), Tags(fracBits=10, QuMode=RND.NEG_INF), None, 64, 1, "split NEG_INF"),
+    (Qu(12, 12), Qu(6, 5), Qu(16, 8), Tags(fracBits=11), [Qu(16, 11)], 64, 1, "split without mul24"),
+    (Qu(4, 3), Qu(4, 3), Qu(16, 3), None, None, 1024, 1, "direct mul24 default tags"),
+    (Qu(4, 3), Qu(4, 3), Qu(16, 3), Qu(5, 4, True, RND.INF, SAT.TCPL), [Qu(6, 5, True, RND.CONV, SAT.SMGN), Qu(8, 4, True, RND.ZERO, SAT.TCPL)], 512, 0, "direct, per-level list"),
+    (Qu(4, 4, False), Qu(4, 4, False), Qu(14, 4, False), None, None, 64, 0, "unsigned direct"),
+    (Qu(4, 4, False), Qu(4, 3), Qu(14, 4), Tags(OfMode=WRP.TCPL, intBits=6), [Qu(7, 4, False, TRN.TCPL, WRP.TCPL)], 64, 0, "unsigned wrap levels"),
+    (Qu(13, 12), Qu(3, 1), Qu(16, 8), Tags(fracBits=12, QuMode=RND.CONV), [Qu(15, 12)], 32, 1, "direct without mul24"),
+    (Qu(6, -3), Qu(6, -3), Qu(16, -3), Tags(FullPrec=True), [Qu(20, -6)], 64, 0, "negative fracBits, FullPrec"),
+]
+
+
+@pytest.mark.parametrize("case", FAST_TREE_CASES, ids=lambda c: c[7])
+def test_fast_tree_kernel_modes(oracle, case):
+    ea, eb, ec, mul, levels, K, dist, _ = case
+    kw = dict(mul_args=mul, add_args=levels)
+    a = _vs_oracle(oracle, ea, eb, ec, 70, 37, K, dist=dist, expect_kernel="tree_i32", **kw)
+    b = _vs_oracle(oracle, ea, eb, ec, 70, 37, K, dist=dist, flags=capi.OPT_GENERIC_TREE, expect_kernel="tree_i64", **kw)
+    assert np.array_equal(a, b)
+    a = _vs_oracle(oracle, ea, eb, ec, 33, 65, K, dist=0, expect_kernel="tree_i32", transposed_a=True, **kw)
 
 
 def test_config5_complex_tf(oracle):
