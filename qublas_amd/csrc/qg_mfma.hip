@@ -15,6 +15,7 @@
 // whose 16-byte chunks are XOR-swizzled on the SOURCE address (the LDS-DMA destination is
 // lane-linear) so that the ds_read_b128 fragment reads are bank-conflict free.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "qg_kernels.h"
 #include "qg_step_all.h"
@@ -40,7 +41,7 @@ __device__ __forceinline__ int swz(int r)
 
 // LA, LB : int8 limbs per A / B element          BK       : k-tile in bytes
 // WGM x WGN waves per workgroup                  TI x TJ  : 32x32 MFMA tiles per wave
-template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE>
+template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE, int ABL>
 __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 {
     constexpr int TM = WGM * TI * 32, TN = WGN * TJ * 32;
@@ -160,14 +161,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             if (ks + 1 < KSTEPS) {
-                load_frags((ks + 1) & 1, sc, ks + 1);
+                if (ABL != 2 && ABL != 3 && ABL != 4) load_frags((ks + 1) & 1, sc, ks + 1);
             } else {
                 // tile kt+1 was issued one iteration ago: wait for this wave's pieces, then publish
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if (kt + 2 < nk) issue(rf, kt + 2);
-                if (kt + 1 < nk) load_frags(0, smem + nx * STAGE, 0);
+                if (ABL != 4) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+                if (kt + 2 < nk && ABL != 1 && ABL != 3 && ABL != 4) issue(rf, kt + 2);
+                if (kt + 1 < nk && ABL != 2 && ABL != 3 && ABL != 4) load_frags(0, smem + nx * STAGE, 0);
             }
             mfmas(ks & 1);
         }
@@ -196,6 +199,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
                 s[e] = x;
             }
             qg_step_all<S, 16>(s, st);
+            if (ABL == 5 && s[0] != (S)0x7ead1234) continue; // diagnostic: keep the arithmetic, drop the stores
             const int col = (wn * TJ + j) * 32 + fr;
             const int row0 = (wm * TI + i) * 32 + 4 * fh;
             const int64_t base = tile_base + (int64_t)col * TM + row0;
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
         }
 }
 
-template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE>
+template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE, int ABL = 0>
 hipError_t launch(const QMfmaArgs& a, hipStream_t st)
 {
     constexpr int TM = WGM * TI * 32, TN = WGN * TJ * 32;
@@ -237,14 +241,14 @@ hipError_t launch(const QMfmaArgs& a, hipStream_t st)
     const int lds = NSTAGE * STAGE;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mfma<LA, LB, BK, WGM, WGN, TI, TJ, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_mfma<LA, LB, BK, WGM, WGN, TI, TJ, NSTAGE, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int64_t blocks = (a.Mp / TM) * (a.Np / TN);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll || a.Kp % BK || a.Mp % TM || a.Np % TN) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_mfma<LA, LB, BK, WGM, WGN, TI, TJ, NSTAGE>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
+    hipLaunchKernelGGL((k_mfma<LA, LB, BK, WGM, WGN, TI, TJ, NSTAGE, ABL>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
     return hipGetLastError();
 }
 
@@ -263,8 +267,37 @@ QMfmaCfg qg_mfma_pick(int LA, int LB, int64_t M, int64_t N)
     return QMfmaCfg{3, 128, 128, 64};
 }
 
+// QG_ABLATE=1..5 selects diagnostic variants of the two benchmarked kernels (results are WRONG by
+// construction; used only by tools/ablate.py to price the phases of the loop)
+static int ablation()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("QG_ABLATE"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
 {
+    if (const int abl = ablation()) {
+        if (LA == 3 && LB == 3) {
+            switch (abl) {
+            case 1: return launch<3, 3, 64, 2, 4, 2, 1, 3, 1>(a, st);
+            case 2: return launch<3, 3, 64, 2, 4, 2, 1, 3, 2>(a, st);
+            case 3: return launch<3, 3, 64, 2, 4, 2, 1, 3, 3>(a, st);
+            case 4: return launch<3, 3, 64, 2, 4, 2, 1, 3, 4>(a, st);
+            default: return launch<3, 3, 64, 2, 4, 2, 1, 3, 5>(a, st);
+            }
+        }
+        if (LA == 1 && LB == 1 && a.variant == 2) {
+            switch (abl) {
+            case 1: return launch<1, 1, 64, 2, 4, 4, 2, 3, 1>(a, st);
+            case 2: return launch<1, 1, 64, 2, 4, 4, 2, 3, 2>(a, st);
+            case 3: return launch<1, 1, 64, 2, 4, 4, 2, 3, 3>(a, st);
+            case 4: return launch<1, 1, 64, 2, 4, 4, 2, 3, 4>(a, st);
+            default: return launch<1, 1, 64, 2, 4, 4, 2, 3, 5>(a, st);
+            }
+        }
+    }
     if (LA == 1 && LB == 1) {
         if (a.variant == 2) return launch<1, 1, 64, 2, 4, 4, 2, 3>(a, st);
         return launch<1, 1, 64, 2, 2, 2, 2, 3>(a, st);
