@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3L", choices=["c3L", "c3T", "c2L"])
     ap.add_argument("--size", type=int, default=4096, help="M=N=K per GPU")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the script on a 1-GPU box)")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -128,10 +129,15 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run for --gpus > 1")
+    ndev = torch.cuda.device_count()
+    local = local % max(1, ndev)   # one rank per GPU on the driver's node; a rehearsal may stack ranks on one card
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
 
     wls = workloads()
     wl = wls[args.workload]
@@ -144,22 +150,38 @@ def main():
     dev = torch.device("cuda", local)
     tA = torch.empty(pb[0], dtype=torch.uint8, device=dev)
     tB = torch.empty(pb[1], dtype=torch.uint8, device=dev)
-    tC = torch.empty(pb[2], dtype=torch.uint8, device=dev)
+    # two C buffers: the gather of step i overlaps the GEMM of step i+1
+    tCs = [torch.empty(pb[2], dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
+    tC = tCs[0]
     # rank r's shard of A: rows [r*M, (r+1)*M) of the (world*M) x K operand -> distinct seed stream
     plan.fill(capi.OPERAND_A, 1 + 1000 * rank, 0, tA.data_ptr())
     plan.fill(capi.OPERAND_B, 2, 0, tB.data_ptr())
     ctx.sync()
-    gather_list = None
+    gather_lists = [None, None]
+    on_host = world > 1 and args.backend != "nccl"
     if world > 1 and rank == 0:
-        gather_list = [torch.empty_like(tC) for _ in range(world)]
+        gather_lists = [[torch.empty(pb[2], dtype=torch.uint8, device="cpu" if on_host else dev) for _ in range(world)]
+                        for _ in range(2)]
+    pending = [None, None]
+    state = {"i": 0}
 
     def step():
-        plan.execute(tC.data_ptr(), tA.data_ptr(), tB.data_ptr())
+        b = state["i"] & 1
+        state["i"] += 1
+        if world > 1 and pending[b] is not None:
+            pending[b].wait()          # buffer b was handed to the collective two steps ago
+            pending[b] = None
+        plan.execute(tCs[b].data_ptr(), tA.data_ptr(), tB.data_ptr())
         if world > 1:
-            ctx.sync()  # the engine launches on its own stream; the collective runs on torch's
-            dist.gather(tC, gather_list, dst=0)
+            ctx.sync()                 # the engine launches on its own stream; the collective runs on torch's
+            src = tCs[b].cpu() if on_host else tCs[b]
+            pending[b] = dist.gather(src, gather_lists[b], dst=0, async_op=True)   # the ONE collective of the path
 
     def barrier():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

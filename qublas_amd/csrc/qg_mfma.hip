@@ -134,6 +134,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
         }
     };
     auto mfmas = [&](int set) {
+        if (ABL == 6) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int la = 0; la < LA; ++la)
 #pragma unroll
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 #pragma unroll
                     for (int j = 0; j < TJ; ++j)
                         acc[la + lb][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[set][la][i], fb[set][lb][j], acc[la + lb][i][j], 0, 0, 0);
+        if (ABL == 6) __builtin_amdgcn_s_setprio(0);
     };
 
     // prologue: tiles 0 and 1 in flight, tile 0 published, its first fragments loaded
@@ -285,6 +287,7 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
             case 2: return launch<3, 3, 64, 2, 4, 2, 1, 3, 2>(a, st);
             case 3: return launch<3, 3, 64, 2, 4, 2, 1, 3, 3>(a, st);
             case 4: return launch<3, 3, 64, 2, 4, 2, 1, 3, 4>(a, st);
+            case 6: return launch<3, 3, 64, 2, 4, 2, 1, 3, 6>(a, st);
             default: return launch<3, 3, 64, 2, 4, 2, 1, 3, 5>(a, st);
             }
         }
@@ -294,6 +297,7 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
             case 2: return launch<1, 1, 64, 2, 4, 4, 2, 3, 2>(a, st);
             case 3: return launch<1, 1, 64, 2, 4, 4, 2, 3, 3>(a, st);
             case 4: return launch<1, 1, 64, 2, 4, 4, 2, 3, 4>(a, st);
+            case 6: return launch<1, 1, 64, 2, 4, 4, 2, 3, 6>(a, st);
             default: return launch<1, 1, 64, 2, 4, 4, 2, 3, 5>(a, st);
             }
         }
