@@ -133,8 +133,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
             for (int l = 0; l < LB; ++l) fb[set][l][j] = *(const v4i*)(sB + (l * TN + rb) * BK + ((c ^ swz<BK>(rb)) * 16));
         }
     };
-    auto mfmas = [&](int set) {
-        if (ABL == 6) __builtin_amdgcn_s_setprio(1);
+    // the LA*LB*TI*TJ MFMAs of one k-step, optionally only those with index in [first, last)
+    auto mfmas = [&](int set, int first, int last) {
+        int n = 0;
 #pragma unroll
         for (int la = 0; la < LA; ++la)
 #pragma unroll
@@ -142,10 +143,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
-                    for (int j = 0; j < TJ; ++j)
-                        acc[la + lb][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[set][la][i], fb[set][lb][j], acc[la + lb][i][j], 0, 0, 0);
-        if (ABL == 6) __builtin_amdgcn_s_setprio(0);
+                    for (int j = 0; j < TJ; ++j, ++n)
+                        if (n >= first && n < last)
+                            acc[la + lb][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[set][la][i], fb[set][lb][j], acc[la + lb][i][j], 0, 0, 0);
     };
+    constexpr int NM = LA * LB * TI * TJ;  // MFMAs per k-step per wave
 
     // prologue: tiles 0 and 1 in flight, tile 0 published, its first fragments loaded
     issue(0, 0);
@@ -171,10 +173,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                 }
+                // (staggering the DMA issue between the two waves of a SIMD was measured: no gain for
+                // the limb kernel, 2-4 % slower for the single-limb one — all waves issue here)
                 if (kt + 2 < nk && ABL != 1 && ABL != 3 && ABL != 4) issue(rf, kt + 2);
                 if (kt + 1 < nk && ABL != 2 && ABL != 3 && ABL != 4) load_frags(0, smem + nx * STAGE, 0);
             }
-            mfmas(ks & 1);
+            mfmas(ks & 1, 0, NM);
         }
         cur = nx;
     }
@@ -287,7 +291,6 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
             case 2: return launch<3, 3, 64, 2, 4, 2, 1, 3, 2>(a, st);
             case 3: return launch<3, 3, 64, 2, 4, 2, 1, 3, 3>(a, st);
             case 4: return launch<3, 3, 64, 2, 4, 2, 1, 3, 4>(a, st);
-            case 6: return launch<3, 3, 64, 2, 4, 2, 1, 3, 6>(a, st);
             default: return launch<3, 3, 64, 2, 4, 2, 1, 3, 5>(a, st);
             }
         }
@@ -297,7 +300,6 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
             case 2: return launch<1, 1, 64, 2, 4, 4, 2, 3, 2>(a, st);
             case 3: return launch<1, 1, 64, 2, 4, 4, 2, 3, 3>(a, st);
             case 4: return launch<1, 1, 64, 2, 4, 4, 2, 3, 4>(a, st);
-            case 6: return launch<1, 1, 64, 2, 4, 4, 2, 3, 6>(a, st);
             default: return launch<1, 1, 64, 2, 4, 4, 2, 3, 5>(a, st);
             }
         }
