@@ -86,8 +86,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 
     auto issue = [&](int stage, int kt) {
         char* sbase = smem + stage * STAGE;
-        const int8_t* a = Ag + (int64_t)kt * A_BYTES;
-        const int8_t* b = Bg + (int64_t)kt * B_BYTES;
+        const int kts = ABL == 6 ? 0 : kt;  // diagnostic: re-read k-tile 0 (cache hits) to separate DMA cost from traffic cost
+        const int8_t* a = Ag + (int64_t)kts * A_BYTES;
+        const int8_t* b = Bg + (int64_t)kts * B_BYTES;
 #pragma unroll
         for (int pi = 0; pi < PPW; ++pi) {
             const int p = wave + NWAVES * pi;       // wave-uniform piece id
@@ -291,6 +292,7 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
             case 2: return launch<3, 3, 64, 2, 4, 2, 1, 3, 2>(a, st);
             case 3: return launch<3, 3, 64, 2, 4, 2, 1, 3, 3>(a, st);
             case 4: return launch<3, 3, 64, 2, 4, 2, 1, 3, 4>(a, st);
+            case 6: return launch<3, 3, 64, 2, 4, 2, 1, 3, 6>(a, st);
             default: return launch<3, 3, 64, 2, 4, 2, 1, 3, 5>(a, st);
             }
         }
@@ -300,6 +302,7 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
             case 2: return launch<1, 1, 64, 2, 4, 4, 2, 3, 2>(a, st);
             case 3: return launch<1, 1, 64, 2, 4, 4, 2, 3, 3>(a, st);
             case 4: return launch<1, 1, 64, 2, 4, 4, 2, 3, 4>(a, st);
+            case 6: return launch<1, 1, 64, 2, 4, 4, 2, 3, 6>(a, st);
             default: return launch<1, 1, 64, 2, 4, 4, 2, 3, 5>(a, st);
             }
         }
