@@ -120,7 +120,8 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
         pc->tm = cfg.TM;
         pc->tn = cfg.TN;
     } else {
-        kernel = d->is_complex ? QG_KERNEL_TREE_CPLX : ((an->tree_fast_ok && !(flags & QG_OPT_GENERIC_TREE)) ? QG_KERNEL_TREE_I32 : QG_KERNEL_TREE_I64);
+        const bool fast = !(flags & QG_OPT_GENERIC_TREE);
+        kernel = d->is_complex ? ((an->cplx_fast_ok && fast) ? QG_KERNEL_TREE_CPLX_I32 : QG_KERNEL_TREE_CPLX) : ((an->tree_fast_ok && !(flags & QG_OPT_GENERIC_TREE)) ? QG_KERNEL_TREE_I32 : QG_KERNEL_TREE_I64);
         *pa = QPackedGeom{d->M, d->K, info->in_bits[0] <= 32 ? 4 : 8, 0, 0, 0};
         *pb = QPackedGeom{d->N, d->K, info->in_bits[1] <= 32 ? 4 : 8, 0, 0, 0};
         pc->Mp = d->M;
@@ -370,6 +371,10 @@ int qgemul_execute(qgemul_plan* p, void* packedC, const void* packedA, const voi
     case QG_KERNEL_TREE_I32:
         QG_HIP(qg_launch_tree_fast(p->dev_table, (int)p->desc.n_levels, p->an.split_s, p->an.mul24_ok, packedA, packedB, packedC,
                                    p->desc.M, p->desc.N, p->desc.K, p->pc.cbytes, st));
+        return QG_OK;
+    case QG_KERNEL_TREE_CPLX_I32:
+        QG_HIP(qg_launch_tree_cplx_fast(p->dev_table, (int)p->desc.n_levels, packedA, packedB, packedC, p->desc.M, p->desc.N,
+                                        p->desc.K, p->pc.cbytes, st));
         return QG_OK;
     case QG_KERNEL_TREE_I64:
     case QG_KERNEL_TREE_CPLX:

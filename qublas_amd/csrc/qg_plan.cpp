@@ -344,6 +344,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
             out->mul24_ok = bitsA <= 24 && bh <= 24;
         }
     }
+    out->cplx_fast_ok = (cx && d->K >= 32 && (d->K & (d->K - 1)) == 0 && d->n_levels <= 16 && c.max_bits <= 31) ? 1 : 0;
     if (!out->linear_ok)
         snprintf(out->reason, sizeof out->reason, "%s",
                  cx ? "complex operands: exact tree evaluation" : "a product or tree node may round or overflow: exact tree evaluation");

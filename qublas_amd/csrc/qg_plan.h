@@ -32,6 +32,7 @@ struct QAnalysis {
     int tree_fast_ok;        // the 32-bit tree kernel applies
     int split_s;             // > 0: product evaluated split at its rounding shift
     int mul24_ok;            // multiplies fit v_mul_i32_i24
+    int cplx_fast_ok;        // the 32-bit complex tree kernel applies
     char reason[96];
     QTreeTable tree;
     QLinearEpilogue lin;

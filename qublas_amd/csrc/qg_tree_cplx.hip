@@ -1,0 +1,240 @@
+// qg_tree_cplx.hip — exact tree-order evaluation for COMPLEX operands, 32-bit VALU path
+// (BASELINE.json configuration 5: Qcomplex<int<6,3>,int<6,-3>>, TFComplexMul, RND + SAT).
+//
+// Each complex product runs the reference's chain of individually quantised real operations —
+// TFComplexMul: A=(a+b)c, B=(c+d)b, C=(b-a)d, re=A-B, im=B-C (/root/reference/include/QuBLAS.h:3524-3529, with B
+// quantised by badT, C by cdbT and (b-a) in the default-merged format, exactly as the header does);
+// BasicComplexMul: re=ac-bd, im=ad+bc (QuBLAS.h:3439-3440) — and the pairwise tree reduces the real
+// and imaginary parts separately with their own per-level formats (complex Qadd is part-wise,
+// QuBLAS.h:3549-3564; the level buffer converts on store, :4966).  The lowering has already resolved
+// every sub-operation's format into the plan's QTreeTable; this kernel only applies them.
+//
+// Mapping: as qg_tree_fast.hip — each lane owns a 2x2 block of complex outputs, the tree is a
+// register-resident binary counter (levels 0-3 unrolled over 16 leaves, upper levels statically
+// indexed), per-node modes are wave-uniform runtime values.  The operand-only sums (a+b), (b-a)
+// depend on the A element alone and (c+d) on the B element alone, so they are formed once per
+// staged element pair, not once per output.
+#include <hip/hip_runtime.h>
+
+#include "qg_kernels.h"
+#include "qg_step_all.h"
+
+namespace {
+
+constexpr int KC = 32;
+constexpr int TMB = 32, TNB = 32;  // 16x16 threads x (2x2)
+constexpr int PITCH = KC + 4;
+
+template <int N>
+__device__ __forceinline__ void addsub_n(int (&out)[N], const int (&x)[N], const int (&y)[N], const QNode& n, bool sub)
+{
+#pragma unroll
+    for (int o = 0; o < N; ++o) {
+        const int xs = (int)((unsigned)x[o] << n.sa), ys = (int)((unsigned)y[o] << n.sb);
+        out[o] = sub ? xs - ys : xs + ys;
+    }
+    qg_step_all<int, N>(out, n.q);
+}
+
+template <int N>
+__device__ __forceinline__ void mul_n(int (&out)[N], const int (&x)[N], const int (&y)[N], const QNode& n)
+{
+#pragma unroll
+    for (int o = 0; o < N; ++o) out[o] = x[o] * y[o];
+    qg_step_all<int, N>(out, n.q);
+}
+
+// tree node of level l for one part: children share a format, so no alignment shift
+template <int N>
+__device__ __forceinline__ void node_n(int (&v)[N], const int (&x)[N], const QTreeTable* __restrict__ t, int part, int l)
+{
+#pragma unroll
+    for (int o = 0; o < N; ++o) v[o] = x[o] + v[o];
+    qg_step_all<int, N>(v, t->level_add[part][l].q);
+    qg_step_all<int, N>(v, t->level_cvt[part][l]);
+}
+
+struct QTreeCplxArgs {
+    const QTreeTable* tab;
+    const int32_t* A;  // [2][M][K]
+    const int32_t* B;  // [2][N][K]
+    char* C;           // [2][M][N] containers
+    int64_t M, N, K;
+    int32_t cbytes;
+};
+
+template <int MAXL>
+__global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
+{
+    __shared__ __attribute__((aligned(16))) int sA[2][TMB][PITCH];
+    __shared__ __attribute__((aligned(16))) int sB[2][TNB][PITCH];
+    const QTreeTable* __restrict__ tab = g.tab;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int64_t tiles_n = (g.N + TNB - 1) / TNB;
+    const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * TMB, n0 = (int64_t)(blockIdx.x % tiles_n) * TNB;
+    const int nl = tab->n_levels;
+    const bool tf = tab->cmul == QG_CMUL_TF;
+
+    int low[2][4][4];
+    int up[2][MAXL - 4][4];
+    int v[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) v[p][o] = 0;
+
+    for (int64_t k0 = 0; k0 < g.K; k0 += KC) {
+        __syncthreads();
+        // stage: A and B, 2 parts x 32 rows x 32 k = 512 16-byte chunks each, 2 per thread
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ch = tid + 256 * c, p = ch >> 8, r = (ch >> 3) & 31, q = ch & 7;
+            int4 x = make_int4(0, 0, 0, 0), y = make_int4(0, 0, 0, 0);
+            if (m0 + r < g.M) x = *(const int4*)(g.A + ((int64_t)p * g.M + m0 + r) * g.K + k0 + q * 4);
+            if (n0 + r < g.N) y = *(const int4*)(g.B + ((int64_t)p * g.N + n0 + r) * g.K + k0 + q * 4);
+            *(int4*)&sA[p][r][q * 4] = x;
+            *(int4*)&sB[p][r][q * 4] = y;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int kb = 0; kb < KC / 16; ++kb) {
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                int4 a4[2][2], b4[2][2];  // [part][row/col of the 2x2 block]
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        a4[p][i] = *(const int4*)&sA[p][ty * 2 + i][kb * 16 + kq * 4];
+                        b4[p][i] = *(const int4*)&sB[p][tx * 2 + i][kb * 16 + kq * 4];
+                    }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kk = kq * 4 + e;
+                    int ar[2], ai[2], br[2], bi[2];  // a = ar + i*ai (rows), b = br + i*bi (cols)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        ar[i] = e == 0 ? a4[0][i].x : e == 1 ? a4[0][i].y : e == 2 ? a4[0][i].z : a4[0][i].w;
+                        ai[i] = e == 0 ? a4[1][i].x : e == 1 ? a4[1][i].y : e == 2 ? a4[1][i].z : a4[1][i].w;
+                        br[i] = e == 0 ? b4[0][i].x : e == 1 ? b4[0][i].y : e == 2 ? b4[0][i].z : b4[0][i].w;
+                        bi[i] = e == 0 ? b4[1][i].x : e == 1 ? b4[1][i].y : e == 2 ? b4[1][i].z : b4[1][i].w;
+                    }
+                    // ---- one complex product per output (x = a+bi from A, y = c+di from B)
+                    int xr[4], xi[4], yr[4], yi[4];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            xr[i * 2 + j] = ar[i]; xi[i * 2 + j] = ai[i];
+                            yr[i * 2 + j] = br[j]; yi[i * 2 + j] = bi[j];
+                        }
+                    if (tf) {
+                        int ab2[2], ba2[2], cd2[2];
+                        addsub_n<2>(ab2, ar, ai, tab->mul[QG_T_AB], false);  // (a+b), per A element
+                        addsub_n<2>(ba2, ai, ar, tab->mul[QG_T_BA], true);   // (b-a), per A element
+                        addsub_n<2>(cd2, br, bi, tab->mul[QG_T_CD], false);  // (c+d), per B element
+                        int ab[4], ba[4], cd[4], PA[4], PB[4], PC[4];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) { ab[i * 2 + j] = ab2[i]; ba[i * 2 + j] = ba2[i]; cd[i * 2 + j] = cd2[j]; }
+                        mul_n<4>(PA, ab, yr, tab->mul[QG_T_A]);
+                        mul_n<4>(PB, cd, xi, tab->mul[QG_T_B]);
+                        mul_n<4>(PC, ba, yi, tab->mul[QG_T_C]);
+                        addsub_n<4>(v[0], PA, PB, tab->mul[QG_T_RE], true);
+                        addsub_n<4>(v[1], PB, PC, tab->mul[QG_T_IM], true);
+                    } else {
+                        int ac[4], bd[4], ad[4], bc[4];
+                        mul_n<4>(ac, xr, yr, tab->mul[QG_B_AC]);
+                        mul_n<4>(bd, xi, yi, tab->mul[QG_B_BD]);
+                        mul_n<4>(ad, xr, yi, tab->mul[QG_B_AD]);
+                        mul_n<4>(bc, xi, yr, tab->mul[QG_B_BC]);
+                        addsub_n<4>(v[0], ac, bd, tab->mul[QG_B_RE], true);
+                        addsub_n<4>(v[1], ad, bc, tab->mul[QG_B_IM], false);
+                    }
+                    // ---- lower four levels (compile-time leaf index)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        if ((kk & 1) == 0) {
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) low[p][0][o] = v[p][o];
+                        } else {
+                            node_n<4>(v[p], low[p][0], tab, p, 0);
+                            if ((kk & 2) == 0) {
+#pragma unroll
+                                for (int o = 0; o < 4; ++o) low[p][1][o] = v[p][o];
+                            } else {
+                                node_n<4>(v[p], low[p][1], tab, p, 1);
+                                if ((kk & 4) == 0) {
+#pragma unroll
+                                    for (int o = 0; o < 4; ++o) low[p][2][o] = v[p][o];
+                                } else {
+                                    node_n<4>(v[p], low[p][2], tab, p, 2);
+                                    if ((kk & 8) == 0) {
+#pragma unroll
+                                        for (int o = 0; o < 4; ++o) low[p][3][o] = v[p][o];
+                                    } else {
+                                        node_n<4>(v[p], low[p][3], tab, p, 3);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            const unsigned idx = (unsigned)((k0 >> 4) + kb);
+            bool parked = false;
+#pragma unroll
+            for (int u = 0; u < MAXL - 4; ++u) {
+                if (!parked && 4 + u < nl) {
+                    if (((idx >> u) & 1u) == 0) {
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) up[p][u][o] = v[p][o];
+                        parked = true;
+                    } else {
+                        node_n<4>(v[0], up[0][u], tab, 0, 4 + u);
+                        node_n<4>(v[1], up[1][u], tab, 1, 4 + u);
+                    }
+                }
+            }
+        }
+    }
+    qg_step_all<int, 4>(v[0], tab->c_cvt[0]);
+    qg_step_all<int, 4>(v[1], tab->c_cvt[1]);
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int64_t m = m0 + ty * 2 + i, n = n0 + tx * 2 + j;
+                if (m < g.M && n < g.N) {
+                    const int64_t idx = ((int64_t)p * g.M + m) * g.N + n;
+                    const int r = v[p][i * 2 + j];
+                    switch (g.cbytes) {
+                    case 1: ((int8_t*)g.C)[idx] = (int8_t)r; break;
+                    case 2: ((int16_t*)g.C)[idx] = (int16_t)r; break;
+                    case 4: ((int32_t*)g.C)[idx] = r; break;
+                    default: ((int64_t*)g.C)[idx] = (int64_t)r; break;
+                    }
+                }
+            }
+}
+
+} // namespace
+
+hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, const void* A, const void* B, void* C, int64_t M,
+                                    int64_t N, int64_t K, int cbytes, hipStream_t st)
+{
+    if (K % KC != 0 || n_levels < 5 || n_levels > 16) return hipErrorInvalidValue;
+    QTreeCplxArgs g{dev_table, (const int32_t*)A, (const int32_t*)B, (char*)C, M, N, K, cbytes};
+    const int64_t blocks = ((M + TMB - 1) / TMB) * ((N + TNB - 1) / TNB);
+    if (blocks <= 0) return hipSuccess;
+    if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
+    if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((k_tree_cplx<16>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    return hipGetLastError();
+}

@@ -117,7 +117,7 @@ def test_config5_2048_complex_tf(oracle):
     wide = Qcomplex(Qu(18, 6, True, RND.POS_INF), Qu(18, 6, True, RND.POS_INF))
     d = lower(c5, c5, wide, 256, 2048, 2048, mul_args=TFComplexMul())
     got, kernel = run_resident(d, dist=1)
-    assert kernel == "tree_cplx"
+    assert kernel == "tree_cplx_i32"
     check_block(oracle, d, c5, c5, wide, got, rows=(100, 116), cols=(0, 2048), dist=1)
 
 

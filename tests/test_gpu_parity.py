@@ -171,9 +171,32 @@ def test_config5_complex_tf(oracle):
     i = Qu(6, -3, True, RND.POS_INF, SAT.TCPL)
     c5 = Qcomplex(r, i)
     wide = Qcomplex(Qu(18, 6, True, RND.POS_INF), Qu(18, 6, True, RND.POS_INF))
-    _vs_oracle(oracle, c5, c5, c5, 64, 48, 2048, mul_args=TFComplexMul(), expect_kernel="tree_cplx")
-    _vs_oracle(oracle, c5, c5, wide, 64, 48, 2048, dist=1, mul_args=TFComplexMul())
-    _vs_oracle(oracle, c5, c5, wide, 40, 24, 100, dist=1, mul_args=BasicComplexMul(), transposed_a=True)
+    _vs_oracle(oracle, c5, c5, c5, 64, 48, 2048, mul_args=TFComplexMul(), expect_kernel="tree_cplx_i32")
+    a = _vs_oracle(oracle, c5, c5, wide, 64, 48, 2048, dist=1, mul_args=TFComplexMul(), expect_kernel="tree_cplx_i32")
+    b = _vs_oracle(oracle, c5, c5, wide, 64, 48, 2048, dist=1, mul_args=TFComplexMul(), flags=capi.OPT_GENERIC_TREE,
+                   expect_kernel="tree_cplx")
+    assert fields_equal(a, b)
+    _vs_oracle(oracle, c5, c5, wide, 40, 24, 100, dist=1, mul_args=BasicComplexMul(), transposed_a=True, expect_kernel="tree_cplx")
+    _vs_oracle(oracle, c5, c5, wide, 70, 33, 256, dist=0, mul_args=BasicComplexMul(), transposed_a=True, expect_kernel="tree_cplx_i32")
+
+
+def test_complex_fast_kernel_tags_and_levels(oracle):
+    """Complex 32-bit kernel with per-sub-op tags (incl. the crossed cdbT/badT use) and complex level types."""
+    r55 = Qu(5, 5)
+    c55 = Qcomplex(r55, r55)
+    wide = Qcomplex(Qu(18, 6, True, RND.POS_INF), Qu(18, 6, True, RND.POS_INF))
+    tA = Qu(9, 4, True, RND.CONV, SAT.SMGN)
+    tB = Qu(7, 2, True, TRN.SMGN, SAT.ZERO)
+    tC = Qu(10, 5, True, RND.ZERO, WRP.TCPL)
+    tD = Qu(8, 3, True, RND.INF, SAT.TCPL)
+    tf = TFComplexMul(abT=tA, cdT=tD, abcT=tC, cdbT=tB, badT=tA, ABT=tD, BCT=tC)
+    l1 = Qcomplex(Qu(12, 4, True, RND.CONV, SAT.SMGN), Qu(11, 6, True, TRN.SMGN, SAT.ZERO))
+    l2 = Qcomplex(Qu(16, 2, True, RND.ZERO), Qu(16, 3, True, RND.INF, WRP.TCPL))
+    for kw in (dict(mul_args=tf), dict(mul_args=tf, add_args=[l1, l2]), dict(mul_args=TFComplexMul(), add_args=[l1]),
+               dict(mul_args=BasicComplexMul(acT=tA, bdT=tB, adT=tC, bcT=tD, acbdT=tC, adbcT=tA), add_args=[l2, l1])):
+        a = _vs_oracle(oracle, c55, c55, wide, 37, 70, 64, expect_kernel="tree_cplx_i32", **kw)
+        b = _vs_oracle(oracle, c55, c55, wide, 37, 70, 64, flags=capi.OPT_GENERIC_TREE, expect_kernel="tree_cplx", **kw)
+        assert fields_equal(a, b)
 
 
 def test_leading_dimensions(oracle):
