@@ -26,6 +26,7 @@ struct Ctx {
     bool exact = true;      // every step so far was the identity
     int max_bits = 1;
     int max_bits_np = 1;    // the same, not counting full-precision products before their rounding
+    int max_fmt_bits = 1;   // widest storage (1 + W) of any format on the path
     bool raw_product = false;
     void fail(int st, const char* why)
     {
@@ -65,8 +66,11 @@ Rng fmt_range(qfmt f)
     return r;
 }
 
+thread_local int g_fmt_bits_seen = 0; // widest target format make_step has seen since qg_analyze reset it
+
 QStep make_step(int fromF, qfmt to, bool identity)
 {
+    if (1 + (int)to.I + (int)to.F > g_fmt_bits_seen) g_fmt_bits_seen = 1 + (int)to.I + (int)to.F;
     QStep s;
     memset(&s, 0, sizeof s);
     s.d = fromF - (int)to.F;
@@ -223,6 +227,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
 {
     memset(out, 0, sizeof *out);
     out->status = QG_OK;
+    g_fmt_bits_seen = 0;
     Ctx c;
     c.out = out;
     if (!d || d->abi != QGEMUL_ABI_VERSION) { c.fail(QG_EINVAL, "null descriptor or ABI mismatch"); return; }
@@ -322,6 +327,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
 
     out->max_bits = c.max_bits;
     out->max_bits_np = c.max_bits_np;
+    c.max_fmt_bits = g_fmt_bits_seen; // the int32 kernels keep every format's bounds in 32-bit registers
     if (c.max_bits > 62) { c.fail(QG_EUNSUPPORTED, "an intermediate needs more than 62 bits"); return; }
     out->linear_ok = (c.exact && !cx) ? 1 : 0;
     out->cls = out->linear_ok ? QG_CLASS_LINEAR : QG_CLASS_TREE;
@@ -329,7 +335,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     // unrounded product fits 31 bits, and the product is either directly 32-bit or splittable at
     // its rounding shift
     out->tree_fast_ok = 0;
-    if (!cx && d->K >= 32 && (d->K & (d->K - 1)) == 0 && d->n_levels <= 16 && c.max_bits_np <= 31) {
+    if (!cx && d->K >= 32 && (d->K & (d->K - 1)) == 0 && d->n_levels <= 16 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) {
         const int bitsA = 1 + (int)d->a[0].I + (int)d->a[0].F, bitsB = 1 + (int)d->b[0].I + (int)d->b[0].F;
         const int sh = T.mul[0].q.d;
         int bh = bitsB - sh;
@@ -344,7 +350,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
             out->mul24_ok = bitsA <= 24 && bh <= 24;
         }
     }
-    out->cplx_fast_ok = (cx && d->K >= 32 && (d->K & (d->K - 1)) == 0 && d->n_levels <= 16 && c.max_bits <= 31) ? 1 : 0;
+    out->cplx_fast_ok = (cx && d->K >= 32 && (d->K & (d->K - 1)) == 0 && d->n_levels <= 16 && c.max_bits <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     if (!out->linear_ok)
         snprintf(out->reason, sizeof out->reason, "%s",
                  cx ? "complex operands: exact tree evaluation" : "a product or tree node may round or overflow: exact tree evaluation");

@@ -96,3 +96,19 @@ def test_no_cpu_fallback():
         capi.run(d, out, A, A)
     assert ei.value.status == capi.QG_ENOGPU
     assert (out == 77).all()
+
+
+def test_int32_kernels_need_32bit_formats():
+    """Values may be small while a declared format is wide: the 32-bit tree kernels keep every format's
+    bounds in 32-bit registers, so the planner must fall back to the 64-bit kernels (found on the GPU:
+    golden case c5_tf_L_tn_4x4x64_full has 37-bit level formats)."""
+    by = {j["name"]: j for j in G.gemm_cases("cplx")}
+    i = capi.classify(desc_from_dict(by["c5_tf_L_tn_4x4x64_full"]))
+    assert capi.KERNEL_NAMES[i.kernel] == "tree_cplx"
+    i = capi.classify(desc_from_dict(by["c5_tf_default_8x8x64_full"]))
+    assert capi.KERNEL_NAMES[i.kernel] == "tree_cplx_i32"
+    e = Qu(4, 3)
+    d = lower(e, e, Qu(16, 3), 64, 64, 64, add_args=[Qu(40, 3)])     # wide level type, tree class (product rounds)
+    assert capi.KERNEL_NAMES[capi.classify(d).kernel] == "tree_i64"
+    d = lower(e, e, Qu(16, 3), 64, 64, 64, add_args=[Qu(20, 3)])
+    assert capi.KERNEL_NAMES[capi.classify(d).kernel] == "tree_i32"
