@@ -20,7 +20,7 @@ timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "ben
 cat $OUT/bench.json
 for WL in $WLS; do
   echo "== rocprofv3 kernel-trace $WL" | tee -a $OUT/progress.log
-  (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_${WL}_trace --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 20 --warmup 2 --no-extra --no-cpu > $OUT/prof_${WL}_trace.log 2>&1); echo "trace rc=$?" | tee -a $OUT/progress.log
+  (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_${WL}_trace --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --workload $WL --steps $( [ $WL = c3T ] && echo 10 || echo 200 ) --warmup 5 --no-extra --no-cpu > $OUT/prof_${WL}_trace.log 2>&1); echo "trace rc=$?" | tee -a $OUT/progress.log
   for PMC in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT" "GRBM_GUI_ACTIVE"; do
     N=$(echo $PMC | tr ' ' '_' | cut -c1-24)
     echo "== rocprofv3 pmc $WL $N" | tee -a $OUT/progress.log

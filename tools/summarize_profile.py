@@ -47,7 +47,7 @@ def main():
         name = top["Name"]
         out = {"workload": wl, "kernel": name, "calls": int(top["Calls"]), "mean_us": float(top["AverageNs"]) / 1e3,
                "min_us": float(top["MinNs"]) / 1e3, "max_us": float(top["MaxNs"]) / 1e3,
-               "command": f"rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --steps 20 --warmup 2 --no-extra --no-cpu"}
+               "command": f"rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --steps {10 if wl == 'c3T' else 200} --warmup 5 --no-extra --no-cpu"}
         if trace:
             d = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(trace))
                  if r["Kernel_Name"] == name]
