@@ -440,4 +440,42 @@ void Qgemul(TC& C, const TA& A, const TB& B)
     if (st != QG_OK) throw std::runtime_error(std::string("Qgemul: ") + qgemul_strerror(st));
 }
 
+// ------------------------------------------------------------------ Qreduce (SURVEY.md §8-f "next" #1)
+// The reference's tree reduction of a tensor, Qreduce<L…>(v) (QuBLAS.h:4960-4990, :5014-5018), on the
+// same engine path: C[1 x 1] = A[1 x len] * ones[len x 1] with the product format equal to the element
+// format (Qmul(a, 1) into a's own format is the identity) and the level list L.  The result type is
+// the reducer's: the last level type used, or the element type when there are no levels / one element.
+namespace detail {
+template <class Elem, size_t Len, class List> struct reduce_result { using type = Elem; };
+template <class Elem, size_t Len, class L0, class... Ls>
+struct reduce_result<Elem, Len, TypeList<L0, Ls...>> {
+    static constexpr size_t nl = [] { size_t n = 0; for (size_t k = Len; k > 1; k = (k + 1) / 2) ++n; return n; }();
+    static constexpr size_t n = 1 + sizeof...(Ls);
+    static constexpr Fmt f = levels_of<TypeList<L0, Ls...>>::value[nl == 0 ? 0 : (nl < n ? nl : n) - 1][0];
+    using type = std::conditional_t<(Len <= 1), Elem, scalar_of<f>>;
+};
+template <class... Ls> struct as_list { using type = TypeList<Ls...>; };
+template <class... Ls> struct as_list<TypeList<Ls...>> { using type = TypeList<Ls...>; };
+} // namespace detail
+
+template <typename... Levels, size_t... D, class Elem>
+    requires(!Elem::is_complex)
+auto Qreduce(const Qu_s<dim<D...>, Elem>& v)
+{
+    using namespace detail;
+    constexpr size_t len = dim<D...>::elems;
+    using list = typename as_list<Levels...>::type;
+    using res_t = typename reduce_result<Elem, len, list>::type;
+    using one_t = Qu<intBits<1>, fracBits<0>, isSigned<false>>;
+    Qu_s<dim<len, 1>, Elem> a;       // dim<K, M> with TransposedA: the vector is row 0 of A'
+    a.data = v.data;
+    Qu_s<dim<len, 1>, one_t> ones;
+    for (auto& o : ones.data) o.data = 1;
+    Qu_s<dim<1, 1>, res_t> c;
+    [&]<class... Ls>(TypeList<Ls...>) {
+        Qgemul<QgemulAddArgs<Ls...>, QgemulMulArgs<Elem>, QgemulTransposedA<true>>(c, a, ones);
+    }(list{});
+    return c.data[0];
+}
+
 } // namespace QuBLAS_amd

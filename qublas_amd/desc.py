@@ -362,3 +362,27 @@ def host_layout(e: Elem) -> Tuple[int, int, Tuple[int, int]]:
     al = max(sr, si)
     size = (off + si + al - 1) // al * al
     return size, off, (sr, si)
+
+
+# ---------------------------------------------------------------------------------------------
+# Qreduce (SURVEY.md §8-f "next" #1): the reference's tree reduction of a vector,
+# Qreduce<L...>(v) (/root/reference/include/QuBLAS.h:4960-4990, :5014-5018), expressed on the SAME engine path:
+# a batch of `rows` vectors of length `length` is the Qgemul  C[rows x 1] = A[rows x length] * ones[length x 1]
+# whose product format is the element's own format (Qmul(a, 1) into a's format is the identity: no
+# rounding shift, value in range) and whose level list is L.  The result type is the reducer's
+# result type: the last level type, or the element type without levels (len 1: the element itself).
+ONE = Qu(1, 0, False)   # the constant 1 as an unsigned 1-bit integer
+
+
+def reduce_result_type(e: Qu, levels, length: int) -> Qu:
+    if length <= 1 or not levels:
+        return e
+    return levels[min(n_levels_for(length), len(levels)) - 1]
+
+
+def lower_reduce(e: Qu, rows: int, length: int, levels=None) -> qgemul_desc:
+    if isinstance(e, Qcomplex):
+        raise ValueError("complex Qreduce is not lowered yet")
+    levels = list(levels) if levels else []
+    return lower(e, ONE, reduce_result_type(e, levels, length), rows, 1, length, add_args=levels, mul_args=e,
+                 transposed_a=True)

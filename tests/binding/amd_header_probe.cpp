@@ -76,6 +76,20 @@ int main()
         using TFall = TFComplexMul<abT<t146>, cdT<t146>, baT<t146>, abcT<t146>, cdbT<t146>, badT<t146>, ABT<t146>, BCT<t146>>;
         probe<c146, c146, c146, 1, 1, 1, false, QgemulMulArgs<TFall>>("tf_quirk_baT_1x1x1");
     }
+    {   // Qreduce lowers onto the Qgemul path: result type follows the reducer's rule (compile-time only here)
+        using type1 = Qu<isSigned<true>, intBits<6>, fracBits<3>, OfMode<SAT::ZERO>>;
+        using type2 = Qu<intBits<6>, fracBits<-3>>;
+        using R1 = detail::reduce_result<e43, 4, TypeList<type2>>::type;
+        static_assert(std::is_same_v<R1, type2>);
+        using R2 = detail::reduce_result<e43, 16, TypeList<type1, type2>>::type;
+        static_assert(std::is_same_v<R2, type2>);
+        using R3 = detail::reduce_result<e43, 2, TypeList<type1, type2>>::type;
+        static_assert(std::is_same_v<R3, type1>);
+        using R4 = detail::reduce_result<e43, 1, TypeList<type1>>::type;
+        static_assert(std::is_same_v<R4, e43>);
+        using R5 = detail::reduce_result<e43, 1000, TypeList<>>::type;
+        static_assert(std::is_same_v<R5, e43>);
+    }
     // value construction honours the type's modes (Qu_s(double), QuBLAS.h:2387-2393): 20 -> 16 in int<6,-3>
     Qu<intBits<6>, fracBits<-3>> q2 = 20;
     if (q2.toDouble() != 16.0) return 1;

@@ -1,0 +1,62 @@
+"""Qreduce on the engine path (SURVEY.md §8-f "next" #1): the reference's vector tree reduction
+(Qreduce<L...>(v), QuBLAS.h:4960-4990) lowered as the Qgemul  C[rows x 1] = A[rows x len] * ones.
+The truth tables come from the real reference header (tests/golden/ref_scalar_4.jsonl.gz: lengths
+1..1000, 0/1/2-entry level lists, result types as the reference reports them)."""
+import numpy as np
+import pytest
+
+import golden_io as G
+from qublas_amd.desc import ONE, Qu, lower_reduce, reduce_result_type
+
+
+def _tables():
+    return [t for t in G.scalar_tables(4) if t["kind"] == "reduce"]
+
+
+def _batch(oracle, t):
+    """All seeds of one table as the rows of one batched reduce: A is len x rows column-major (transposed)."""
+    fin = Qu.from_tuple(t["fin"])
+    levels = [Qu.from_tuple(x) for x in t["levels"]]
+    L = oracle.lib()
+    n, rows = t["len"], len(t["seeds"])
+    A = np.zeros(n * rows, dtype=np.int32)
+    for r, seed in enumerate(t["seeds"]):
+        A[r * n:(r + 1) * n] = [L.qoracle_synth(fin.c(), seed, t["dist"], i, 0) for i in range(n)]
+    ec = reduce_result_type(fin, levels, n)
+    return fin, levels, ec, A, np.ones(n, dtype=np.int32), rows
+
+
+@pytest.mark.parametrize("t", _tables(), ids=lambda t: t["name"])
+def test_reduce_lowering_matches_reference(oracle, t):
+    fin, levels, ec, A, ones, rows = _batch(oracle, t)
+    for (y, fr) in t["y"]:
+        assert list(ec.as_tuple()) == fr            # result type rule
+    d = lower_reduce(fin, rows, t["len"], levels)
+    out = oracle.gemm(d, A, ones, ec)
+    assert [int(v) for v in out] == [y for (y, _) in t["y"]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", _tables(), ids=lambda t: t["name"])
+def test_reduce_on_gpu_matches_reference(oracle, t):
+    from qublas_amd import capi
+    fin, levels, ec, A, ones, rows = _batch(oracle, t)
+    d = lower_reduce(fin, rows, t["len"], levels)
+    out = capi.run(d, np.zeros(rows, dtype=oracle.host_dtype(ec)), A, ones)
+    assert [int(v) for v in out] == [y for (y, _) in t["y"]]
+
+
+@pytest.mark.gpu
+def test_batched_reduce_large(oracle):
+    """65536 vectors of length 1024, two-entry level list, against the CPU restatement."""
+    from qublas_amd import capi
+    e = Qu(4, 3)
+    levels = [Qu(6, 3, True, 4, 2), Qu(12, 3)]
+    rows, n = 4096, 1024
+    d = lower_reduce(e, rows, n, levels)
+    A = oracle.fill(e, rows * n, 7)
+    ones = np.ones(n, np.int32)
+    ec = reduce_result_type(e, levels, n)
+    got = capi.run(d, np.zeros(rows, np.int32), A, ones)
+    exp = oracle.gemm(d, A, ones, ec, nthreads=8)
+    assert np.array_equal(got, exp)
