@@ -166,7 +166,7 @@ def main():
     state = {"i": 0}
 
     def step():
-        b = state["i"] & 1
+        b = (state["i"] & 1) if world > 1 else 0
         state["i"] += 1
         if world > 1 and pending[b] is not None:
             pending[b].wait()          # buffer b was handed to the collective two steps ago
