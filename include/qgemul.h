@@ -130,7 +130,8 @@ typedef struct qgemul_opts {
 enum {
     QG_OPT_FORCE_TREE = 1u,   /* run the exact tree kernel even when the linear class is provable */
     QG_OPT_CHECK_RANGE = 2u,  /* validate that A and B raw values lie inside their formats */
-    QG_OPT_GENERIC_TREE = 4u  /* tree class: use the any-descriptor 64-bit kernel, not the 32-bit fast path */
+    QG_OPT_GENERIC_TREE = 4u, /* tree class: use the any-descriptor 64-bit kernel, not the 32-bit fast path */
+    QG_OPT_RUNTIME_MODES = 8u /* 32-bit tree kernel: use the runtime-mode variant even when a fixed-mode one applies */
 };
 
 /* status codes */

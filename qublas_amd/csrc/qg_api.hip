@@ -369,7 +369,8 @@ int qgemul_execute(qgemul_plan* p, void* packedC, const void* packedA, const voi
         return QG_OK;
     }
     case QG_KERNEL_TREE_I32:
-        QG_HIP(qg_launch_tree_fast(p->dev_table, (int)p->desc.n_levels, p->an.split_s, p->an.mul24_ok, packedA, packedB, packedC,
+        QG_HIP(qg_launch_tree_fast(p->dev_table, (int)p->desc.n_levels, p->an.split_s, p->an.mul24_ok,
+                                   (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : p->an.fast_mode, packedA, packedB, packedC,
                                    p->desc.M, p->desc.N, p->desc.K, p->pc.cbytes, st));
         return QG_OK;
     case QG_KERNEL_TREE_CPLX_I32:

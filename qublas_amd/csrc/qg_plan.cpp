@@ -350,6 +350,16 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
             out->mul24_ok = bitsA <= 24 && bh <= 24;
         }
     }
+    // fixed-mode variants of the 32-bit tree kernel: product and all levels in one format, truncating
+    // product, SAT::ZERO or SAT::TCPL overflow (the shapes default tags produce)
+    out->fast_mode = 0;
+    if (out->tree_fast_ok && out->mul24_ok) {
+        const qfmt pf = d->mul[0];
+        bool one = (pf.Q == QG_TRN_TCPL || T.mul[0].q.d <= 0) && T.mul[0].q.d >= 0 && (pf.O == QG_SAT_ZERO || pf.O == QG_SAT_TCPL);
+        for (uint32_t l = 0; l < d->n_levels && one; ++l) one = same(d->level[0][l], pf) && same(d->level_add[0][l], pf);
+        const int W = (int)pf.I + (int)pf.F;
+        if (one && W + 1 + T.mul[0].q.d <= 30) out->fast_mode = pf.O == QG_SAT_ZERO ? 1 : 2;
+    }
     out->cplx_fast_ok = (cx && d->K >= 32 && (d->K & (d->K - 1)) == 0 && d->n_levels <= 16 && c.max_bits <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     if (!out->linear_ok)
         snprintf(out->reason, sizeof out->reason, "%s",

@@ -110,6 +110,21 @@ __device__ __forceinline__ void step_all(int (&v)[NOUT], const QStep& s)
 }
 
 // node of level l: both children have the level's input format (no alignment shift for real GEMMs)
+template <int MODE>
+__device__ __forceinline__ void node_fixed(int (&v)[NOUT], const int (&x)[NOUT], int flo, int fhi, int bias, unsigned span)
+{
+    if (MODE == 1) {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const int t = x[o] + v[o] - bias;               // biased sum (v_add3_u32)
+            v[o] = ((unsigned)t > span) ? bias : t;          // out of range -> biased zero
+        }
+    } else {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) v[o] = min(max(x[o] + v[o], flo), fhi);
+    }
+}
+
 __device__ __forceinline__ void node_all(int (&v)[NOUT], const int (&x)[NOUT], const QTreeTable* __restrict__ t, int l)
 {
 #pragma unroll
@@ -161,7 +176,18 @@ struct QTreeFastArgs {
     int32_t split_s;    // SPLIT: rounding shift of the product (= bits split off B)
 };
 
-template <bool SPLIT, bool MUL24, int MAXL>
+// MODE 0: per-node formats and modes are runtime values (any real descriptor the planner admits).
+// MODE 1 / 2: the product and every tree level share ONE format, rounding is TRN::TCPL and the overflow mode is
+//   SAT::ZERO (1) or SAT::TCPL (2) — the default-tag shapes (configurations 1 and 3 as literally configured).  Then
+//   a node is 3 (ZERO, on values biased by -lo so that the range test is one unsigned compare) or 2 (TCPL:
+//   v_add + v_med3) VALU instructions and the leaf needs no separate rounding step.
+#define NODE(X, L)                                                         \
+    do {                                                                   \
+        if (MODE != 0) node_fixed<MODE>(v, X, flo, fhi, bias, span);       \
+        else node_all(v, X, tab, L);                                       \
+    } while (0)
+
+template <bool SPLIT, bool MUL24, int MAXL, int MODE>
 __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
 {
     __shared__ __attribute__((aligned(16))) int sA[TMB][PITCH];
@@ -176,6 +202,11 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
     const int s = g.split_s;
     const int smask = SPLIT ? ((1 << s) - 1) : 0;
     const QStep pstep = tab->mul[0].q;
+    // MODE 1/2 constants: the shared format's bounds
+    const int flo = (int)pstep.lo, fhi = (int)pstep.hi;
+    const int bias = MODE == 1 ? -flo : 0;
+    const unsigned span = (unsigned)(fhi - flo);
+    const int pd = pstep.d > 0 ? pstep.d : 0;  // DIRECT: TCPL shift of the product
 
     int low[4][NOUT];
     int up[MAXL - 4][NOUT];
@@ -229,7 +260,24 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
                         if (SPLIT) blv[j] = e == 0 ? bl4[j].x : e == 1 ? bl4[j].y : e == 2 ? bl4[j].z : bl4[j].w;
                     }
                     // ---- leaves: 8 quantised products
-                    if (SPLIT) {
+                    if (MODE != 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                int p;
+                                if (SPLIT) {
+                                    // floor(a*b / 2^s) + bias = a*bh + ((a*bl + bias*2^s) >> s)
+                                    const int t = __mul24(av[i], blv[j]) + (bias << s);
+                                    p = __mul24(av[i], bhv[j]) + (t >> s);
+                                } else {
+                                    p = (__mul24(av[i], bhv[j]) + (bias << pd)) >> pd;
+                                }
+                                if (MODE == 1) p = ((unsigned)p > span) ? bias : p;
+                                else p = min(max(p, flo), fhi);
+                                v[i * 2 + j] = p;
+                            }
+                    } else if (SPLIT) {
                         int lw[NOUT];
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
@@ -240,35 +288,36 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
                                 lw[i * 2 + j] = t & smask;
                             }
                         round_split_all(v, lw, s, pstep.Q);
+                        overflow_all(v, pstep);
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
                             for (int j = 0; j < 2; ++j) v[i * 2 + j] = MUL24 ? __mul24(av[i], bhv[j]) : av[i] * bhv[j];
                         round_all(v, pstep.d, pstep.Q);
+                        overflow_all(v, pstep);
                     }
-                    overflow_all(v, pstep);
                     // ---- lower four levels: binary counter on the compile-time index kk
                     if ((kk & 1) == 0) {
 #pragma unroll
                         for (int o = 0; o < NOUT; ++o) low[0][o] = v[o];
                     } else {
-                        node_all(v, low[0], tab, 0);
+                        NODE(low[0], 0);
                         if ((kk & 2) == 0) {
 #pragma unroll
                             for (int o = 0; o < NOUT; ++o) low[1][o] = v[o];
                         } else {
-                            node_all(v, low[1], tab, 1);
+                            NODE(low[1], 1);
                             if ((kk & 4) == 0) {
 #pragma unroll
                                 for (int o = 0; o < NOUT; ++o) low[2][o] = v[o];
                             } else {
-                                node_all(v, low[2], tab, 2);
+                                NODE(low[2], 2);
                                 if ((kk & 8) == 0) {
 #pragma unroll
                                     for (int o = 0; o < NOUT; ++o) low[3][o] = v[o];
                                 } else {
-                                    node_all(v, low[3], tab, 3);
+                                    NODE(low[3], 3);
                                 }
                             }
                         }
@@ -286,13 +335,17 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
                         for (int o = 0; o < NOUT; ++o) up[u][o] = v[o];
                         parked = true;
                     } else {
-                        node_all(v, up[u], tab, 4 + u);
+                        NODE(up[u], 4 + u);
                     }
                 }
             }
         }
     }
     // after the last block the counter has carried through every level: v holds the root
+    if (MODE == 1) {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) v[o] -= bias;
+    }
     step_all(v, tab->c_cvt[0]);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -314,15 +367,15 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
 
 } // namespace
 
-template <bool SPLIT, bool MUL24>
+template <bool SPLIT, bool MUL24, int MODE>
 static void launch_tf(int n_levels, dim3 grid, hipStream_t st, const QTreeFastArgs& g)
 {
-    if (n_levels <= 12) hipLaunchKernelGGL((k_tree_fast<SPLIT, MUL24, 12>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((k_tree_fast<SPLIT, MUL24, 16>), grid, dim3(256), 0, st, g);
+    if (n_levels <= 12) hipLaunchKernelGGL((k_tree_fast<SPLIT, MUL24, 12, MODE>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((k_tree_fast<SPLIT, MUL24, 16, MODE>), grid, dim3(256), 0, st, g);
 }
 
-hipError_t qg_launch_tree_fast(const QTreeTable* dev_table, int n_levels, int split_s, int mul24, const void* A, const void* B, void* C,
-                               int64_t M, int64_t N, int64_t K, int cbytes, hipStream_t st)
+hipError_t qg_launch_tree_fast(const QTreeTable* dev_table, int n_levels, int split_s, int mul24, int mode, const void* A, const void* B,
+                               void* C, int64_t M, int64_t N, int64_t K, int cbytes, hipStream_t st)
 {
     if (K % KC != 0 || n_levels < 5 || n_levels > 16) return hipErrorInvalidValue;
     QTreeFastArgs g{dev_table, (const int32_t*)A, (const int32_t*)B, (char*)C, M, N, K, cbytes, split_s};
@@ -330,12 +383,17 @@ hipError_t qg_launch_tree_fast(const QTreeTable* dev_table, int n_levels, int sp
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks);
+    if (mode != 0 && !mul24) mode = 0;  // the fixed-mode variants are built for 24-bit multiplies only
     if (split_s > 0) {
-        if (mul24) launch_tf<true, true>(n_levels, grid, st, g);
-        else launch_tf<true, false>(n_levels, grid, st, g);
+        if (mode == 1) launch_tf<true, true, 1>(n_levels, grid, st, g);
+        else if (mode == 2) launch_tf<true, true, 2>(n_levels, grid, st, g);
+        else if (mul24) launch_tf<true, true, 0>(n_levels, grid, st, g);
+        else launch_tf<true, false, 0>(n_levels, grid, st, g);
     } else {
-        if (mul24) launch_tf<false, true>(n_levels, grid, st, g);
-        else launch_tf<false, false>(n_levels, grid, st, g);
+        if (mode == 1) launch_tf<false, true, 1>(n_levels, grid, st, g);
+        else if (mode == 2) launch_tf<false, true, 2>(n_levels, grid, st, g);
+        else if (mul24) launch_tf<false, true, 0>(n_levels, grid, st, g);
+        else launch_tf<false, false, 0>(n_levels, grid, st, g);
     }
     return hipGetLastError();
 }

@@ -250,3 +250,24 @@ def test_resident_api_and_device_fill(oracle):
         for p in (pA, pB, pC, dC):
             ctx.free(p)
         plan.close()
+
+
+@pytest.mark.parametrize("elem,K,dist", [
+    (Qu(8, 8, True, TRN.TCPL, SAT.ZERO), 4096, 1),    # configuration 3 as configured: split product, SAT::ZERO, biased nodes
+    (Qu(8, 8, True, TRN.TCPL, SAT.ZERO), 64, 0),
+    (Qu(8, 8, True, TRN.TCPL, SAT.TCPL), 256, 1),     # split product, clamp nodes
+    (Qu(4, 3), 1024, 1),                               # direct product with a TCPL shift, clamp nodes
+    (Qu(4, 3, True, TRN.TCPL, SAT.ZERO), 128, 1),
+    (Qu(4, 4, False), 64, 1),                          # unsigned: lower bound 0
+    (Qu(4, 4, False, TRN.TCPL, SAT.ZERO), 64, 1),
+    (Qu(6, 0), 32, 1),                                 # integer format: no product shift
+])
+def test_fast_tree_fixed_mode_variants(oracle, elem, K, dist):
+    """Default-tag shapes take the fixed-mode variants of the 32-bit tree kernel (one format everywhere);
+    they must equal the oracle and the runtime-mode variant of the same kernel."""
+    wide = Qu(elem.intBits + 6, elem.fracBits, elem.isSigned)
+    for ec in (elem, wide):
+        a = _vs_oracle(oracle, elem, elem, ec, 70, 40, K, dist=dist, expect_kernel="tree_i32")
+        b = _vs_oracle(oracle, elem, elem, ec, 70, 40, K, dist=dist, flags=capi.OPT_RUNTIME_MODES, expect_kernel="tree_i32")
+        assert np.array_equal(a, b)
+    _vs_oracle(oracle, elem, elem, elem, 33, 65, K, dist=0, mul_args=elem, add_args=[elem], transposed_a=True, expect_kernel="tree_i32")
