@@ -170,6 +170,10 @@ def main():
         state["i"] += 1
         if world > 1 and pending[b] is not None:
             pending[b].wait()          # buffer b was handed to the collective two steps ago
+            if not on_host:
+                # with RCCL wait() only orders torch's current stream; the engine launches on its own
+                # stream, so block the host until the collective has really finished reading buffer b
+                torch.cuda.current_stream().synchronize()
             pending[b] = None
         plan.execute(tCs[b].data_ptr(), tA.data_ptr(), tB.data_ptr())
         if world > 1:
