@@ -110,8 +110,8 @@ def load_traffic(workload: str):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c3L", choices=["c3L", "c3T", "c2L"])
     ap.add_argument("--size", type=int, default=4096, help="M=N=K per GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the script on a 1-GPU box)")
@@ -228,6 +228,37 @@ def main():
                           "sharding": f"rows of A/C over {world} rank(s), B replicated, one RCCL gather of C to rank 0" if world > 1 else "single GPU"},
                "pct_of_int8_peak": 100.0 * value / (INT8_DENSE_PEAK_OPS * world),
                "roofline": roof}
+        if world > 1:
+            # the curve with and without the gather
+            out["value_without_gather"] = achieved * world
+            out["gather_bytes_per_step_per_rank"] = int(pb[2])
+        if world == 1 and not args.no_extra:
+            # the layout steps either side of the hot path, timed separately (never part of `value`)
+            try:
+                import numpy as np
+                hb = info.host_elem_bytes
+                hA = torch.zeros(M * K * hb[0], dtype=torch.uint8, device=dev)
+                hB = torch.zeros(K * N * hb[1], dtype=torch.uint8, device=dev)
+                hC = torch.empty(M * N * hb[2], dtype=torch.uint8, device=dev)
+                lay = {}
+                for nm, fn in (("pack_a_ms", lambda: plan.pack(capi.OPERAND_A, hA.data_ptr(), tA.data_ptr())),
+                               ("pack_b_ms", lambda: plan.pack(capi.OPERAND_B, hB.data_ptr(), tB.data_ptr())),
+                               ("unpack_c_ms", lambda: plan.unpack_c(tC.data_ptr(), hC.data_ptr()))):
+                    fn(); ctx.sync()
+                    t1 = time.perf_counter()
+                    for _ in range(5):
+                        fn()
+                    ctx.sync()
+                    lay[nm] = (time.perf_counter() - t1) / 5 * 1e3
+                lay["host_layout_bytes"] = [int(hA.numel()), int(hB.numel()), int(hC.numel())]
+                # zeros were packed over the synthetic operands: regenerate them for the extras below
+                plan.fill(capi.OPERAND_A, 1, 0, tA.data_ptr())
+                plan.fill(capi.OPERAND_B, 2, 0, tB.data_ptr())
+                ctx.sync()
+                out["layout_steps"] = lay
+                del hA, hB, hC
+            except Exception as e:
+                out["layout_steps"] = {"error": str(e)}
         if world == 1 and not args.no_extra:
             extra = {}
             for name, (m2, n2, k2) in (("c3T", (S, S, S)), ("c2L", (8192, 8192, 4096))):
