@@ -1,0 +1,69 @@
+// ref_binding_demo.cpp — TEST INFRASTRUCTURE: the reference's OWN header and types driving the MI355X
+// engine through include/qgemul_reference_binding.hpp.  Built in the build container (it needs
+// /root/reference/include) into oracle/_ref/; the binary travels to the GPU box, where
+// tests/test_gpu_cpp_dropin.py runs it and compares the printed C matrices with the golden vectors the
+// reference's own Qmul/Qreduce produced (tests/golden).  Operand values come from ref_driver.hpp's copy
+// of the synthetic generator, exactly as the golden records were generated.
+#include "QuBLAS.h"
+#include "qgemul_reference_binding.hpp"
+#include "ref_driver.hpp"
+
+#include <cstdio>
+
+using namespace QuBLAS;
+
+template <class T>
+static void print_matrix(const char* name, const T& m, size_t n)
+{
+    std::printf("{\"name\":\"%s\",\"C\":[", name);
+    for (size_t e = 0; e < n; ++e) std::printf("%s%lld", e ? "," : "", (long long)m.data[e].data.data);
+    std::printf("]}\n");
+}
+
+template <class T>
+static void fill_synth(T& m, size_t n, uint64_t seed, int dist)
+{
+    using E = typename T::elem_t;
+    for (size_t e = 0; e < n; ++e) m.data[e].data.data = refdrv::synth<E>(seed, dist, e, 0);
+}
+
+int main()
+{
+    try {
+        {   // configuration 1: 4x4x4 int<8,8> TCPL / SAT::ZERO, values 1..16, NN and TN (SURVEY.md §8-a known answer)
+            using e88z = Qu<intBits<8>, fracBits<8>, isSigned<true>, QuMode<TRN::TCPL>, OfMode<SAT::ZERO>>;
+            using mat = Qu<dim<4, 4>, e88z>;
+            mat m1 = {1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0, 9.0, 10.0, 11.0, 12.0, 13.0, 14.0, 15.0, 16.0}, m3;
+            Qgemul<QgemulAddArgs<e88z>, QgemulMulArgs<e88z>>(m3, m1, m1);
+            print_matrix("c1_nn_classT", m3, 16);
+            Qgemul<QgemulAddArgs<e88z>, QgemulMulArgs<e88z>, QgemulTransposedA<true>>(m3, m1, m1);
+            print_matrix("c1_tn_classT", m3, 16);
+        }
+        {   // the README call, verbatim tags (readme.md:84-87), inputs as in the golden record
+            using type1 = Qu<isSigned<true>, intBits<6>, fracBits<3>, OfMode<SAT::ZERO>>;
+            using type2 = Qu<intBits<6>, fracBits<-3>>;
+            using list = TypeList<type1, type2>;
+            using matType = Qu<dim<4, 4>, type1>;
+            matType a, b, m3;
+            fill_synth(a, 16, 1, 1);
+            fill_synth(b, 16, 2, 1);
+            Qgemul<QgemulAddArgs<list>, QgemulMulArgs<type1>, QgemulTransposedA<true>>(m3, a, b);
+            print_matrix("readme_list_tn_4x4x4", m3, 16);
+        }
+        {   // linear class on the MFMA path, ragged shape, wide C
+            using e43 = Qu<intBits<4>, fracBits<3>>;
+            using w16 = Qu<intBits<16>, fracBits<3>>;
+            Qu<dim<33, 128>, e43> a;
+            Qu<dim<128, 17>, e43> b;
+            Qu<dim<33, 17>, w16> c;
+            fill_synth(a, 33 * 128, 1, 0);
+            fill_synth(b, 128 * 17, 2, 0);
+            Qgemul<QgemulMulArgs<intBits<9>, fracBits<6>>, QgemulAddArgs<Qu<intBits<19>, fracBits<6>>>>(c, a, b);
+            print_matrix("e43_L_33x17x128_full_wideC", c, 33 * 17);
+        }
+    } catch (const std::exception& e) {
+        std::printf("{\"error\":\"%s\"}\n", e.what());
+        return 3;
+    }
+    return 0;
+}

@@ -1,0 +1,41 @@
+// Runs Qgemul and Qreduce through include/QuBLAS_amd.h on the GPU (compiled by tests/test_gpu_cpp_dropin.py
+// on the GPU box with clang++ -std=c++23 and linked against qublas_amd/libqugemm.so).
+#include "QuBLAS_amd.h"
+
+#include <cstdio>
+
+using namespace QuBLAS_amd;
+
+template <class T>
+static void print_matrix(const char* name, const T& m)
+{
+    std::printf("{\"name\":\"%s\",\"C\":[", name);
+    for (size_t e = 0; e < m.data.size(); ++e) std::printf("%s%lld", e ? "," : "", (long long)m.data[e].data);
+    std::printf("]}\n");
+}
+
+int main()
+{
+    try {
+        using e88z = Qu<intBits<8>, fracBits<8>, isSigned<true>, QuMode<TRN::TCPL>, OfMode<SAT::ZERO>>;
+        using mat = Qu<dim<4, 4>, e88z>;
+        mat m1 = {1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0, 9.0, 10.0, 11.0, 12.0, 13.0, 14.0, 15.0, 16.0}, m3;
+        Qgemul<QgemulAddArgs<e88z>, QgemulMulArgs<e88z>>(m3, m1, m1);
+        print_matrix("c1_nn_classT", m3);
+        Qgemul<QgemulTransposedA<true>, QgemulMulArgs<e88z>, QgemulAddArgs<TypeList<e88z>>>(m3, m1, m1);
+        print_matrix("c1_tn_classT", m3);
+        Qgemul<>(m3, m1, m1);
+        print_matrix("c1_nn_default", m3);
+        Qgemul<QgemulMulArgs<intBits<17>, fracBits<16>>, QgemulAddArgs<Qu<intBits<29>, fracBits<16>>>>(m3, m1, m1);
+        print_matrix("c1_nn_classL", m3);
+        // Qreduce of a vector: 1+2+3+4 in int<4,3> reduced into Qu<intBits<8>,fracBits<3>> = 10.0 -> raw 80
+        using e43 = Qu<intBits<4>, fracBits<3>>;
+        Qu<dim<4>, e43> v = {1.0, 2.0, 3.0, 4.0};
+        auto r = Qreduce<Qu<intBits<8>, fracBits<3>>>(v);
+        std::printf("{\"name\":\"qreduce\",\"C\":[%lld]}\n", (long long)r.data);
+    } catch (const std::exception& e) {
+        std::printf("{\"error\":\"%s\"}\n", e.what());
+        return 3;
+    }
+    return 0;
+}
