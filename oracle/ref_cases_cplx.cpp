@@ -80,6 +80,19 @@ int main(int argc, char** argv)
         run_case<c5, c5, c5, TypeList<TFL>, TypeList<lw>, true, 4, 4, 64>("c5_tf_L_tn_4x4x64_full", syn(0), out);
         break;
     }
+    case 3: { // complex LINEAR class: BasicComplexMul with exact sub-ops and headroom in every level.
+              // (TFComplexMul can never be linear: its (b-a) is always formed in the default-merged format,
+              //  QuBLAS.h:3515, whose intBits = max(Ia, Ib) cannot hold b-a over the operands' full range.)
+        using BL = BasicComplexMul<acT<Qu<intBits<14>, fracBits<6>>>, bdT<Qu<intBits<14>, fracBits<-6>>>, adT<Qu<intBits<14>, fracBits<0>>>,
+                                   bcT<Qu<intBits<14>, fracBits<0>>>, acbdT<Qu<intBits<15>, fracBits<6>>>, adbcT<Qu<intBits<15>, fracBits<0>>>>;
+        using lw = Qcomplex<Qu<intBits<30>, fracBits<6>>, Qu<intBits<30>, fracBits<0>>>;
+        using cn = Qcomplex<Qu<intBits<9>, fracBits<2>, QuMode<RND::CONV>, OfMode<SAT::SMGN>>, Qu<intBits<7>, fracBits<-1>, QuMode<RND::ZERO>, OfMode<WRP::TCPL>>>;
+        run_case<c5, c5, cw, TypeList<BL>, TypeList<lw>, false, 8, 8, 64>("c5_basic_L_8x8x64_full_wideC", syn(0), out);
+        run_case<c5, c5, cn, TypeList<BL>, TypeList<lw>, true, 5, 7, 128>("c5_basic_L_tn_5x7x128_full_narrowC", syn(0), out);
+        run_case<c5, c5, c5, TypeList<BL>, TypeList<lw>, false, 2, 2, 2048>("c5_basic_L_2x2x2048_full", syn(0), out);
+        run_case<c5, c5, cw, TypeList<BL>, TypeList<lw>, false, 3, 3, 100>("c5_basic_L_K100_small_wideC", syn(1), out);
+        break;
+    }
     default:
         return 2;
     }

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libqugemm.so")
 QG_OK, QG_EINVAL, QG_EUNSUPPORTED, QG_EHIP, QG_ERCCL, QG_ERANGE, QG_ENOGPU = 0, -1, -2, -3, -4, -5, -6
 OPT_FORCE_TREE, OPT_CHECK_RANGE, OPT_GENERIC_TREE, OPT_RUNTIME_MODES = 1, 2, 4, 8
 OPERAND_A, OPERAND_B, OPERAND_C = 0, 1, 2
-KERNEL_NAMES = {0: "none", 1: "mfma_i8", 2: "mfma_i8_limb", 3: "tree_i32", 4: "tree_i64", 5: "tree_cplx", 6: "tree_cplx_i32"}
+KERNEL_NAMES = {0: "none", 1: "mfma_i8", 2: "mfma_i8_limb", 3: "tree_i32", 4: "tree_i64", 5: "tree_cplx", 6: "tree_cplx_i32", 7: "mfma_cplx"}
 
 EXPORTS = [
     "qgemul_classify", "qgemul_strerror", "qgemul_abi_version", "qgemul_last_hip_error", "qgemul_run",

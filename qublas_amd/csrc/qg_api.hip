@@ -42,6 +42,8 @@ struct qgemul_plan {
     QCGeom pc;
     QHostElem ha, hb, hc;
     QTreeTable* dev_table;
+    int64_t* workspace;   // complex linear class: raw dot products [2Mh x 2Nh] int64
+    QMfmaCfg cfg;
 };
 
 static int pow2_bytes(int storage_bits)
@@ -55,7 +57,7 @@ static int pow2_bytes(int storage_bits)
 static int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // fill info + geometry for a descriptor; no GPU access
-static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qgemul_info* info, int* pLA, int* pLB, int* pVar,
+static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qgemul_info* info, int* pLA, int* pLB, QMfmaCfg* pVar,
                          QPackedGeom* pa, QPackedGeom* pb, QCGeom* pc, QHostElem* ha, QHostElem* hb, QHostElem* hc)
 {
     qg_analyze(d, an);
@@ -96,10 +98,15 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     if (an->linear_ok && !(flags & QG_OPT_FORCE_TREE)) {
         LA = qg_limbs_for(d->a[0]);
         LB = qg_limbs_for(d->b[0]);
+        if (d->is_complex) {  // parts are stacked along the row axis and share one limb count
+            const int la2 = qg_limbs_for(d->a[1]), lb2 = qg_limbs_for(d->b[1]);
+            if (la2 > LA) LA = la2;
+            if (lb2 > LB) LB = lb2;
+        }
         const int mn = LA < LB ? LA : LB;
-        cfg = qg_mfma_pick(LA, LB, d->M, d->N);
+        cfg = qg_mfma_pick(LA, LB, d->M * parts, d->N * parts);
         if (cfg.variant && (int64_t)mn * d->K <= (1ll << 17) - 1)
-            kernel = (LA == 1 && LB == 1) ? QG_KERNEL_MFMA_I8 : QG_KERNEL_MFMA_I8_LIMB;
+            kernel = d->is_complex ? QG_KERNEL_MFMA_CPLX : ((LA == 1 && LB == 1) ? QG_KERNEL_MFMA_I8 : QG_KERNEL_MFMA_I8_LIMB);
         else {
             LA = LB = 0;
             snprintf(info->reason, sizeof info->reason, "linear class, but limbs/K outside the MFMA kernel's exact range: tree kernel");
@@ -119,6 +126,13 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
         pc->Np = pb->rows_p;
         pc->tm = cfg.TM;
         pc->tn = cfg.TN;
+        if (d->is_complex) {
+            // the MFMA kernel writes the raw 2Mh x 2Nh dot products into the plan's workspace; the combine
+            // pass writes the packed complex C row-major [2][M][N]
+            pc->Mp = d->M;
+            pc->Np = d->N;
+            pc->tm = pc->tn = 0;
+        }
     } else {
         const bool fast = !(flags & QG_OPT_GENERIC_TREE);
         kernel = d->is_complex ? ((an->cplx_fast_ok && fast) ? QG_KERNEL_TREE_CPLX_I32 : QG_KERNEL_TREE_CPLX) : ((an->tree_fast_ok && !(flags & QG_OPT_GENERIC_TREE)) ? QG_KERNEL_TREE_I32 : QG_KERNEL_TREE_I64);
@@ -136,7 +150,7 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     info->packed_bytes[2] = (int64_t)parts * pc->Mp * pc->Np * pc->cbytes;
     *pLA = LA;
     *pLB = LB;
-    *pVar = cfg.variant;
+    *pVar = cfg;
     return QG_OK;
 }
 
@@ -164,7 +178,8 @@ int qgemul_classify(const qgemul_desc* d, uint32_t opt_flags, qgemul_info* out)
     if (!d || !out) return QG_EINVAL;
     QAnalysis* an = new (std::nothrow) QAnalysis;
     if (!an) return QG_EINVAL;
-    int LA, LB, variant;
+    int LA, LB;
+    QMfmaCfg variant;
     QPackedGeom pa, pb;
     QCGeom pc;
     QHostElem ha, hb, hc;
@@ -253,8 +268,9 @@ int qgemul_plan_create(qgemul_ctx* c, const qgemul_desc* d, uint32_t opt_flags, 
     p->ctx = c;
     p->desc = *d;
     p->flags = opt_flags;
-    int st = plan_geometry(d, opt_flags, &p->an, &p->info, &p->LA, &p->LB, &p->variant, &p->pa, &p->pb, &p->pc, &p->ha, &p->hb, &p->hc);
+    int st = plan_geometry(d, opt_flags, &p->an, &p->info, &p->LA, &p->LB, &p->cfg, &p->pa, &p->pb, &p->pc, &p->ha, &p->hb, &p->hc);
     if (st != QG_OK) { delete p; return st; }
+    p->variant = p->cfg.variant;
     if (hipSetDevice(c->device) != hipSuccess || hipMalloc((void**)&p->dev_table, sizeof(QTreeTable)) != hipSuccess) {
         delete p;
         return QG_EHIP;
@@ -265,6 +281,14 @@ int qgemul_plan_create(qgemul_ctx* c, const qgemul_desc* d, uint32_t opt_flags, 
         delete p;
         return QG_EHIP;
     }
+    if (p->info.kernel == QG_KERNEL_MFMA_CPLX) {
+        const size_t ws = (size_t)(2 * p->pa.rows_p) * (size_t)(2 * p->pb.rows_p) * sizeof(int64_t);
+        if (hipMalloc((void**)&p->workspace, ws) != hipSuccess) {
+            hipFree(p->dev_table);
+            delete p;
+            return QG_EHIP;
+        }
+    }
     *out = p;
     return QG_OK;
 }
@@ -274,6 +298,7 @@ void qgemul_plan_destroy(qgemul_plan* p)
     if (!p) return;
     hipStreamSynchronize(p->ctx->stream);
     hipFree(p->dev_table);
+    hipFree(p->workspace);
     delete p;
 }
 
@@ -366,6 +391,36 @@ int qgemul_execute(qgemul_plan* p, void* packedC, const void* packedA, const voi
         a.variant = p->variant;
         a.to_c = p->an.lin.to_c[0];
         QG_HIP(qg_launch_mfma(p->LA, p->LB, a, st));
+        return QG_OK;
+    }
+    case QG_KERNEL_MFMA_CPLX: {
+        QMfmaArgs a;
+        a.A = (const int8_t*)packedA;
+        a.B = (const int8_t*)packedB;
+        a.C = p->workspace;
+        a.Mp = 2 * p->pa.rows_p;
+        a.Np = 2 * p->pb.rows_p;
+        a.Kp = p->pa.K_p;
+        a.cbytes = 8;
+        a.variant = p->variant;
+        memset(&a.to_c, 0, sizeof a.to_c);
+        a.to_c.identity = 1;  // raw 64-bit dot products
+        QG_HIP(qg_launch_mfma(p->LA, p->LB, a, st));
+        QCplxCombine g;
+        g.D = p->workspace;
+        g.C = (char*)packedC;
+        g.M = p->desc.M;
+        g.N = p->desc.N;
+        g.Mh = p->pa.rows_p;
+        g.Nh = p->pb.rows_p;
+        g.Np = 2 * p->pb.rows_p;
+        g.tm = p->cfg.TM;
+        g.tn = p->cfg.TN;
+        g.cbytes = p->pc.cbytes;
+        for (int i = 0; i < 4; ++i) g.sh[i] = p->an.lin.sh[i];
+        g.to_c[0] = p->an.lin.to_c[0];
+        g.to_c[1] = p->an.lin.to_c[1];
+        QG_HIP(qg_launch_cplx_combine(g, st));
         return QG_OK;
     }
     case QG_KERNEL_TREE_I32:

@@ -24,7 +24,7 @@ struct QOperandGeom {
 //           LDS-DMA (1 KiB per wave instruction, fully sequential in HBM; no row pitch, hence no
 //           power-of-two-stride channel camping).
 struct QPackedGeom {
-    int64_t rows_p, K_p;    // padded extents
+    int64_t rows_p, K_p;    // padded extents (rows_p per part: complex limb operands stack their parts along rows)
     int32_t cbytes;         // container bytes (tree layout), 1 for limb layout
     int32_t limbs;          // 0 = tree layout, >0 = limb layout
     int32_t tr, bk;         // limb layout: rows per tile, k bytes per tile
@@ -43,6 +43,17 @@ hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const voi
                           int* range_flag, hipStream_t st);
 hipError_t qg_launch_fill(const QOperandGeom& g, const QPackedGeom& p, uint64_t seed, int dist, void* dst, hipStream_t st);
 hipError_t qg_launch_unpack_c(const QCGeom& c, const void* packed, void* dst, hipStream_t st);
+
+// complex linear class: combine the four raw dot-product blocks of D (tiled int64) into packed complex C [2][M][N]
+struct QCplxCombine {
+    const int64_t* D;   // [Mp/tm][Np/tn][tn][tm], Mp = 2*Mh, Np = 2*Nh
+    char* C;
+    int64_t M, N, Mh, Nh, Np;
+    int32_t tm, tn, cbytes;
+    int32_t sh[4];
+    QStep to_c[2];
+};
+hipError_t qg_launch_cplx_combine(const QCplxCombine& g, hipStream_t st);
 
 // exact tree evaluation, any descriptor (real / complex, any K), 64-bit arithmetic
 hipError_t qg_launch_tree_generic(const QTreeTable* dev_table, int parts, const void* A, const void* B, void* C, int64_t M,

@@ -38,12 +38,14 @@ __device__ __forceinline__ int64_t load_container(const char* src, int64_t idx, 
 }
 
 // write one logical value (r,k,part) into the packed operand
-__device__ __forceinline__ void put_packed(const QPackedGeom& p, char* dst, int part, int64_t r, int64_t k, int64_t v)
+__device__ __forceinline__ void put_packed(const QPackedGeom& p, char* dst, int part, int64_t r, int64_t k, int64_t v)  // r, k: indices inside the part
 {
     if (p.limbs == 0) {
         store_container(dst, ((int64_t)part * p.rows_p + r) * p.K_p + k, p.cbytes, v);
     } else {
         // pre-tiled, pre-swizzled limb planes (see QPackedGeom)
+        // complex operands stack their parts along the row axis: part q occupies rows [q*rows_p, (q+1)*rows_p)
+        r += (int64_t)part * p.rows_p;
         const int64_t nk = p.K_p / p.bk;
         const int rl = (int)(r % p.tr), kl = (int)(k % p.bk);
         const int cpr = p.bk / 16, rpb = 256 / p.bk;
@@ -131,7 +133,33 @@ __global__ __launch_bounds__(256) void k_unpack_c(QCGeom c, const char* __restri
     }
 }
 
+// complex linear class: D = [A_re; A_im] x [B_re | B_im] raw dot products (tiled int64, as the MFMA kernel stores a
+// cbytes = 8 C), combined into re = (P1 << s0) - (P2 << s1), im = (P3 << s2) + (P4 << s3), one round + overflow per part
+__global__ __launch_bounds__(256) void k_cplx_combine(QCplxCombine g)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= g.M * g.N) return;
+    const int64_t m = idx / g.N, n = idx % g.N;
+    auto D = [&](int64_t r, int64_t c) {
+        const int64_t tn = g.Np / g.tn;
+        return g.D[(((r / g.tm) * tn + c / g.tn) * g.tn + c % g.tn) * g.tm + r % g.tm];
+    };
+    const int64_t P1 = D(m, n), P2 = D(g.Mh + m, g.Nh + n), P3 = D(m, g.Nh + n), P4 = D(g.Mh + m, n);
+    const int64_t re = qg_shl<int64_t>(P1, g.sh[0]) - qg_shl<int64_t>(P2, g.sh[1]);
+    const int64_t im = qg_shl<int64_t>(P3, g.sh[2]) + qg_shl<int64_t>(P4, g.sh[3]);
+    store_container(g.C, m * g.N + n, g.cbytes, qg_step<int64_t>(re, g.to_c[0]));
+    store_container(g.C, g.M * g.N + m * g.N + n, g.cbytes, qg_step<int64_t>(im, g.to_c[1]));
+}
+
 } // namespace
+
+hipError_t qg_launch_cplx_combine(const QCplxCombine& g, hipStream_t st)
+{
+    const int64_t n = g.M * g.N;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_cplx_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
+    return hipGetLastError();
+}
 
 hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const void* src, void* dst, int check_range,
                           int* range_flag, hipStream_t st)

@@ -323,13 +323,39 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
             if (out->lin.to_c[0].d > 61 || out->lin.to_c[0].d < -61) c.exact = false;
         }
     }
+    if (cx) {
+        // Complex linear class.  When every sub-operation and tree node is exact, both multipliers reduce to
+        //   re = sum_k (a c - b d),  im = sum_k (a d + b c)
+        // (TF: A - B = (a+b)c - (c+d)b, B - C = (c+d)b - (b-a)d), each term carrying the power of two of its
+        // operands' fracBits.  Evaluate the two parts at frac Fx = max(Fa+Fc, Fb+Fd) and Fy = max(Fa+Fd, Fb+Fc).
+        const int Fa = d->a[0].F, Fb = d->a[1].F, Fc = d->b[0].F, Fd = d->b[1].F;
+        const int Fx = (Fa + Fc > Fb + Fd) ? Fa + Fc : Fb + Fd;
+        const int Fy = (Fa + Fd > Fb + Fc) ? Fa + Fd : Fb + Fc;
+        out->lin.sh[0] = Fx - (Fa + Fc);
+        out->lin.sh[1] = Fx - (Fb + Fd);
+        out->lin.sh[2] = Fy - (Fa + Fd);
+        out->lin.sh[3] = Fy - (Fb + Fc);
+        out->lin.to_c[0] = make_step(Fx, d->c[0], false);
+        out->lin.to_c[1] = make_step(Fy, d->c[1], false);
+        for (int p = 0; p < 2; ++p)
+            if (out->lin.to_c[p].d > 61 || out->lin.to_c[p].d < -61) c.exact = false;
+        // width of the combined value: K terms of |a c| 2^sh + |b d| 2^sh
+        Rng ra = fmt_range(d->a[0]), rb = fmt_range(d->a[1]), rc = fmt_range(d->b[0]), rd = fmt_range(d->b[1]);
+        I128 m = 0;
+        auto mag = [](Rng r) { I128 a = r.lo < 0 ? -r.lo : r.lo; return a > r.hi ? a : r.hi; };
+        I128 t1 = mag(ra) * mag(rc) * ((I128)1 << out->lin.sh[0]) + mag(rb) * mag(rd) * ((I128)1 << out->lin.sh[1]);
+        I128 t2 = mag(ra) * mag(rd) * ((I128)1 << out->lin.sh[2]) + mag(rb) * mag(rc) * ((I128)1 << out->lin.sh[3]);
+        m = (t1 > t2 ? t1 : t2) * d->K;
+        out->dot_bits = bits_of(m);
+        if (out->dot_bits > 62 || out->lin.sh[0] > 40 || out->lin.sh[1] > 40 || out->lin.sh[2] > 40 || out->lin.sh[3] > 40) c.exact = false;
+    }
     if (out->status != QG_OK) return;
 
     out->max_bits = c.max_bits;
     out->max_bits_np = c.max_bits_np;
     c.max_fmt_bits = g_fmt_bits_seen; // the int32 kernels keep every format's bounds in 32-bit registers
     if (c.max_bits > 62) { c.fail(QG_EUNSUPPORTED, "an intermediate needs more than 62 bits"); return; }
-    out->linear_ok = (c.exact && !cx) ? 1 : 0;
+    out->linear_ok = c.exact ? 1 : 0;
     out->cls = out->linear_ok ? QG_CLASS_LINEAR : QG_CLASS_TREE;
     // 32-bit tree kernel (qg_tree_fast.hip): real, K a power of two >= 32, every value except the
     // unrounded product fits 31 bits, and the product is either directly 32-bit or splittable at
@@ -363,5 +389,5 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     out->cplx_fast_ok = (cx && d->K >= 32 && (d->K & (d->K - 1)) == 0 && d->n_levels <= 16 && c.max_bits <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     if (!out->linear_ok)
         snprintf(out->reason, sizeof out->reason, "%s",
-                 cx ? "complex operands: exact tree evaluation" : "a product or tree node may round or overflow: exact tree evaluation");
+                 "a product or tree node may round or overflow: exact tree evaluation");
 }

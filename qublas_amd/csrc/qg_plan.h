@@ -20,6 +20,10 @@ struct QTreeTable {
 // epilogue of the linear class: exact dot product at frac (Fa+Fb) -> C
 struct QLinearEpilogue {
     QStep to_c[2];
+    // complex linear class: with the raw dot products P1 = sum a*c, P2 = sum b*d, P3 = sum a*d, P4 = sum b*c
+    // (x = a+bi from A, y = c+di from B),  re = (P1 << sh[0]) - (P2 << sh[1]),  im = (P3 << sh[2]) + (P4 << sh[3]),
+    // each then rounded/overflowed ONCE into C's part by to_c[part]
+    int32_t sh[4];
 };
 
 struct QAnalysis {

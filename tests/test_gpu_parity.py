@@ -271,3 +271,26 @@ def test_fast_tree_fixed_mode_variants(oracle, elem, K, dist):
         b = _vs_oracle(oracle, elem, elem, ec, 70, 40, K, dist=dist, flags=capi.OPT_RUNTIME_MODES, expect_kernel="tree_i32")
         assert np.array_equal(a, b)
     _vs_oracle(oracle, elem, elem, elem, 33, 65, K, dist=0, mul_args=elem, add_args=[elem], transposed_a=True, expect_kernel="tree_i32")
+
+
+def test_complex_linear_class_on_mfma(oracle):
+    """Complex operands whose BasicComplexMul sub-ops and tree levels are all exact: four real int8-limb dot
+    products on MFMA + one combine pass, against the oracle and against the exact tree kernel."""
+    r = Qu(6, 3, True, RND.POS_INF, SAT.TCPL)
+    i = Qu(6, -3, True, RND.POS_INF, SAT.TCPL)
+    c5 = Qcomplex(r, i)
+    BL = BasicComplexMul(acT=Qu(14, 6), bdT=Qu(14, -6), adT=Qu(14, 0), bcT=Qu(14, 0), acbdT=Qu(15, 6), adbcT=Qu(15, 0))
+    lw = Qcomplex(Qu(30, 6), Qu(30, 0))
+    wide = Qcomplex(Qu(18, 6, True, RND.POS_INF), Qu(18, 6, True, RND.POS_INF))
+    narrow = Qcomplex(Qu(9, 2, True, RND.CONV, SAT.SMGN), Qu(7, -1, True, RND.ZERO, WRP.TCPL))
+    for ec, shape, ta in ((wide, (200, 130, 512), False), (narrow, (130, 257, 256), True), (c5, (64, 64, 2048), False)):
+        M, N, K = shape
+        a = _vs_oracle(oracle, c5, c5, ec, M, N, K, mul_args=BL, add_args=[lw], transposed_a=ta, expect_kernel="mfma_cplx")
+        b = _vs_oracle(oracle, c5, c5, ec, M, N, K, mul_args=BL, add_args=[lw], transposed_a=ta, flags=capi.OPT_FORCE_TREE)
+        assert fields_equal(a, b)
+    # symmetric 8-bit parts: single limb per part
+    r8 = Qu(4, 3)
+    c8 = Qcomplex(r8, r8)
+    B8 = BasicComplexMul(acT=Qu(9, 6), bdT=Qu(9, 6), adT=Qu(9, 6), bcT=Qu(9, 6), acbdT=Qu(10, 6), adbcT=Qu(10, 6))
+    l8 = Qcomplex(Qu(22, 6), Qu(22, 6))
+    _vs_oracle(oracle, c8, c8, Qcomplex(Qu(16, 3), Qu(16, 3)), 300, 200, 1024, mul_args=B8, add_args=[l8], expect_kernel="mfma_cplx")

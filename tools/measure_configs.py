@@ -28,6 +28,9 @@ CASES = [
     ("c4 shard 2048x16384x4096 (what one of 8 GPUs computes)", lower(E43, E43, E43, 2048, 16384, 4096, mul_args=Tags(9, 6), add_args=[Qu(21, 6)]), 50),
     ("c5 2048^2 (K=2048) Qcomplex<int<6,3>,int<6,-3>> TFComplexMul RND+SAT -> tree (complex)", lower(C5, C5, C5, 2048, 2048, 2048, mul_args=TFComplexMul()), 2),
     ("c5 same, BasicComplexMul", lower(C5, C5, C5, 2048, 2048, 2048, mul_args=BasicComplexMul()), 2),
+    ("c5 linear-class variant: BasicComplexMul with exact sub-op types, levels Qcomplex<Qu<30,6>,Qu<30,0>> -> 4 real limb GEMMs on MFMA",
+     lower(C5, C5, C5, 2048, 2048, 2048, mul_args=BasicComplexMul(acT=Qu(14, 6), bdT=Qu(14, -6), adT=Qu(14, 0), bcT=Qu(14, 0), acbdT=Qu(15, 6), adbcT=Qu(15, 0)),
+           add_args=[Qcomplex(Qu(30, 6), Qu(30, 0))]), 20),
 ]
 
 
