@@ -291,6 +291,7 @@ def test_complex_linear_class_on_mfma(oracle):
     # symmetric 8-bit parts: single limb per part
     r8 = Qu(4, 3)
     c8 = Qcomplex(r8, r8)
-    B8 = BasicComplexMul(acT=Qu(9, 6), bdT=Qu(9, 6), adT=Qu(9, 6), bcT=Qu(9, 6), acbdT=Qu(10, 6), adbcT=Qu(10, 6))
+    # adbcT needs 11 int bits: ad + bc reaches exactly 2^15 at a=b=c=d=-128, and two of those overflow Qu<10,6> by one LSB
+    B8 = BasicComplexMul(acT=Qu(9, 6), bdT=Qu(9, 6), adT=Qu(9, 6), bcT=Qu(9, 6), acbdT=Qu(11, 6), adbcT=Qu(11, 6))
     l8 = Qcomplex(Qu(22, 6), Qu(22, 6))
     _vs_oracle(oracle, c8, c8, Qcomplex(Qu(16, 3), Qu(16, 3)), 300, 200, 1024, mul_args=B8, add_args=[l8], expect_kernel="mfma_cplx")
