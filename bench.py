@@ -33,7 +33,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 INT8_DENSE_PEAK_OPS = 5.0e15   # MI355X dense int8 MFMA, /opt/skills/guides/MI355X_MICROARCH.md (I8 = 2x BF16 ~2.5 PF)
-HBM_PEAK = 8.0e12
 
 
 def workloads():
@@ -80,7 +79,6 @@ def cpu_baseline(variant: str, budget_s: float = 20.0):
                 "sample": f"{procs_n} processes x ({rows} rows x {cols} cols x K={res[0]['K']}) of the same workload, "
                           f"reference Qmul+Qreduce+convert via oracle/_ref/ref_bench {variant}, {wall:.1f} s wall"}
     # fall back to the C restatement (kind "port")
-    import numpy as np
     from oracle import qoracle
     wl = workloads()["c3L" if variant == "c3L" else "c3T" if variant == "c3T" else "c2L"]
     from qublas_amd.desc import lower
@@ -235,7 +233,6 @@ def main():
         if world == 1 and not args.no_extra:
             # the layout steps either side of the hot path, timed separately (never part of `value`)
             try:
-                import numpy as np
                 hb = info.host_elem_bytes
                 hA = torch.zeros(M * K * hb[0], dtype=torch.uint8, device=dev)
                 hB = torch.zeros(K * N * hb[1], dtype=torch.uint8, device=dev)

@@ -94,10 +94,6 @@ template <class M> struct tag_apply<QuMode<M>> { static constexpr void go(TagSet
 template <class M> struct tag_apply<OfMode<M>> { static constexpr void go(TagSet& t) { if (!t.hasO) { t.hasO = true; t.O = M::value; } } };
 template <> struct tag_apply<FullPrec> { static constexpr void go(TagSet& t) { t.full = true; } };
 
-template <class T> struct is_scalar_qu : std::false_type {};
-template <int I, int F, bool S, class Q, class O>
-struct is_scalar_qu<Qu_s<intBits<I>, fracBits<F>, isSigned<S>, QuMode<Q>, OfMode<O>>> : std::true_type {};
-
 // parse<Tags…>: loose tags; a TypeList is opened; a full scalar Qu type counts as its five tags
 // ONLY when it is the sole argument (MergerArgsWrapper_s single-argument specialisation,
 // QuBLAS.h:3097-3099) — next to other arguments the reference leaves it wrapped and no tag
