@@ -36,7 +36,10 @@ __device__ __forceinline__ int swz(int r)
 {
     constexpr int CPR = BK / 16;   // chunks per row
     constexpr int RPB = 256 / BK;  // rows per 256-byte bank row
-    return (r / RPB) % CPR;
+    const int q = (r / RPB) % CPR;
+    // For 64-byte rows q -> {0,2,3,1}[q] keeps the 32x32x32 reads conflict free (any bijection does) AND makes the
+    // 16x16x64 fragment reads (rows l&15, chunk l>>4) conflict free; k_pack applies the same function.
+    return BK == 64 ? ((0x78 >> (2 * q)) & 3) : q;
 }
 
 // LA, LB : int8 limbs per A / B element          BK       : k-tile in bytes
@@ -240,6 +243,178 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Single-limb variant on v_mfma_i32_16x16x64_i8: same tiles, LDS image and pipeline idea, but one MFMA
+// k-step covers a whole 64-byte k-tile, so the fragment double-buffer alternates per K-TILE and the one
+// barrier per k-tile sits at the top of the iteration.  (A/B of the two MFMA shapes: DESIGN.md §9.)
+// Fragment map: lane l holds row (l & 15), bytes [16*(l>>4), +16) of the 64-byte k-step for A and B alike;
+// C/D: col = lane & 15, rows 4*(lane>>4) .. +3 in the 4 result registers.
+typedef int v4acc __attribute__((ext_vector_type(4)));
+
+template <int WGM, int WGN, int TI, int TJ>   // TI x TJ tiles of 16x16 per wave
+__global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
+{
+    constexpr int BK = 64, NSTAGE = 3;
+    constexpr int TM = WGM * TI * 16, TN = WGN * TJ * 16;
+    constexpr int NWAVES = WGM * WGN;
+    constexpr int STAGE = (TM + TN) * BK;
+    constexpr int PIECES = STAGE / 1024;
+    constexpr int PPW = PIECES / NWAVES;
+    static_assert(PIECES % NWAVES == 0, "every wave issues the same number of LDS-DMA pieces");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int tiles_m = (int)(g.Mp / TM), tiles_n = (int)(g.Np / TN);
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+    }
+    constexpr int GM = 8;
+    const int grp = bid / (GM * tiles_n);
+    const int first_m = grp * GM;
+    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int tile_m = first_m + (bid % (GM * tiles_n)) % gsz;
+    const int tile_n = (bid % (GM * tiles_n)) / gsz;
+
+    const int nk = (int)(g.Kp / BK);
+    constexpr int A_BYTES = TM * BK, B_BYTES = TN * BK, A_PIECES = A_BYTES / 1024;
+    const int8_t* Ag = g.A + (int64_t)tile_m * nk * A_BYTES + lane * 16;
+    const int8_t* Bg = g.B + (int64_t)tile_n * nk * B_BYTES + lane * 16;
+    auto issue = [&](int stage, int kt) {
+        char* sbase = smem + stage * STAGE;
+        const int8_t* a = Ag + (int64_t)kt * A_BYTES;
+        const int8_t* b = Bg + (int64_t)kt * B_BYTES;
+#pragma unroll
+        for (int pi = 0; pi < PPW; ++pi) {
+            const int p = wave + NWAVES * pi;
+            const int8_t* src = p < A_PIECES ? a + p * 1024 : b + (p - A_PIECES) * 1024;
+            __builtin_amdgcn_global_load_lds(QG_GLOBAL_PTR(src), QG_LDS_PTR(sbase + p * 1024), 16, 0, 0);
+        }
+    };
+
+    v4acc acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0;
+
+    const int fr = lane & 15, fq = lane >> 4;
+    v4i fa[2][TI], fb[2][TJ];
+    auto load_frags = [&](int set, const char* sA) {
+        const char* sB = sA + TM * BK;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int ra = (wm * TI + i) * 16 + fr;
+            fa[set][i] = *(const v4i*)(sA + ra * BK + ((fq ^ swz<BK>(ra)) * 16));
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int rb = (wn * TJ + j) * 16 + fr;
+            fb[set][j] = *(const v4i*)(sB + rb * BK + ((fq ^ swz<BK>(rb)) * 16));
+        }
+    };
+    auto mfmas = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+    };
+    auto publish = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // tiles 0, 1 in flight; tile 0 published and its fragments loaded
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_frags(0, smem);
+    // iteration kt: publish tile kt+1, refill the stage of tile kt-1 with tile kt+2, prefetch fragments of kt+1, MFMA kt
+    int st1 = 1, st2 = 2;  // stages of tiles kt+1, kt+2
+    for (int kt = 0; kt < nk; kt += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = kt + h;
+            if (k < nk) {
+                if (k + 1 < nk) {
+                    publish();
+                    if (k + 2 < nk) issue(st2, k + 2);
+                    load_frags(h ^ 1, smem + st1 * STAGE);
+                }
+                mfmas(h);
+                st1 = st2;
+                st2 = (st1 + 1) % 3;
+            }
+        }
+    }
+
+    const QStep st = g.to_c;
+    char* C = (char*)g.C;
+    const int64_t tile_base = ((int64_t)tile_m * tiles_n + tile_n) * TM * TN;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        int32_t s[4 * TJ];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[j * 4 + e] = acc[i][j][e];
+        qg_step_all<int32_t, 4 * TJ>(s, st);
+        const int row0 = (wm * TI + i) * 16 + 4 * fq;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int col = (wn * TJ + j) * 16 + fr;
+            const int64_t base = tile_base + (int64_t)col * TM + row0;
+            const int32_t* q = s + j * 4;
+            switch (g.cbytes) {
+            case 1:
+                *(uint32_t*)(C + base) = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) | ((uint32_t)(q[3] & 0xff) << 24);
+                break;
+            case 2:
+                *(uint2*)(C + base * 2) = make_uint2((uint32_t)(q[0] & 0xffff) | ((uint32_t)(q[1] & 0xffff) << 16), (uint32_t)(q[2] & 0xffff) | ((uint32_t)(q[3] & 0xffff) << 16));
+                break;
+            case 4:
+                *(int4*)(C + base * 4) = make_int4(q[0], q[1], q[2], q[3]);
+                break;
+            default: {
+                int64_t* p = (int64_t*)(C + base * 8);
+                *(longlong2*)p = make_longlong2((int64_t)q[0], (int64_t)q[1]);
+                *(longlong2*)(p + 2) = make_longlong2((int64_t)q[2], (int64_t)q[3]);
+                break;
+            }
+            }
+        }
+    }
+}
+
+template <int WGM, int WGN, int TI, int TJ>
+hipError_t launch16(const QMfmaArgs& a, hipStream_t st)
+{
+    constexpr int TM = WGM * TI * 16, TN = WGN * TJ * 16;
+    const int lds = 3 * (TM + TN) * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_mfma16<WGM, WGN, TI, TJ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int64_t blocks = (a.Mp / TM) * (a.Np / TN);
+    if (blocks <= 0) return hipSuccess;
+    if (blocks > 0x7fffffffll || a.Kp % 64 || a.Mp % TM || a.Np % TN) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_mfma16<WGM, WGN, TI, TJ>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
+    return hipGetLastError();
+}
+
 template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE, int ABL = 0>
 hipError_t launch(const QMfmaArgs& a, hipStream_t st)
 {
@@ -297,6 +472,7 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
             }
         }
         if (LA == 1 && LB == 1 && a.variant == 2) {
+            if (abl == 16) return launch16<2, 4, 8, 4>(a, st);
             switch (abl) {
             case 1: return launch<1, 1, 64, 2, 4, 4, 2, 3, 1>(a, st);
             case 2: return launch<1, 1, 64, 2, 4, 4, 2, 3, 2>(a, st);

@@ -49,7 +49,9 @@ __device__ __forceinline__ void put_packed(const QPackedGeom& p, char* dst, int 
         const int64_t nk = p.K_p / p.bk;
         const int rl = (int)(r % p.tr), kl = (int)(k % p.bk);
         const int cpr = p.bk / 16, rpb = 256 / p.bk;
-        const int slot = (kl / 16) ^ ((rl / rpb) % cpr);
+        int sw = (rl / rpb) % cpr;
+        if (p.bk == 64) sw = (0x78 >> (2 * sw)) & 3;  // the kernels' swz<64>(): {0,2,3,1}
+        const int slot = (kl / 16) ^ sw;
         const int64_t blk = ((r / p.tr) * nk + k / p.bk) * p.limbs;
         for (int l = 0; l < p.limbs; ++l) {
             int64_t d = (int64_t)(int8_t)(v & 0xff); // balanced digit in [-128,127]
