@@ -3,7 +3,7 @@
 // When every intermediate conversion of the reference expression is provably the identity, the
 // whole tree equals the exact integer dot product and ONE round + overflow into C's format is
 // the entire epilogue (converting constructor, /root/reference/include/QuBLAS.h:2398-2411).  The dot product runs on
-// v_mfma_i32_32x32x32_i8.  Operands wider than 8 storage bits are split on the host-facing pack
+// v_mfma_i32_32x32x32_i8 (limb kernels) or v_mfma_i32_16x16x64_i8 (single limb).  Operands wider than 8 storage bits are split on the host-facing pack
 // step into balanced base-256 int8 limbs (x = sum_l d_l * 256^l, d_l in [-128,127]); the kernel
 // then issues LA*LB MFMAs per k-step into LA+LB-1 int32 accumulators, one per limb weight, and
 // recombines them in 64-bit in the epilogue.  int32 accumulation is exact: |d*d'| <= 2^14 and
@@ -460,7 +460,7 @@ static int ablation()
 
 hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
 {
-    if (const int abl = ablation()) {
+    if (const int abl = ablation(); abl > 0 && abl < 16) {
         if (LA == 3 && LB == 3) {
             switch (abl) {
             case 1: return launch<3, 3, 64, 2, 4, 2, 1, 3, 1>(a, st);
@@ -472,7 +472,6 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
             }
         }
         if (LA == 1 && LB == 1 && a.variant == 2) {
-            if (abl == 16) return launch16<2, 4, 8, 4>(a, st);
             switch (abl) {
             case 1: return launch<1, 1, 64, 2, 4, 4, 2, 3, 1>(a, st);
             case 2: return launch<1, 1, 64, 2, 4, 4, 2, 3, 2>(a, st);
@@ -484,8 +483,11 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
         }
     }
     if (LA == 1 && LB == 1) {
-        if (a.variant == 2) return launch<1, 1, 64, 2, 4, 4, 2, 3>(a, st);
-        return launch<1, 1, 64, 2, 2, 2, 2, 3>(a, st);
+        // single limb: v_mfma_i32_16x16x64_i8 measured 8 % faster than 32x32x32 at the same tiles
+        // (0.283 vs 0.308 ms at 8192x8192x4096, profiles/r01n_ablation_mfma_shape.log); QG_ABLATE=32 keeps the other
+        if (ablation() == 32) return a.variant == 2 ? launch<1, 1, 64, 2, 4, 4, 2, 3>(a, st) : launch<1, 1, 64, 2, 2, 2, 2, 3>(a, st);
+        if (a.variant == 2) return launch16<2, 4, 8, 4>(a, st);
+        return launch16<2, 2, 4, 4>(a, st);
     }
     switch (LA * 10 + LB) {
     case 12: return launch<1, 2, 64, 2, 4, 2, 1, 3>(a, st);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Price the phases of the MFMA kernels: runs bench-sized launches of the diagnostic variants
 (QG_ABLATE, results wrong by construction) in child processes and prints kernel ms for each.
-   0 full | 1 no LDS-DMA in loop | 2 no fragment ds_reads in loop | 3 neither | 4 neither, no barrier | 5 no C stores | 6 LDS-DMA always re-reads k-tile 0 (all cache hits)"""
+   0 full | 1 no LDS-DMA in loop | 2 no fragment ds_reads in loop | 3 neither | 4 neither, no barrier | 5 no C stores | 6 LDS-DMA always re-reads k-tile 0 (all cache hits) | 32 single-limb kernel on the 32x32x32 MFMA shape instead of 16x16x64"""
 import json
 import os
 import subprocess
@@ -25,7 +25,7 @@ print(json.dumps({"ms": ms}))
 ''' % ROOT
 
 for wl, shape in (("c3L", (4096, 4096, 4096)), ("c2L", (8192, 8192, 4096))):
-    for abl in ((0, 16, 0, 16, 0, 16) if wl == 'c2L' else (0,)):
+    for abl in ((0, 32, 0, 32, 0, 32) if wl == 'c2L' else (0, 1, 2, 3, 4, 5, 6, 0)):
         env = dict(os.environ, QG_ABLATE=str(abl))
         out = subprocess.check_output([sys.executable, "-c", CODE, wl, *map(str, shape)], env=env, text=True)
         ms = json.loads(out.strip().splitlines()[-1])["ms"]
