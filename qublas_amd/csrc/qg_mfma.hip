@@ -251,15 +251,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 // C/D: col = lane & 15, rows 4*(lane>>4) .. +3 in the 4 result registers.
 typedef int v4acc __attribute__((ext_vector_type(4)));
 
-template <int WGM, int WGN, int TI, int TJ>   // TI x TJ tiles of 16x16 per wave
+// LA x LB limbs; DBUF: fragments double-buffered across k-tiles (only when the registers allow it)
+template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF>   // TI x TJ tiles of 16x16 per wave
 __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
 {
     constexpr int BK = 64, NSTAGE = 3;
     constexpr int TM = WGM * TI * 16, TN = WGN * TJ * 16;
     constexpr int NWAVES = WGM * WGN;
-    constexpr int STAGE = (TM + TN) * BK;
+    constexpr int NW = LA + LB - 1;
+    constexpr int STAGE = (LA * TM + LB * TN) * BK;
     constexpr int PIECES = STAGE / 1024;
     constexpr int PPW = PIECES / NWAVES;
+    constexpr int NSET = DBUF ? 2 : 1;
     static_assert(PIECES % NWAVES == 0, "every wave issues the same number of LDS-DMA pieces");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
     const int tile_n = (bid % (GM * tiles_n)) / gsz;
 
     const int nk = (int)(g.Kp / BK);
-    constexpr int A_BYTES = TM * BK, B_BYTES = TN * BK, A_PIECES = A_BYTES / 1024;
+    constexpr int A_BYTES = LA * TM * BK, B_BYTES = LB * TN * BK, A_PIECES = A_BYTES / 1024;
     const int8_t* Ag = g.A + (int64_t)tile_m * nk * A_BYTES + lane * 16;
     const int8_t* Bg = g.B + (int64_t)tile_n * nk * B_BYTES + lane * 16;
     auto issue = [&](int stage, int kt) {
@@ -296,35 +299,43 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
         }
     };
 
-    v4acc acc[TI][TJ];
+    v4acc acc[NW][TI][TJ];
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0;
-
-    const int fr = lane & 15, fq = lane >> 4;
-    v4i fa[2][TI], fb[2][TJ];
-    auto load_frags = [&](int set, const char* sA) {
-        const char* sB = sA + TM * BK;
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            const int ra = (wm * TI + i) * 16 + fr;
-            fa[set][i] = *(const v4i*)(sA + ra * BK + ((fq ^ swz<BK>(ra)) * 16));
-        }
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int rb = (wn * TJ + j) * 16 + fr;
-            fb[set][j] = *(const v4i*)(sB + rb * BK + ((fq ^ swz<BK>(rb)) * 16));
-        }
-    };
-    auto mfmas = [&](int set) {
+    for (int w = 0; w < NW; ++w)
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[w][i][j][e] = 0;
+
+    const int fr = lane & 15, fq = lane >> 4;
+    v4i fa[NSET][LA][TI], fb[NSET][LB][TJ];
+    auto load_frags = [&](int set, const char* sA) {
+        const char* sB = sA + LA * TM * BK;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int ra = (wm * TI + i) * 16 + fr;
+#pragma unroll
+            for (int l = 0; l < LA; ++l) fa[set][l][i] = *(const v4i*)(sA + (l * TM + ra) * BK + ((fq ^ swz<BK>(ra)) * 16));
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int rb = (wn * TJ + j) * 16 + fr;
+#pragma unroll
+            for (int l = 0; l < LB; ++l) fb[set][l][j] = *(const v4i*)(sB + (l * TN + rb) * BK + ((fq ^ swz<BK>(rb)) * 16));
+        }
+    };
+    auto mfmas = [&](int set) {
+#pragma unroll
+        for (int la = 0; la < LA; ++la)
+#pragma unroll
+            for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[la + lb][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][la][i], fb[set][lb][j], acc[la + lb][i][j], 0, 0, 0);
     };
     auto publish = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -332,50 +343,61 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
         asm volatile("" ::: "memory");
     };
 
-    // tiles 0, 1 in flight; tile 0 published and its fragments loaded
+    // tiles 0, 1 in flight; tile 0 published
     issue(0, 0);
     if (nk > 1) issue(1, 1);
     if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    load_frags(0, smem);
-    // iteration kt: publish tile kt+1, refill the stage of tile kt-1 with tile kt+2, prefetch fragments of kt+1, MFMA kt
-    int st1 = 1, st2 = 2;  // stages of tiles kt+1, kt+2
-    for (int kt = 0; kt < nk; kt += 2) {
+    static_assert(DBUF, "fragments are double-buffered across k-tiles (a register-lean single-buffered limb variant of this"
+                        " kernel was measured 2 % slower than k_mfma on 32x32x32 and dropped)");
+    {
+        // iteration k: publish tile k+1, refill the stage of tile k-1 with tile k+2, prefetch fragments of k+1, MFMA k
+        load_frags(0, smem);
+        int st1 = 1, st2 = 2;  // stages of tiles k+1, k+2
+        for (int kt = 0; kt < nk; kt += 2) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k = kt + h;
-            if (k < nk) {
-                if (k + 1 < nk) {
-                    publish();
-                    if (k + 2 < nk) issue(st2, k + 2);
-                    load_frags(h ^ 1, smem + st1 * STAGE);
+            for (int h = 0; h < 2; ++h) {
+                const int k = kt + h;
+                if (k < nk) {
+                    if (k + 1 < nk) {
+                        publish();
+                        if (k + 2 < nk) issue(st2, k + 2);
+                        load_frags(DBUF ? (h ^ 1) : 0, smem + st1 * STAGE);
+                    }
+                    mfmas(DBUF ? h : 0);
+                    st1 = st2;
+                    st2 = (st1 + 1) % 3;
                 }
-                mfmas(h);
-                st1 = st2;
-                st2 = (st1 + 1) % 3;
             }
         }
     }
 
+    // epilogue: recombine limb weights, one round + overflow into C, store runs of 4 rows (column-major tile)
     const QStep st = g.to_c;
     char* C = (char*)g.C;
     const int64_t tile_base = ((int64_t)tile_m * tiles_n + tile_n) * TM * TN;
+    using S = std::conditional_t<(NW == 1), int32_t, int64_t>;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
-        int32_t s[4 * TJ];
+        S s[4 * TJ];
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s[j * 4 + e] = acc[i][j][e];
-        qg_step_all<int32_t, 4 * TJ>(s, st);
+            for (int e = 0; e < 4; ++e) {
+                S x = (S)acc[NW - 1][i][j][e];
+#pragma unroll
+                for (int w = NW - 2; w >= 0; --w) x = x * 256 + (S)acc[w][i][j][e];
+                s[j * 4 + e] = x;
+            }
+        qg_step_all<S, 4 * TJ>(s, st);
         const int row0 = (wm * TI + i) * 16 + 4 * fq;
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const int col = (wn * TJ + j) * 16 + fr;
             const int64_t base = tile_base + (int64_t)col * TM + row0;
-            const int32_t* q = s + j * 4;
+            const S* q = s + j * 4;
             switch (g.cbytes) {
             case 1:
                 *(uint32_t*)(C + base) = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) | ((uint32_t)(q[3] & 0xff) << 24);
@@ -384,7 +406,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
                 *(uint2*)(C + base * 2) = make_uint2((uint32_t)(q[0] & 0xffff) | ((uint32_t)(q[1] & 0xffff) << 16), (uint32_t)(q[2] & 0xffff) | ((uint32_t)(q[3] & 0xffff) << 16));
                 break;
             case 4:
-                *(int4*)(C + base * 4) = make_int4(q[0], q[1], q[2], q[3]);
+                *(int4*)(C + base * 4) = make_int4((int)q[0], (int)q[1], (int)q[2], (int)q[3]);
                 break;
             default: {
                 int64_t* p = (int64_t*)(C + base * 8);
@@ -397,21 +419,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
     }
 }
 
-template <int WGM, int WGN, int TI, int TJ>
+template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF>
 hipError_t launch16(const QMfmaArgs& a, hipStream_t st)
 {
     constexpr int TM = WGM * TI * 16, TN = WGN * TJ * 16;
-    const int lds = 3 * (TM + TN) * 64;
+    const int lds = 3 * (LA * TM + LB * TN) * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mfma16<WGM, WGN, TI, TJ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int64_t blocks = (a.Mp / TM) * (a.Np / TN);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll || a.Kp % 64 || a.Mp % TM || a.Np % TN) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_mfma16<WGM, WGN, TI, TJ>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
+    hipLaunchKernelGGL((k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
     return hipGetLastError();
 }
 
@@ -486,8 +508,8 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
         // single limb: v_mfma_i32_16x16x64_i8 measured 8 % faster than 32x32x32 at the same tiles
         // (0.283 vs 0.308 ms at 8192x8192x4096, profiles/r01n_ablation_mfma_shape.log); QG_ABLATE=32 keeps the other
         if (ablation() == 32) return a.variant == 2 ? launch<1, 1, 64, 2, 4, 4, 2, 3>(a, st) : launch<1, 1, 64, 2, 2, 2, 2, 3>(a, st);
-        if (a.variant == 2) return launch16<2, 4, 8, 4>(a, st);
-        return launch16<2, 2, 4, 4>(a, st);
+        if (a.variant == 2) return launch16<1, 1, 2, 4, 8, 4, true>(a, st);
+        return launch16<1, 1, 2, 2, 4, 4, true>(a, st);
     }
     switch (LA * 10 + LB) {
     case 12: return launch<1, 2, 64, 2, 4, 2, 1, 3>(a, st);
