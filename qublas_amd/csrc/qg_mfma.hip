@@ -509,7 +509,7 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
         // (0.283 vs 0.308 ms at 8192x8192x4096, profiles/r01n_ablation_mfma_shape.log); QG_ABLATE=32 keeps the other
         if (ablation() == 32) return a.variant == 2 ? launch<1, 1, 64, 2, 4, 4, 2, 3>(a, st) : launch<1, 1, 64, 2, 2, 2, 2, 3>(a, st);
         if (a.variant == 2) return launch16<1, 1, 2, 4, 8, 4, true>(a, st);
-        return launch16<1, 1, 2, 2, 4, 4, true>(a, st);
+        return launch<1, 1, 64, 2, 2, 2, 2, 3>(a, st);  // 128x128 tiles (small problems): the 32x32x32 kernel is the faster one there
     }
     switch (LA * 10 + LB) {
     case 12: return launch<1, 2, 64, 2, 4, 2, 1, 3>(a, st);

@@ -71,8 +71,18 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
     const QTreeTable* __restrict__ tab = g.tab;
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
-    const int64_t tiles_n = (g.N + TNB - 1) / TNB;
-    const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * TMB, n0 = (int64_t)(blockIdx.x % tiles_n) * TNB;
+    // XCD-aware block order (blocks b and b+8 share an XCD and its L2): every XCD gets a contiguous run of
+    // tiles, walked column-major in groups of 16 tile rows, so neighbouring blocks re-use A rows and B columns in L2
+    const int64_t tiles_n = (g.N + TNB - 1) / TNB, tiles_m = (g.M + TMB - 1) / TMB;
+    int64_t bid = blockIdx.x;
+    {
+        const int64_t nwg = tiles_m * tiles_n, q = nwg / 8, r = nwg % 8, x = bid % 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+    }
+    constexpr int64_t GMT = 16;
+    const int64_t grp = bid / (GMT * tiles_n), first_m = grp * GMT;
+    const int64_t gsz = (tiles_m - first_m) < GMT ? (tiles_m - first_m) : GMT;
+    const int64_t m0 = (first_m + (bid % (GMT * tiles_n)) % gsz) * TMB, n0 = ((bid % (GMT * tiles_n)) / gsz) * TNB;
     const int nl = tab->n_levels;
     const bool tf = tab->cmul == QG_CMUL_TF;
 
