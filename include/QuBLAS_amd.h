@@ -123,36 +123,45 @@ constexpr Fmt merge_add(Fmt a, Fmt b, TagSet t)
                t.hasO ? t.O : (a.O == b.O ? a.O : int(QG_SAT_TCPL))};
 }
 
-// double -> raw with the format's own rounding and overflow (Qu_s(double), QuBLAS.h:2387-2393)
+// double -> raw with the format's own rounding and overflow (Qu_s(double), QuBLAS.h:2387-2393).
+// Exact: v = m * 2^e with a 53-bit integer m, so the raw value at F fraction bits is m * 2^(e+F) — a left
+// shift, or ONE rounding of the integer m by d = -(e+F) bits with the type's QuMode; then its OfMode.
+// (The reference loads the double into a 2400-bit buffer first; zero, NaN and infinity give 0, :670-674.)
 inline int64_t from_double(double v, Fmt f)
 {
     if (v == 0.0 || std::isnan(v) || std::isinf(v)) return 0;
-    const double t = std::ldexp(v, f.F);
-    const double h = std::floor(t);
-    const double fr = t - h;  // exact in binary floating point
-    double r = h;
-    switch (f.Q) {
-    case QG_RND_POS_INF: r = h + (fr >= 0.5); break;
-    case QG_RND_NEG_INF: r = h + (fr > 0.5); break;
-    case QG_RND_ZERO: r = h + (fr > 0.5 || (fr == 0.5 && v < 0)); break;
-    case QG_RND_INF: r = h + (fr > 0.5 || (fr == 0.5 && v > 0)); break;
-    case QG_RND_CONV: r = h + (fr > 0.5 || (fr == 0.5 && std::fmod(h, 2.0) != 0.0)); break;
-    case QG_TRN_SMGN: r = std::trunc(t); break;
-    default: break;
+    int ex = 0;
+    const double fr = std::frexp(v, &ex);                 // v = fr * 2^ex, 0.5 <= |fr| < 1
+    __int128 m = (__int128)std::ldexp(fr, 53);            // exact 53-bit signed integer
+    int e = ex - 53 + f.F;                                // v * 2^F = m * 2^e
+    __int128 r;
+    if (e >= 0) {
+        r = m * ((__int128)1 << (e > 60 ? 60 : e));       // far outside every supported format when clipped
+    } else {
+        int d = -e;
+        if (d > 120) { m = m < 0 ? -1 : 1; d = 8; }       // all mantissa bits below the rounding position
+        const __int128 h = m >> d, l = m & (((__int128)1 << d) - 1), t = (__int128)1 << (d - 1);
+        r = h;
+        switch (f.Q) {
+        case QG_RND_POS_INF: r = h + (l >= t); break;
+        case QG_RND_NEG_INF: r = h + (l > t); break;
+        case QG_RND_ZERO: r = h + (l > t || (l == t && m < 0)); break;
+        case QG_RND_INF: r = h + (l > t || (l == t && m > 0)); break;
+        case QG_RND_CONV: r = h + (l > t || (l == t && (h & 1))); break;
+        case QG_TRN_SMGN: r = m < 0 ? -((-m) >> d) : h; break;
+        default: break;  // TRN::TCPL
+        }
     }
     const int W = f.I + f.F;
-    const double hi = std::ldexp(1.0, W) - 1, lo = f.S ? -std::ldexp(1.0, W) : 0.0;
+    const __int128 hi = ((__int128)1 << W) - 1, lo = f.S ? -((__int128)1 << W) : 0;
     switch (f.O) {
     case QG_SAT_TCPL: r = r > hi ? hi : (r < lo ? lo : r); break;
-    case QG_SAT_ZERO: r = (r > hi || r < lo) ? 0.0 : r; break;
-    case QG_SAT_SMGN: { const double l2 = f.S ? -hi : 0.0; r = r > hi ? hi : (r < l2 ? l2 : r); break; }
-    default: {  // WRP::TCPL
-        const double m = std::ldexp(1.0, W + (f.S ? 1 : 0));
-        r = std::fmod(r, m);
-        if (r < 0) r += m;
-        if (f.S && r > hi) r -= m;
+    case QG_SAT_ZERO: r = (r > hi || r < lo) ? 0 : r; break;
+    case QG_SAT_SMGN: { const __int128 l2 = f.S ? -hi : 0; r = r > hi ? hi : (r < l2 ? l2 : r); break; }
+    default:  // WRP::TCPL
+        if (f.S) { const __int128 mask = ((__int128)1 << (W + 1)) - 1, w = r & mask; r = (w >> W) ? (w | ~mask) : w; }
+        else r &= hi;
         break;
-    }
     }
     return int64_t(r);
 }

@@ -212,6 +212,10 @@ enum { QG_OPERAND_A = 0, QG_OPERAND_B = 1, QG_OPERAND_C = 2 };
 /* reference-layout (device-resident copy) -> packed.  `src_dev` is a device pointer to the same
  * bytes the host tensor holds; ld in elements (0 = tight). */
 int qgemul_pack(qgemul_plan* p, int operand, const void* src_dev, int64_t ld, void* packed_dev);
+/* quantise-on-load: `src_dev` is a device pointer to a column-major tensor of doubles with the
+ * operand's declared shape (complex: {re, im} pairs); every value is converted exactly as Qu_s(double) does
+ * (QuBLAS.h:2387-2393: the element type's own QuMode, then its OfMode) and packed in one pass. */
+int qgemul_pack_f64(qgemul_plan* p, int operand, const double* src_dev, int64_t ld, void* packed_dev);
 /* packed C -> reference layout (device-resident), ready for one D2H copy */
 int qgemul_unpack_c(qgemul_plan* p, const void* packed_dev, void* dst_dev, int64_t ld);
 /* the hot path: packed A, packed B -> packed C, asynchronous on the ctx stream */

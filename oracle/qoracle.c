@@ -315,6 +315,40 @@ int qoracle_gemm(const qgemul_desc* d, void* C, const void* A, const void* B, in
     return st;
 }
 
+/*
+ * Qu_s(double), QuBLAS.h:2387-2393: the double is loaded EXACTLY into a 2400-bit buffer with 1200+F fraction
+ * bits (loadFromDouble, :663-749: 0 for zero / NaN / infinity), then fracConvert<1200+F -> F> with the type's
+ * QuMode and intConvert with its OfMode.  Restated on a 53-bit mantissa: v = m * 2^e exactly, so the raw
+ * value at F fraction bits is m * 2^(e+F): an exact left shift, or one rounding by d = -(e+F) bits.
+ */
+int64_t qoracle_from_double(double v, qfmt f)
+{
+    if (v == 0.0 || v != v || v - v != 0.0) return 0;
+    uint64_t bits;
+    memcpy(&bits, &v, 8);
+    const int neg = (int)(bits >> 63);
+    int ex = (int)((bits >> 52) & 0x7ff);
+    qi m = (qi)(bits & 0xfffffffffffffull);
+    if (ex == 0) ex = 1;                 /* subnormal: no implicit one */
+    else m |= (qi)1 << 52;
+    int e = ex - 1075 + (int)f.F;        /* value * 2^F = m * 2^e */
+    if (neg) m = -m;
+    qi r;
+    if (e >= 0) {
+        if (e > 60) e = 60;              /* |m| >= 1: far outside every supported format either way */
+        r = qo_shl(m, e);
+    } else {
+        int d = -e;
+        if (d > 120) {                   /* every mantissa bit is below the rounding position */
+            qi tiny = neg ? -1 : 1;      /* same rounding class as any 0 < |x| < 1/2 ulp */
+            r = qo_round(tiny, 8, f.Q);
+        } else {
+            r = qo_round(m, d, f.Q);
+        }
+    }
+    return (int64_t)qo_overflow(r, f);
+}
+
 /* ---- scalar entry points for the known-answer tests (values as int64 raw integers) ---- */
 int64_t qoracle_convert(int64_t x, qfmt from, qfmt to) { return (int64_t)qo_cvt(x, from, to); }
 /* source wider than 64 bits (the reference tests' 141-bit High_t): value = hi*2^64 + lo */

@@ -56,6 +56,8 @@ def lib() -> C.CDLL:
         L.qoracle_reduce.argtypes = [C.POINTER(C.c_int64), C.c_int64, qfmt, C.POINTER(qfmt), C.c_int]
         L.qoracle_convert128.restype = C.c_int64
         L.qoracle_convert128.argtypes = [C.c_int64, C.c_uint64, qfmt, qfmt]
+        L.qoracle_from_double.restype = C.c_int64
+        L.qoracle_from_double.argtypes = [C.c_double, qfmt]
         L.qoracle_synth.restype = C.c_int64
         L.qoracle_synth.argtypes = [qfmt, C.c_uint64, C.c_int, C.c_uint64, C.c_int]
         L.qoracle_fill.restype = None

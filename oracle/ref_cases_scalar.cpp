@@ -121,6 +121,48 @@ static void reduce_table(FILE* out, const char* name)
     std::fprintf(out, "]}\n");
 }
 
+// Qu_s(double): loadFromDouble into a 2400-bit buffer, then the type's own fracConvert / intConvert
+// (QuBLAS.h:2387-2393, :663-749).  Doubles are printed as hex-float so the table is exact.
+template <class T>
+static void from_double_table(FILE* out)
+{
+    static const double vals[] = {0.0, 1.0, -1.0, 1.25, -1.25, 1.5, -1.5, 1.75, -1.75, 0.5, -0.5, 0.125, -0.125, 0.0625, -0.0625, 0.1875,
+                                  -0.1875, 0.3125, -0.3125, 3.999, -3.999, 7.5, -7.5, 7.75, -8.0, -8.25, 15.999, 16.0, -16.0, 20.0, -20.0,
+                                  63.5, 64.0, -64.0, -64.5, 100.0, -100.0, 255.0, 256.0, 1e6, -1e6, 1e-9, -1e-9, 0.1, -0.1, 0.3, -0.3, 2.71828182845904,
+                                  -3.14159265358979, 0.4999999999999999, -0.5000000000000001, 12345.6789, -54321.125, 1.0000000000000002,
+                                  5.0e-324, -5.0e-324, 1.7e308, -1.7e308, 0.9999999999999999, 127.99609375, -128.00390625};
+    std::fprintf(out, "{\"kind\":\"from_double\",\"to\":%s,\"x\":[", fmt_json<T>().c_str());
+    bool first = true;
+    for (double v : vals) { std::fprintf(out, "%s\"%a\"", first ? "" : ",", v); first = false; }
+    std::fprintf(out, "],\"y\":[");
+    first = true;
+    for (double v : vals) { T t = v; std::fprintf(out, "%s%lld", first ? "" : ",", (long long)t.data.data); first = false; }
+    std::fprintf(out, "]}\n");
+}
+
+template <class Q, class O>
+static void from_double_targets(FILE* out)
+{
+    from_double_table<Qu<intBits<3>, fracBits<2>, isSigned<true>, QuMode<Q>, OfMode<O>>>(out);
+    from_double_table<Qu<intBits<3>, fracBits<2>, isSigned<false>, QuMode<Q>, OfMode<O>>>(out);
+    from_double_table<Qu<intBits<8>, fracBits<8>, isSigned<true>, QuMode<Q>, OfMode<O>>>(out);
+    from_double_table<Qu<intBits<6>, fracBits<-3>, isSigned<true>, QuMode<Q>, OfMode<O>>>(out);
+    from_double_table<Qu<intBits<4>, fracBits<3>, isSigned<true>, QuMode<Q>, OfMode<O>>>(out);
+    from_double_table<Qu<intBits<20>, fracBits<30>, isSigned<true>, QuMode<Q>, OfMode<O>>>(out);
+}
+
+template <class O>
+static void from_double_modes(FILE* out)
+{
+    from_double_targets<RND::POS_INF, O>(out);
+    from_double_targets<RND::NEG_INF, O>(out);
+    from_double_targets<RND::ZERO, O>(out);
+    from_double_targets<RND::INF, O>(out);
+    from_double_targets<RND::CONV, O>(out);
+    from_double_targets<TRN::TCPL, O>(out);
+    from_double_targets<TRN::SMGN, O>(out);
+}
+
 int main(int argc, char** argv)
 {
     int part = argc > 1 ? std::atoi(argv[1]) : 0;
@@ -198,6 +240,12 @@ int main(int argc, char** argv)
         reduce_table<e, 1000>(out, "len1000_default");
         break;
     }
+    case 5:
+        from_double_modes<SAT::TCPL>(out);
+        from_double_modes<SAT::ZERO>(out);
+        from_double_modes<SAT::SMGN>(out);
+        from_double_modes<WRP::TCPL>(out);
+        break;
     default:
         return 2;
     }

@@ -28,7 +28,7 @@ EXPORTS = [
     "qgemul_ctx_create", "qgemul_ctx_destroy", "qgemul_ctx_sync", "qgemul_ctx_stream",
     "qgemul_plan_create", "qgemul_plan_destroy", "qgemul_plan_info",
     "qgemul_dev_alloc", "qgemul_dev_free", "qgemul_memcpy_h2d", "qgemul_memcpy_d2h",
-    "qgemul_pack", "qgemul_unpack_c", "qgemul_execute", "qgemul_fill_packed", "qgemul_time_execute",
+    "qgemul_pack", "qgemul_pack_f64", "qgemul_unpack_c", "qgemul_execute", "qgemul_fill_packed", "qgemul_time_execute",
 ]
 
 _lib = None
@@ -73,6 +73,7 @@ def lib() -> C.CDLL:
         L.qgemul_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
         L.qgemul_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
         L.qgemul_pack.argtypes = [vp, C.c_int, vp, i64, vp]
+        L.qgemul_pack_f64.argtypes = [vp, C.c_int, vp, i64, vp]
         L.qgemul_unpack_c.argtypes = [vp, vp, vp, i64]
         L.qgemul_execute.argtypes = [vp, vp, vp, vp]
         L.qgemul_fill_packed.argtypes = [vp, C.c_int, u64, C.c_int, vp]
@@ -165,6 +166,9 @@ class Plan:
 
     def pack(self, operand: int, src_dev: int, packed_dev: int, ld: int = 0):
         _chk(lib().qgemul_pack(self.h, operand, C.c_void_p(src_dev), ld, C.c_void_p(packed_dev)), "qgemul_pack")
+
+    def pack_f64(self, operand: int, src_dev: int, packed_dev: int, ld: int = 0):
+        _chk(lib().qgemul_pack_f64(self.h, operand, C.c_void_p(src_dev), ld, C.c_void_p(packed_dev)), "qgemul_pack_f64")
 
     def fill(self, operand: int, seed: int, dist: int, packed_dev: int):
         _chk(lib().qgemul_fill_packed(self.h, operand, seed, dist, C.c_void_p(packed_dev)), "qgemul_fill_packed")

@@ -324,6 +324,9 @@ static QOperandGeom operand_geom(const qgemul_plan* p, int operand, int64_t ld)
         g.sb[q] = h.sb[q];
         g.W[q] = (int)f[q].I + (int)f[q].F;
         g.S[q] = f[q].S;
+        g.F[q] = f[q].F;
+        g.Q[q] = f[q].Q;
+        g.O[q] = f[q].O;
     }
     if (operand == QG_OPERAND_A) {
         g.rows = d.M;
@@ -351,6 +354,15 @@ int qgemul_pack(qgemul_plan* p, int operand, const void* src_dev, int64_t ld, vo
         QG_HIP(hipStreamSynchronize(p->ctx->stream));
         if (flag) return QG_ERANGE;
     }
+    return QG_OK;
+}
+
+int qgemul_pack_f64(qgemul_plan* p, int operand, const double* src_dev, int64_t ld, void* packed_dev)
+{
+    if (!p || !src_dev || !packed_dev || (operand != QG_OPERAND_A && operand != QG_OPERAND_B)) return QG_EINVAL;
+    QOperandGeom g = operand_geom(p, operand, ld);
+    const QPackedGeom& pg = operand == QG_OPERAND_A ? p->pa : p->pb;
+    QG_HIP(qg_launch_pack_f64(g, pg, src_dev, packed_dev, p->ctx->stream));
     return QG_OK;
 }
 

@@ -13,6 +13,7 @@ struct QOperandGeom {
     int32_t off[2], sb[2];  // byte offset / byte width (4|8) of each part inside the element
     int32_t parts;          // 1 real, 2 complex
     int32_t W[2], S[2];     // format of each part (range check, synthetic fill)
+    int32_t F[2], Q[2], O[2]; // quantise-on-load: fracBits, QuMode, OfMode of each part
 };
 
 // packed (device-private) layouts
@@ -41,6 +42,9 @@ struct QCGeom {
 
 hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const void* src, void* dst, int check_range,
                           int* range_flag, hipStream_t st);
+// the same with a column-major tensor of DOUBLES as source (complex: {re, im} pairs), quantised on load with each
+// part's own QuMode / OfMode exactly as Qu_s(double) does (QuBLAS.h:2387-2393)
+hipError_t qg_launch_pack_f64(const QOperandGeom& g, const QPackedGeom& p, const void* src, void* dst, hipStream_t st);
 hipError_t qg_launch_fill(const QOperandGeom& g, const QPackedGeom& p, uint64_t seed, int dist, void* dst, hipStream_t st);
 hipError_t qg_launch_unpack_c(const QCGeom& c, const void* packed, void* dst, hipStream_t st);
 

@@ -37,6 +37,34 @@ __device__ __forceinline__ int64_t load_container(const char* src, int64_t idx, 
     }
 }
 
+// Qu_s(double) on the device: v = m * 2^e exactly (53-bit m), raw = m * 2^(e+F): a left shift or ONE rounding of m
+// with the format's QuMode, then its OfMode.  Zero, NaN and infinity give 0 (loadFromDouble, QuBLAS.h:670-674).
+__device__ __forceinline__ int64_t quantize_f64(double v, int W, int S, int F, int Q, int O)
+{
+    if (v == 0.0 || v != v || (v - v) != 0.0) return 0;
+    const uint64_t bits = (uint64_t)__double_as_longlong(v);
+    const bool neg = (bits >> 63) != 0;
+    int ex = (int)((bits >> 52) & 0x7ff);
+    int64_t m = (int64_t)(bits & 0xfffffffffffffull);
+    if (ex == 0) ex = 1; else m |= (int64_t)1 << 52;
+    const int e = ex - 1075 + F;
+    if (neg) m = -m;
+    const int64_t hi = ((int64_t)1 << W) - 1, lo = S ? -((int64_t)1 << W) : 0;
+    if (e >= 0) {
+        if (e <= 9) return qg_overflow<int64_t>(m << e, O, W, S, lo, hi);
+        // |value| >= 2^62 exceeds every supported format: saturate by sign, or wrap the (exact) low bits
+        switch (O) {
+        case QG_SAT_TCPL: return neg ? lo : hi;
+        case QG_SAT_ZERO: return 0;
+        case QG_SAT_SMGN: return neg ? (S ? -hi : 0) : hi;
+        default: return qg_overflow<int64_t>(e < 64 ? (int64_t)((uint64_t)m << e) : 0, O, W, S, lo, hi);
+        }
+    }
+    int d = -e;
+    if (d > 62) { m = neg ? -1 : 1; d = 8; }  // every mantissa bit lies below the rounding position
+    return qg_overflow<int64_t>(qg_round<int64_t>(m, d, Q), O, W, S, lo, hi);
+}
+
 // write one logical value (r,k,part) into the packed operand
 __device__ __forceinline__ void put_packed(const QPackedGeom& p, char* dst, int part, int64_t r, int64_t k, int64_t v)  // r, k: indices inside the part
 {
@@ -83,7 +111,10 @@ __global__ __launch_bounds__(256) void k_pack(QOperandGeom g, QPackedGeom p, con
         int64_t k = tk * 64 + (r_fast ? i : tx);
         int64_t v = 0;
         if (r < g.rows && k < g.K) {
-            if (fill) {
+            if (fill == 2) {
+                const double* ds = (const double*)src + (r * g.rs + k * g.ks) * g.parts + part;
+                v = quantize_f64(*ds, W, S, g.F[part], g.Q[part], g.O[part]);
+            } else if (fill) {
                 // tight host linear index of the element, as a host-side fill of the tensor would see it
                 v = qg_synth(W, S, seed, dist, (uint64_t)(r * g.rs + k * g.ks), part);
             } else {
@@ -171,6 +202,15 @@ hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const voi
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)blocks), dim3(256), 0, st, g, p, (const char*)src, (char*)dst, check_range,
                        range_flag, 0, 0ull, 0);
+    return hipGetLastError();
+}
+
+hipError_t qg_launch_pack_f64(const QOperandGeom& g, const QPackedGeom& p, const void* src, void* dst, hipStream_t st)
+{
+    int64_t blocks = ((p.K_p + 63) / 64) * ((p.rows_p + 63) / 64) * g.parts;
+    if (blocks <= 0) return hipSuccess;
+    if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)blocks), dim3(256), 0, st, g, p, (const char*)src, (char*)dst, 0, (int*)nullptr, 2, 0ull, 0);
     return hipGetLastError();
 }
 

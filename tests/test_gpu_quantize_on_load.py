@@ -1,0 +1,111 @@
+"""Quantise-on-load: double matrices handed to the engine are converted on the device exactly as
+Qu_s(double) does (QuBLAS.h:2387-2393) and packed in the same pass.  Checked against the oracle's from_double, which is
+pinned by the reference's own construction tables (tests/test_from_double.py).  -m gpu."""
+import numpy as np
+import pytest
+
+from qublas_amd import capi
+from qublas_amd.desc import Qcomplex, Qu, RND, SAT, TRN, WRP, Tags, TFComplexMul, lower
+
+pytestmark = pytest.mark.gpu
+
+
+def quantize(oracle, e: Qu, x: np.ndarray) -> np.ndarray:
+    L = oracle.lib()
+    return np.array([L.qoracle_from_double(float(v), e.c()) for v in x], dtype=np.int64)
+
+
+def awkward_doubles(rng, n, scale):
+    x = rng.standard_normal(n) * scale
+    x[rng.integers(0, n, n // 8)] = np.round(x[rng.integers(0, n, n // 8)] * 8) / 8 + 0.0625   # exact ties
+    x[rng.integers(0, n, 16)] = [0.0, -0.0, 1e-320, -1e-320, 1e300, -1e300, np.inf, -np.inf, np.nan, 0.5, -0.5, 1.5, -1.5, 2.5, -2.5, 1e-9]
+    return x
+
+
+@pytest.mark.parametrize("ea,eb", [
+    (Qu(4, 3), Qu(4, 3)),
+    (Qu(8, 8, True, RND.CONV, SAT.ZERO), Qu(6, 2, False, RND.POS_INF, SAT.SMGN)),
+    (Qu(6, -3, True, TRN.SMGN, WRP.TCPL), Qu(3, 5, True, RND.INF, SAT.TCPL)),
+    (Qu(5, 4, True, RND.ZERO, WRP.TCPL), Qu(5, 4, True, RND.NEG_INF, SAT.ZERO)),
+])
+@pytest.mark.parametrize("ta", [False, True])
+def test_pack_f64_then_gemm(oracle, ea, eb, ta):
+    rng = np.random.default_rng(7)
+    M, N, K = 70, 45, 96
+    Ad = awkward_doubles(rng, M * K, 6.0)
+    Bd = awkward_doubles(rng, K * N, 6.0)
+    ec = Qu(20, 6)
+    d = lower(ea, eb, ec, M, N, K, transposed_a=ta)
+    Ai = quantize(oracle, ea, Ad).astype(oracle.host_dtype(ea))
+    Bi = quantize(oracle, eb, Bd).astype(oracle.host_dtype(eb))
+    exp = oracle.gemm(d, Ai, Bi, ec)
+    with capi.Context() as ctx:
+        plan = capi.Plan(ctx, d)
+        pb = plan.info.packed_bytes
+        pA, pB, pC = ctx.alloc(pb[0]), ctx.alloc(pb[1]), ctx.alloc(pb[2])
+        dA, dB, dC = ctx.alloc(Ad.nbytes), ctx.alloc(Bd.nbytes), ctx.alloc(M * N * 4)
+        ctx.h2d(dA, Ad)
+        ctx.h2d(dB, Bd)
+        plan.pack_f64(capi.OPERAND_A, dA, pA)
+        plan.pack_f64(capi.OPERAND_B, dB, pB)
+        plan.execute(pC, pA, pB)
+        plan.unpack_c(pC, dC)
+        got = np.zeros(M * N, np.int32)
+        ctx.d2h(got, dC)
+        for p in (pA, pB, pC, dA, dB, dC):
+            ctx.free(p)
+        plan.close()
+    assert np.array_equal(got, exp)
+
+
+def test_pack_f64_complex_and_limbs(oracle):
+    rng = np.random.default_rng(11)
+    r, i = Qu(6, 3, True, RND.POS_INF, SAT.TCPL), Qu(6, -3, True, RND.POS_INF, SAT.TCPL)
+    c5 = Qcomplex(r, i)
+    wide = Qcomplex(Qu(18, 6), Qu(18, 6))
+    M, N, K = 40, 33, 64
+    Ad = awkward_doubles(rng, 2 * M * K, 20.0)   # {re, im} pairs
+    Bd = awkward_doubles(rng, 2 * K * N, 20.0)
+    d = lower(c5, c5, wide, M, N, K, mul_args=TFComplexMul())
+    A = np.zeros(M * K, dtype=oracle.host_dtype(c5))
+    B = np.zeros(K * N, dtype=oracle.host_dtype(c5))
+    A["re"], A["im"] = quantize(oracle, r, Ad[0::2]), quantize(oracle, i, Ad[1::2])
+    B["re"], B["im"] = quantize(oracle, r, Bd[0::2]), quantize(oracle, i, Bd[1::2])
+    exp = oracle.gemm(d, A, B, wide)
+    with capi.Context() as ctx:
+        plan = capi.Plan(ctx, d)
+        pb = plan.info.packed_bytes
+        pA, pB, pC = ctx.alloc(pb[0]), ctx.alloc(pb[1]), ctx.alloc(pb[2])
+        dA, dB, dC = ctx.alloc(Ad.nbytes), ctx.alloc(Bd.nbytes), ctx.alloc(exp.nbytes)
+        ctx.h2d(dA, Ad); ctx.h2d(dB, Bd)
+        plan.pack_f64(capi.OPERAND_A, dA, pA)
+        plan.pack_f64(capi.OPERAND_B, dB, pB)
+        plan.execute(pC, pA, pB)
+        plan.unpack_c(pC, dC)
+        got = np.zeros(M * N, dtype=exp.dtype)
+        ctx.d2h(got, dC)
+        plan.close()
+    assert np.array_equal(got["re"], exp["re"]) and np.array_equal(got["im"], exp["im"])
+    # linear class: int<8,8> doubles -> 3 int8 limbs straight from the doubles
+    e = Qu(8, 8)
+    ec = Qu(23, 8)
+    M, N, K = 128, 128, 128
+    Ad = awkward_doubles(rng, M * K, 60.0)
+    Bd = awkward_doubles(rng, K * N, 60.0)
+    d = lower(e, e, ec, M, N, K, mul_args=Tags(17, 16), add_args=[Qu(27, 16)])
+    exp = oracle.gemm(d, quantize(oracle, e, Ad).astype(np.int32), quantize(oracle, e, Bd).astype(np.int32), ec)
+    with capi.Context() as ctx:
+        plan = capi.Plan(ctx, d)
+        assert capi.KERNEL_NAMES[plan.info.kernel] == "mfma_i8_limb"
+        pb = plan.info.packed_bytes
+        pA, pB, pC = ctx.alloc(pb[0]), ctx.alloc(pb[1]), ctx.alloc(pb[2])
+        dA, dB, dC = ctx.alloc(Ad.nbytes), ctx.alloc(Bd.nbytes), ctx.alloc(M * N * 4)
+        ctx.h2d(dA, Ad); ctx.h2d(dB, Bd)
+        plan.pack_f64(capi.OPERAND_A, dA, pA)
+        plan.pack_f64(capi.OPERAND_B, dB, pB)
+        plan.execute(pC, pA, pB)
+        plan.unpack_c(pC, dC)
+        got = np.zeros(M * N, np.int32)
+        ctx.d2h(got, dC)
+        plan.close()
+    assert np.array_equal(got, exp)
