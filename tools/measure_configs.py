@@ -57,13 +57,13 @@ def main():
     # the drop-in call with HOST buffers (qgemul_run): H2D + pack + GEMM + unpack + D2H + alloc/free, wall time
     import time
     import numpy as np
-    from oracle import qoracle
     for name, ea, ec, kw, S in (("c3 linear, host buffers through qgemul_run", E88Z, Qu(23, 8), dict(mul_args=Tags(17, 16), add_args=[Qu(29, 16)]), 4096),
                                 ("c2 linear 1024^3, host buffers through qgemul_run", E43, E43, dict(mul_args=Tags(9, 6), add_args=[Qu(19, 6)]), 1024)):
         d = lower(ea, ea, ec, S, S, S, **kw)
-        A = qoracle.fill(ea, S * S, 1)
-        B = qoracle.fill(ea, S * S, 2)
-        Cc = np.zeros(S * S, dtype=qoracle.host_dtype(ec))
+        rng = np.random.default_rng(1)
+        A = rng.integers(ea.raw_min, ea.raw_max + 1, S * S, dtype=np.int32)
+        B = rng.integers(ea.raw_min, ea.raw_max + 1, S * S, dtype=np.int32)
+        Cc = np.zeros(S * S, dtype=np.int32)
         capi.run(d, Cc, A, B)
         t0 = time.perf_counter()
         n = 5
