@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--workload", default="c3L", choices=["c3L", "c3T", "c2L"])
     ap.add_argument("--size", type=int, default=4096, help="M=N=K per GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the script on a 1-GPU box)")
+    ap.add_argument("--force-dist", action="store_true", help="exercise the collective path even with one rank (rehearsal of the RCCL calls on a 1-GPU box)")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -130,8 +131,12 @@ def main():
     ndev = torch.cuda.device_count()
     local = local % max(1, ndev)   # one rank per GPU on the driver's node; a rehearsal may stack ranks on one card
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -149,24 +154,24 @@ def main():
     tA = torch.empty(pb[0], dtype=torch.uint8, device=dev)
     tB = torch.empty(pb[1], dtype=torch.uint8, device=dev)
     # two C buffers: the gather of step i overlaps the GEMM of step i+1
-    tCs = [torch.empty(pb[2], dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
+    tCs = [torch.empty(pb[2], dtype=torch.uint8, device=dev) for _ in range(2 if use_dist else 1)]
     tC = tCs[0]
     # rank r's shard of A: rows [r*M, (r+1)*M) of the (world*M) x K operand -> distinct seed stream
     plan.fill(capi.OPERAND_A, 1 + 1000 * rank, 0, tA.data_ptr())
     plan.fill(capi.OPERAND_B, 2, 0, tB.data_ptr())
     ctx.sync()
     gather_lists = [None, None]
-    on_host = world > 1 and args.backend != "nccl"
-    if world > 1 and rank == 0:
+    on_host = use_dist and args.backend != "nccl"
+    if use_dist and rank == 0:
         gather_lists = [[torch.empty(pb[2], dtype=torch.uint8, device="cpu" if on_host else dev) for _ in range(world)]
                         for _ in range(2)]
     pending = [None, None]
     state = {"i": 0}
 
     def step():
-        b = (state["i"] & 1) if world > 1 else 0
+        b = (state["i"] & 1) if use_dist else 0
         state["i"] += 1
-        if world > 1 and pending[b] is not None:
+        if use_dist and pending[b] is not None:
             pending[b].wait()          # buffer b was handed to the collective two steps ago
             if not on_host:
                 # with RCCL wait() only orders torch's current stream; the engine launches on its own
@@ -174,7 +179,7 @@ def main():
                 torch.cuda.current_stream().synchronize()
             pending[b] = None
         plan.execute(tCs[b].data_ptr(), tA.data_ptr(), tB.data_ptr())
-        if world > 1:
+        if use_dist:
             ctx.sync()                 # the engine launches on its own stream; the collective runs on torch's
             src = tCs[b].cpu() if on_host else tCs[b]
             pending[b] = dist.gather(src, gather_lists[b], dst=0, async_op=True)   # the ONE collective of the path
@@ -184,7 +189,7 @@ def main():
             if pending[b] is not None:
                 pending[b].wait()
                 pending[b] = None
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -196,7 +201,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -226,7 +231,7 @@ def main():
                           "sharding": f"rows of A/C over {world} rank(s), B replicated, one RCCL gather of C to rank 0" if world > 1 else "single GPU"},
                "pct_of_int8_peak": 100.0 * value / (INT8_DENSE_PEAK_OPS * world),
                "roofline": roof}
-        if world > 1:
+        if use_dist:
             # the curve with and without the gather
             out["value_without_gather"] = achieved * world
             out["gather_bytes_per_step_per_rank"] = int(pb[2])
@@ -286,7 +291,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "int-op/s (2*M*N*K/s)", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     plan.close()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
