@@ -193,6 +193,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # setup, untimed: bring the card to its steady clock before the W warm-up steps (the first few hundred ms of
+    # MFMA work after an idle period run on a ramping clock: 0.478 vs 0.450 ms per launch, tools/launch_gap.py)
+    PREWARM = 300
+    for _ in range(PREWARM):
+        plan.execute(tCs[0].data_ptr(), tA.data_ptr(), tB.data_ptr())
+    ctx.sync()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -229,6 +235,7 @@ def main():
                "dtype": "i8 limbs -> i32/i64" if bound == "mfma" else "i64", "data": "synthetic",
                "config": {"workload": wl["text"], "M_per_gpu": M, "N": N, "K": K, "class": "linear" if info.cls == 1 else "tree",
                           "sharding": f"rows of A/C over {world} rank(s), B replicated, one RCCL gather of C to rank 0" if world > 1 else "single GPU"},
+               "prewarm_launches": PREWARM,
                "pct_of_int8_peak": 100.0 * value / (INT8_DENSE_PEAK_OPS * world),
                "roofline": roof}
         if use_dist:
