@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--size", type=int, default=4096, help="M=N=K per GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the script on a 1-GPU box)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the collective path even with one rank (rehearsal of the RCCL calls on a 1-GPU box)")
+    ap.add_argument("--prewarm", type=int, default=300, help="untimed launches before the warm-up steps (lets the GPU clock settle); 0 for counter passes")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -195,7 +196,7 @@ def main():
 
     # setup, untimed: bring the card to its steady clock before the W warm-up steps (the first few hundred ms of
     # MFMA work after an idle period run on a ramping clock: 0.478 vs 0.450 ms per launch, tools/launch_gap.py)
-    PREWARM = 300
+    PREWARM = max(0, args.prewarm) if args.workload != "c3T" else min(max(0, args.prewarm), 20)
     for _ in range(PREWARM):
         plan.execute(tCs[0].data_ptr(), tA.data_ptr(), tB.data_ptr())
     ctx.sync()

@@ -24,7 +24,7 @@ for WL in $WLS; do
   for PMC in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT" "GRBM_GUI_ACTIVE"; do
     N=$(echo $PMC | tr ' ' '_' | cut -c1-24)
     echo "== rocprofv3 pmc $WL $N" | tee -a $OUT/progress.log
-    (cd /tmp && timeout -k 10 600 rocprofv3 --pmc $PMC -d $OUT/prof_${WL}_pmc_$N --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 3 --warmup 1 --no-extra --no-cpu > $OUT/prof_${WL}_pmc_$N.log 2>&1); echo "pmc rc=$?" | tee -a $OUT/progress.log
+    (cd /tmp && timeout -k 10 600 rocprofv3 --pmc $PMC -d $OUT/prof_${WL}_pmc_$N --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 3 --warmup 1 --prewarm 0 --no-extra --no-cpu > $OUT/prof_${WL}_pmc_$N.log 2>&1); echo "pmc rc=$?" | tee -a $OUT/progress.log
   done
 done
 # keep the merged-back payload small: drop rocprof's per-process databases, keep csv
