@@ -131,7 +131,13 @@ enum {
     QG_OPT_FORCE_TREE = 1u,   /* run the exact tree kernel even when the linear class is provable */
     QG_OPT_CHECK_RANGE = 2u,  /* validate that A and B raw values lie inside their formats */
     QG_OPT_GENERIC_TREE = 4u, /* tree class: use the any-descriptor 64-bit kernel, not the 32-bit fast path */
-    QG_OPT_RUNTIME_MODES = 8u /* 32-bit tree kernel: use the runtime-mode variant even when a fixed-mode one applies */
+    QG_OPT_RUNTIME_MODES = 8u, /* 32-bit tree kernel: use the runtime-mode variant even when a fixed-mode one applies */
+    /* element-wise epilogue placement.  Default: inside the 3x3-limb MFMA kernel's epilogue when the planner has bounded
+     * the chain by 32-bit arithmetic (measured 0.473 vs 0.490 ms at 4096^3), otherwise ONE linear pass over the stored C
+     * (HBM-bound, 5-6 TB/s).  The single-limb kernels also have a fused variant but it is slower than the pass (one
+     * workgroup per CU: the matrix cores idle during the longer epilogue), so it is opt-in. */
+    QG_OPT_FUSED_EPILOGUE = 16u,  /* fuse wherever a fused variant exists (32-bit chains on the single-limb kernels too) */
+    QG_OPT_UNFUSED_EPILOGUE = 32u /* never fuse: always the pass after the kernel */
 };
 
 /* status codes */
@@ -228,6 +234,65 @@ int qgemul_fill_packed(qgemul_plan* p, int operand, uint64_t seed, int dist, voi
  * returns average milliseconds per launch */
 int qgemul_time_execute(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB,
                         int warmup, int iters, float* avg_ms);
+
+/* ---- fused element-wise epilogue ----
+ * The reference's lazy tensor operators (Qmul/Qadd/Qsub on tensors, QuBLAS.h:3780-3877, front-ends
+ * :4079-4100) evaluate  Qop<tags...>(x[i], e[i])  per element on operator[] (:3795-3798, :3828-3831,
+ * :3861-3864; a scalar operand is used as is, autoCall :3767-3778), and a tensor constructed from such an
+ * expression converts every element into its own element type (:2732-2746, converting constructor
+ * :2398-2411).  So after  Qgemul<...>(C, A, B)  the statement
+ *        Qu<dim<M,N>, DT> D = Qadd<t2...>(Qmul<t1...>(C, s), Bias);
+ * The tensor front-ends take Qu tensors only (:4080-4100), not expressions, so a chain materialises a tensor per
+ * operator; after  Qgemul<...>(C, A, B)  the statements
+ *        Qu<dim<M,N>, T1> t = Qmul<t1...>(C, s);      Qu<dim<M,N>, DT> D = Qadd<t2...>(t, Bias);
+ * are, per element,  D[i] = cvt_DT( Qadd<t2>( cvt_T1( Qmul<t1>(C[i], s) ), Bias[i] ) ).  The epilogue below runs that
+ * chain inside the GEMM kernel's own epilogue, on the value the kernel has just converted into C's element type, so
+ * neither C nor the intermediate tensors go to memory.  Real GEMMs only.
+ *   x_0 = C[i,j] (format desc.c[0]);   y_k = Qop_k(x_k, e_k) or Qop_k(e_k, x_k), format stage[k].r;
+ *   x_{k+1} = cvt_{stage[k].t}(y_k) for k < n-1;   D[i,j] = cvt_d(y_{n-1})   (cvt = the identity when source and
+ *   target agree in all five fields).  n = 0:  D = C converted element by element (:2766-2777). */
+#define QG_MAX_EW 4
+enum { QG_EW_ADD = 1, QG_EW_SUB = 2, QG_EW_MUL = 3 };
+typedef struct qgemul_ew_stage {
+    uint8_t op;        /* QG_EW_* */
+    uint8_t x_first;   /* 1: Qop(x, e)   0: Qop(e, x)  — the order matters for QG_EW_SUB */
+    uint8_t e_scalar;  /* 1: e is a scalar (isScalar operand)   0: a tensor of dim<M,N> */
+    uint8_t reserved;
+    qfmt e;            /* element format of the operand */
+    qfmt r;            /* resolved result format of this Qop<tags...> (MulMerger :3107-3120 / AddMerger :3126-3139) */
+    qfmt t;            /* element type of the tensor this stage's result is assigned to (ignored for the last stage: d) */
+} qgemul_ew_stage;
+typedef struct qgemul_epilogue {
+    uint32_t n_stages; /* 0 .. QG_MAX_EW (0: D is C converted into d) */
+    uint32_t reserved;
+    qgemul_ew_stage stage[QG_MAX_EW];
+    qfmt d;            /* element format of the destination tensor */
+} qgemul_epilogue;
+/* run-time operands of the stages: packed tensors (qgemul_pack_e) or one raw scalar value each */
+typedef struct qgemul_ep_args {
+    const void* e_packed[QG_MAX_EW];
+    int64_t e_scalar[QG_MAX_EW];
+} qgemul_ep_args;
+
+/* classify / plan with an epilogue: info.host_elem_bytes[2] and info.packed_bytes[2] then describe D, and
+ * qgemul_unpack_c unpacks D.  ep == NULL is qgemul_classify / qgemul_plan_create. */
+int qgemul_classify_ep(const qgemul_desc* d, const qgemul_epilogue* ep, uint32_t opt_flags, qgemul_info* out);
+int qgemul_plan_create_ep(qgemul_ctx* c, const qgemul_desc* d, const qgemul_epilogue* ep, uint32_t opt_flags, qgemul_plan** out);
+/* 1 when qgemul_execute_ep runs the chain inside the GEMM kernel, 0 when it runs as its own pass after it */
+int qgemul_plan_fuses_epilogue(const qgemul_plan* p);
+/* bytes of one packed tensor operand of stage k (0 for a scalar stage) */
+int64_t qgemul_packed_e_bytes(const qgemul_plan* p, int stage);
+/* reference-layout tensor operand of stage k (device-resident copy, column-major M x N, ld in elements,
+ * 0 = tight; int32/int64 raw values like any tensor) -> the plan's packed-C layout */
+int qgemul_pack_e(qgemul_plan* p, int stage, const void* src_dev, int64_t ld, void* packed_dev);
+/* the hot path with the epilogue: packed A, packed B, stage operands -> packed D */
+int qgemul_execute_ep(qgemul_plan* p, void* packedD, const void* packedA, const void* packedB, const qgemul_ep_args* args);
+int qgemul_time_execute_ep(qgemul_plan* p, void* packedD, const void* packedA, const void* packedB, const qgemul_ep_args* args,
+                           int warmup, int iters, float* avg_ms);
+/* one-shot: host pointers in reference layout; E[k] points to stage k's tensor (tight, column-major M x N) or to its
+ * one scalar element; D (ldc from opts) is fully overwritten */
+int qgemul_run_ep(const qgemul_desc* d, const qgemul_epilogue* ep, void* D, const void* A, const void* B,
+                  const void* const* E, const qgemul_opts* o);
 
 #ifdef __cplusplus
 }

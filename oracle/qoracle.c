@@ -388,6 +388,35 @@ void qoracle_cproduct(const qgemul_desc* d, const int64_t x[2], const int64_t y[
     out[1] = (int64_t)p[1];
 }
 
+/* ---- element-wise epilogue: the lazy tensor operators applied per element after a Qgemul ----
+ * Restates MulExpression / AddExpression / SubExpression::operator[] (/root/reference/include/QuBLAS.h:3795-3798,
+ * :3828-3831, :3861-3864: Qop<toArgs...>(autoCall(q1, i), autoCall(q2, i)), a scalar operand used as is
+ * :3767-3778) followed by the tensor's constructor from an indexable expression (:2732-2746), whose
+ * data[i] = val[i] is the converting constructor (:2398-2411).  x[] holds C's raw values (format c), e[k] the
+ * tensor operands' raw values (or one value for a scalar stage); out[] receives D's raw values. */
+int qoracle_eltwise(const qgemul_epilogue* ep, qfmt c, int64_t n, const int64_t* x, const int64_t* const* e, int64_t* out)
+{
+    if (!ep || ep->n_stages > QG_MAX_EW) return -1;
+    for (int64_t i = 0; i < n; ++i) {
+        qi v = x[i];
+        qfmt f = c;
+        for (uint32_t k = 0; k < ep->n_stages; ++k) {
+            const qgemul_ew_stage* s = &ep->stage[k];
+            const qi ev = s->e_scalar ? e[k][0] : e[k][i];
+            const qi a = s->x_first ? v : ev, b = s->x_first ? ev : v;
+            const qfmt fa = s->x_first ? f : s->e, fb = s->x_first ? s->e : f;
+            if (s->op == QG_EW_MUL) v = qo_mul(a, fa, b, fb, s->r);
+            else if (s->op == QG_EW_ADD || s->op == QG_EW_SUB) v = qo_addsub(a, fa, b, fb, s->r, s->op == QG_EW_SUB);
+            else return -1;
+            f = s->r;
+            if (k + 1 < ep->n_stages) { v = qo_cvt(v, f, s->t); f = s->t; }   /* the intermediate tensor */
+        }
+        out[i] = (int64_t)qo_cvt(v, f, ep->d);
+    }
+    return 0;
+}
+
+
 /*
  * Synthetic operands: raw value of host element e, part p is drawn from the
  * counter-based generator below, so host and device produce identical tensors without sharing

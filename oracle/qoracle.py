@@ -18,7 +18,7 @@ if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 
 from qublas_amd.desc import (Qcomplex, Qu, elem_parts, host_layout, qfmt,  # noqa: E402
-                             qgemul_desc)
+                             qgemul_desc, qgemul_epilogue)
 
 _lib = None
 
@@ -62,6 +62,9 @@ def lib() -> C.CDLL:
         L.qoracle_synth.argtypes = [qfmt, C.c_uint64, C.c_int, C.c_uint64, C.c_int]
         L.qoracle_fill.restype = None
         L.qoracle_fill.argtypes = [C.POINTER(qfmt), C.c_int, C.c_uint64, C.c_int, C.c_int64, C.c_void_p]
+        L.qoracle_eltwise.restype = C.c_int
+        L.qoracle_eltwise.argtypes = [C.POINTER(qgemul_epilogue), qfmt, C.c_int64, C.POINTER(C.c_int64),
+                                      C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.c_int64)]
         L.qoracle_elem_bytes.restype = C.c_int
         L.qoracle_elem_bytes.argtypes = [C.POINTER(qfmt), C.c_int]
         L.qoracle_imag_offset.restype = C.c_int
@@ -105,4 +108,18 @@ def gemm(desc: qgemul_desc, A: np.ndarray, B: np.ndarray, c_elem, *, lda=0, ldb=
                             B.ctypes.data_as(C.c_void_p), lda, ldb, ldc, rows[0], rows[1], cols[0], cols[1], nthreads)
     if st != 0:
         raise RuntimeError(f"qoracle_gemm failed: {st}")
+    return out
+
+
+def eltwise(ep: qgemul_epilogue, c: Qu, x: np.ndarray, E) -> np.ndarray:
+    """CPU restatement of the element-wise chain on raw values: x = C's values, E[k] = operand k (array, or 1 element
+    for a scalar stage).  Returns D's raw values as int64."""
+    x = np.ascontiguousarray(x, dtype=np.int64)
+    Es = [np.ascontiguousarray(np.asarray(e).reshape(-1), dtype=np.int64) for e in E]
+    ptrs = (C.POINTER(C.c_int64) * max(1, len(Es)))(*[e.ctypes.data_as(C.POINTER(C.c_int64)) for e in Es])
+    out = np.zeros(x.size, dtype=np.int64)
+    st = lib().qoracle_eltwise(C.byref(ep), c.c(), x.size, x.ctypes.data_as(C.POINTER(C.c_int64)), ptrs,
+                               out.ctypes.data_as(C.POINTER(C.c_int64)))
+    if st != 0:
+        raise RuntimeError(f"qoracle_eltwise failed: {st}")
     return out

@@ -13,13 +13,13 @@ from typing import Optional
 
 import numpy as np
 
-from .desc import (Qcomplex, Qu, host_layout, qgemul_desc, qgemul_info, qgemul_opts)
+from .desc import (Qcomplex, Qu, host_layout, qgemul_desc, qgemul_ep_args, qgemul_epilogue, qgemul_info, qgemul_opts)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libqugemm.so")
 
 QG_OK, QG_EINVAL, QG_EUNSUPPORTED, QG_EHIP, QG_ERCCL, QG_ERANGE, QG_ENOGPU = 0, -1, -2, -3, -4, -5, -6
-OPT_FORCE_TREE, OPT_CHECK_RANGE, OPT_GENERIC_TREE, OPT_RUNTIME_MODES = 1, 2, 4, 8
+OPT_FORCE_TREE, OPT_CHECK_RANGE, OPT_GENERIC_TREE, OPT_RUNTIME_MODES, OPT_FUSED_EPILOGUE, OPT_UNFUSED_EPILOGUE = 1, 2, 4, 8, 16, 32
 OPERAND_A, OPERAND_B, OPERAND_C = 0, 1, 2
 KERNEL_NAMES = {0: "none", 1: "mfma_i8", 2: "mfma_i8_limb", 3: "tree_i32", 4: "tree_i64", 5: "tree_cplx", 6: "tree_cplx_i32", 7: "mfma_cplx"}
 
@@ -29,6 +29,8 @@ EXPORTS = [
     "qgemul_plan_create", "qgemul_plan_destroy", "qgemul_plan_info",
     "qgemul_dev_alloc", "qgemul_dev_free", "qgemul_memcpy_h2d", "qgemul_memcpy_d2h",
     "qgemul_pack", "qgemul_pack_f64", "qgemul_unpack_c", "qgemul_execute", "qgemul_fill_packed", "qgemul_time_execute",
+    "qgemul_classify_ep", "qgemul_plan_create_ep", "qgemul_packed_e_bytes", "qgemul_pack_e", "qgemul_execute_ep",
+    "qgemul_time_execute_ep", "qgemul_run_ep", "qgemul_plan_fuses_epilogue",
 ]
 
 _lib = None
@@ -78,6 +80,17 @@ def lib() -> C.CDLL:
         L.qgemul_execute.argtypes = [vp, vp, vp, vp]
         L.qgemul_fill_packed.argtypes = [vp, C.c_int, u64, C.c_int, vp]
         L.qgemul_time_execute.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        pe = C.POINTER(qgemul_epilogue)
+        pa = C.POINTER(qgemul_ep_args)
+        L.qgemul_classify_ep.argtypes = [pd, pe, u32, C.POINTER(qgemul_info)]
+        L.qgemul_plan_create_ep.argtypes = [vp, pd, pe, u32, C.POINTER(vp)]
+        L.qgemul_plan_fuses_epilogue.argtypes = [vp]
+        L.qgemul_packed_e_bytes.argtypes = [vp, C.c_int]
+        L.qgemul_packed_e_bytes.restype = i64
+        L.qgemul_pack_e.argtypes = [vp, C.c_int, vp, i64, vp]
+        L.qgemul_execute_ep.argtypes = [vp, vp, vp, vp, pa]
+        L.qgemul_time_execute_ep.argtypes = [vp, vp, vp, vp, pa, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        L.qgemul_run_ep.argtypes = [pd, pe, vp, vp, vp, C.POINTER(vp), C.POINTER(qgemul_opts)]
         _lib = L
     return _lib
 
@@ -91,6 +104,25 @@ def classify(desc: qgemul_desc, flags: int = 0) -> qgemul_info:
     info = qgemul_info()
     _chk(lib().qgemul_classify(C.byref(desc), flags, C.byref(info)), "qgemul_classify")
     return info
+
+
+def classify_ep_status(desc: qgemul_desc, ep: qgemul_epilogue, flags: int = 0):
+    info = qgemul_info()
+    st = lib().qgemul_classify_ep(C.byref(desc), C.byref(ep), flags, C.byref(info))
+    return st, info
+
+
+def run_ep(desc: qgemul_desc, ep: qgemul_epilogue, D_out: np.ndarray, A: np.ndarray, B: np.ndarray, E, *, lda: int = 0,
+           ldb: int = 0, ldc: int = 0, device: int = -1, flags: int = 0) -> np.ndarray:
+    """qgemul_run_ep: E[k] = host-layout tensor (tight, column-major flattening) or a 1-element array for a scalar stage."""
+    A = np.ascontiguousarray(A)
+    B = np.ascontiguousarray(B)
+    E = [np.ascontiguousarray(e) for e in E]
+    ptrs = (C.c_void_p * max(1, len(E)))(*[e.ctypes.data for e in E])
+    o = qgemul_opts(lda, ldb, ldc, device, flags)
+    _chk(lib().qgemul_run_ep(C.byref(desc), C.byref(ep), D_out.ctypes.data_as(C.c_void_p), A.ctypes.data_as(C.c_void_p),
+                             B.ctypes.data_as(C.c_void_p), ptrs, C.byref(o)), "qgemul_run_ep")
+    return D_out
 
 
 def classify_status(desc: qgemul_desc, flags: int = 0):
@@ -151,11 +183,15 @@ class Context:
 
 
 class Plan:
-    def __init__(self, ctx: Context, desc: qgemul_desc, flags: int = 0):
+    def __init__(self, ctx: Context, desc: qgemul_desc, flags: int = 0, epilogue: Optional[qgemul_epilogue] = None):
         self.ctx = ctx
         self.desc = desc
+        self.epilogue = epilogue
         self.h = C.c_void_p()
-        _chk(lib().qgemul_plan_create(ctx.h, C.byref(desc), flags, C.byref(self.h)), "qgemul_plan_create")
+        if epilogue is None:
+            _chk(lib().qgemul_plan_create(ctx.h, C.byref(desc), flags, C.byref(self.h)), "qgemul_plan_create")
+        else:
+            _chk(lib().qgemul_plan_create_ep(ctx.h, C.byref(desc), C.byref(epilogue), flags, C.byref(self.h)), "qgemul_plan_create_ep")
         self.info = qgemul_info()
         _chk(lib().qgemul_plan_info(self.h, C.byref(self.info)), "qgemul_plan_info")
 
@@ -175,6 +211,33 @@ class Plan:
 
     def execute(self, pC: int, pA: int, pB: int):
         _chk(lib().qgemul_execute(self.h, C.c_void_p(pC), C.c_void_p(pA), C.c_void_p(pB)), "qgemul_execute")
+
+    def fuses_epilogue(self) -> bool:
+        return bool(lib().qgemul_plan_fuses_epilogue(self.h))
+
+    def packed_e_bytes(self, stage: int) -> int:
+        return int(lib().qgemul_packed_e_bytes(self.h, stage))
+
+    def pack_e(self, stage: int, src_dev: int, packed_dev: int, ld: int = 0):
+        _chk(lib().qgemul_pack_e(self.h, stage, C.c_void_p(src_dev), ld, C.c_void_p(packed_dev)), "qgemul_pack_e")
+
+    @staticmethod
+    def ep_args(packed=(), scalars=()) -> qgemul_ep_args:
+        a = qgemul_ep_args()
+        for k, ptr in enumerate(packed):
+            a.e_packed[k] = ptr or None
+        for k, v in enumerate(scalars):
+            a.e_scalar[k] = int(v or 0)
+        return a
+
+    def execute_ep(self, pD: int, pA: int, pB: int, args: qgemul_ep_args):
+        _chk(lib().qgemul_execute_ep(self.h, C.c_void_p(pD), C.c_void_p(pA), C.c_void_p(pB), C.byref(args)), "qgemul_execute_ep")
+
+    def time_execute_ep(self, pD: int, pA: int, pB: int, args: qgemul_ep_args, warmup: int, iters: int) -> float:
+        ms = C.c_float()
+        _chk(lib().qgemul_time_execute_ep(self.h, C.c_void_p(pD), C.c_void_p(pA), C.c_void_p(pB), C.byref(args), warmup, iters,
+                                          C.byref(ms)), "qgemul_time_execute_ep")
+        return ms.value
 
     def unpack_c(self, pC: int, dst_dev: int, ld: int = 0):
         _chk(lib().qgemul_unpack_c(self.h, C.c_void_p(pC), C.c_void_p(dst_dev), ld), "qgemul_unpack_c")

@@ -44,6 +44,13 @@ struct qgemul_plan {
     QTreeTable* dev_table;
     int64_t* workspace;   // complex linear class: raw dot products [2Mh x 2Nh] int64
     QMfmaCfg cfg;
+    // element-wise epilogue (qgemul_epilogue): pc then describes packed D; pc_c is the kernel's own packed C, which
+    // only exists in memory (cwork) for the kernels that do not fuse the chain
+    int has_ep;
+    qgemul_epilogue ep;
+    QEpTable ept;
+    QCGeom pc_c;
+    void* cwork;
 };
 
 static int pow2_bytes(int storage_bits)
@@ -58,7 +65,8 @@ static int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // fill info + geometry for a descriptor; no GPU access
 static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qgemul_info* info, int* pLA, int* pLB, QMfmaCfg* pVar,
-                         QPackedGeom* pa, QPackedGeom* pb, QCGeom* pc, QHostElem* ha, QHostElem* hb, QHostElem* hc)
+                         QPackedGeom* pa, QPackedGeom* pb, QCGeom* pc, QHostElem* ha, QHostElem* hb, QHostElem* hc,
+                         const qgemul_epilogue* ep = nullptr, QEpTable* ept = nullptr, QCGeom* pc_c = nullptr)
 {
     qg_analyze(d, an);
     memset(info, 0, sizeof *info);
@@ -151,7 +159,50 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     *pLA = LA;
     *pLB = LB;
     *pVar = cfg;
+    if (pc_c) *pc_c = *pc;
+    if (ep) {
+        // D replaces C as the stored result: same index space, D's container and host element
+        if (d->is_complex) {
+            info->supported = 0;
+            snprintf(info->reason, sizeof info->reason, "element-wise epilogue: real GEMMs only");
+            return QG_EUNSUPPORTED;
+        }
+        QEpTable local;
+        QEpTable* t = ept ? ept : &local;
+        int ep_bits = 0;
+        char why[96];
+        const int st = qg_analyze_ep(d->c[0], ep, t, &ep_bits, why, sizeof why);
+        if (st != QG_OK) {
+            info->supported = 0;
+            snprintf(info->reason, sizeof info->reason, "%s", why);
+            return st;
+        }
+        if (ep_bits > info->max_bits) info->max_bits = ep_bits;
+        const qfmt df[2] = {ep->d, ep->d};
+        *hc = qg_host_elem(df, 0);
+        pc->cbytes = t->dbytes;
+        pc->elem_bytes = hc->size;
+        pc->off[0] = hc->off[0];
+        pc->sb[0] = hc->sb[0];
+        info->host_elem_bytes[2] = hc->size;
+        info->packed_bytes[2] = pc->Mp * pc->Np * pc->cbytes;
+    }
     return QG_OK;
+}
+
+// Where the chain runs (measurements: profiles/r01u_eltwise.jsonl, chain = scale + bias into C's own type):
+//   3x3-limb kernel, 4096^3: plain 0.458 ms, chain fused into the kernel's epilogue 0.473, chain as a pass 0.490
+//   single-limb 256^2-tile kernel, 8192^2 x 4096: plain 0.280, fused 0.503, pass 0.436  (the fused epilogue spills:
+//   128 accumulator registers stay live; and with one workgroup per CU the matrix cores idle meanwhile)
+// so the default fuses on the limb kernel only, and only chains the planner has bounded by 32-bit arithmetic (a 64-bit
+// chain inside the kernel was measured slower than the pass on every kernel).  Everything else runs as ONE linear,
+// HBM-bound pass over the stored C (all stages and the final conversion in that pass, 5-6 TB/s).
+static bool fuses_epilogue(const qgemul_plan* p)
+{
+    if (p->flags & QG_OPT_UNFUSED_EPILOGUE) return false;
+    if (!p->ept.bits32) return false;
+    if (p->info.kernel == QG_KERNEL_MFMA_I8_LIMB && p->LA == 3 && p->LB == 3) return true;
+    return p->info.kernel == QG_KERNEL_MFMA_I8 && (p->flags & QG_OPT_FUSED_EPILOGUE);
 }
 
 extern "C" {
@@ -173,7 +224,9 @@ const char* qgemul_strerror(int st)
     }
 }
 
-int qgemul_classify(const qgemul_desc* d, uint32_t opt_flags, qgemul_info* out)
+int qgemul_classify(const qgemul_desc* d, uint32_t opt_flags, qgemul_info* out) { return qgemul_classify_ep(d, nullptr, opt_flags, out); }
+
+int qgemul_classify_ep(const qgemul_desc* d, const qgemul_epilogue* ep, uint32_t opt_flags, qgemul_info* out)
 {
     if (!d || !out) return QG_EINVAL;
     QAnalysis* an = new (std::nothrow) QAnalysis;
@@ -183,7 +236,7 @@ int qgemul_classify(const qgemul_desc* d, uint32_t opt_flags, qgemul_info* out)
     QPackedGeom pa, pb;
     QCGeom pc;
     QHostElem ha, hb, hc;
-    int st = plan_geometry(d, opt_flags, an, out, &LA, &LB, &variant, &pa, &pb, &pc, &ha, &hb, &hc);
+    int st = plan_geometry(d, opt_flags, an, out, &LA, &LB, &variant, &pa, &pb, &pc, &ha, &hb, &hc, ep);
     delete an;
     return st;
 }
@@ -261,6 +314,11 @@ int qgemul_memcpy_d2h(qgemul_ctx* c, void* dst, const void* src, size_t bytes)
 
 int qgemul_plan_create(qgemul_ctx* c, const qgemul_desc* d, uint32_t opt_flags, qgemul_plan** out)
 {
+    return qgemul_plan_create_ep(c, d, nullptr, opt_flags, out);
+}
+
+int qgemul_plan_create_ep(qgemul_ctx* c, const qgemul_desc* d, const qgemul_epilogue* ep, uint32_t opt_flags, qgemul_plan** out)
+{
     if (!c || !d || !out) return QG_EINVAL;
     qgemul_plan* p = new (std::nothrow) qgemul_plan;
     if (!p) return QG_EINVAL;
@@ -268,7 +326,9 @@ int qgemul_plan_create(qgemul_ctx* c, const qgemul_desc* d, uint32_t opt_flags, 
     p->ctx = c;
     p->desc = *d;
     p->flags = opt_flags;
-    int st = plan_geometry(d, opt_flags, &p->an, &p->info, &p->LA, &p->LB, &p->cfg, &p->pa, &p->pb, &p->pc, &p->ha, &p->hb, &p->hc);
+    if (ep) { p->has_ep = 1; p->ep = *ep; }
+    int st = plan_geometry(d, opt_flags, &p->an, &p->info, &p->LA, &p->LB, &p->cfg, &p->pa, &p->pb, &p->pc, &p->ha, &p->hb, &p->hc,
+                           ep, &p->ept, &p->pc_c);
     if (st != QG_OK) { delete p; return st; }
     p->variant = p->cfg.variant;
     if (hipSetDevice(c->device) != hipSuccess || hipMalloc((void**)&p->dev_table, sizeof(QTreeTable)) != hipSuccess) {
@@ -289,6 +349,16 @@ int qgemul_plan_create(qgemul_ctx* c, const qgemul_desc* d, uint32_t opt_flags, 
             return QG_EHIP;
         }
     }
+    if (p->has_ep && !fuses_epilogue(p)) {
+        // the tree kernels store C; the chain then runs as a pass over it
+        const size_t cb = (size_t)(p->pc_c.Mp * p->pc_c.Np) * (size_t)p->pc_c.cbytes;
+        if (hipMalloc(&p->cwork, cb ? cb : 16) != hipSuccess) {
+            hipFree(p->dev_table);
+            hipFree(p->workspace);
+            delete p;
+            return QG_EHIP;
+        }
+    }
     *out = p;
     return QG_OK;
 }
@@ -299,6 +369,7 @@ void qgemul_plan_destroy(qgemul_plan* p)
     hipStreamSynchronize(p->ctx->stream);
     hipFree(p->dev_table);
     hipFree(p->workspace);
+    hipFree(p->cwork);
     delete p;
 }
 
@@ -384,22 +455,99 @@ int qgemul_unpack_c(qgemul_plan* p, const void* packed_dev, void* dst_dev, int64
     return QG_OK;
 }
 
+static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB, const qgemul_ep_args* epa);
+
 int qgemul_execute(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB)
 {
     if (!p || !packedC || !packedA || !packedB) return QG_EINVAL;
+    if (p->has_ep) return QG_EINVAL;  // a plan with an epilogue runs through qgemul_execute_ep
     if (p->desc.M == 0 || p->desc.N == 0) return QG_OK;
+    return execute_kernel(p, packedC, packedA, packedB, nullptr);
+}
+
+int qgemul_execute_ep(qgemul_plan* p, void* packedD, const void* packedA, const void* packedB, const qgemul_ep_args* args)
+{
+    if (!p || !packedD || !packedA || !packedB) return QG_EINVAL;
+    if (!p->has_ep) return args ? QG_EINVAL : qgemul_execute(p, packedD, packedA, packedB);
+    if (!args && p->ept.n > 0) return QG_EINVAL;
+    for (int k = 0; k < p->ept.n; ++k)
+        if (!p->ept.st[k].scalar && !args->e_packed[k]) return QG_EINVAL;
+    if (p->desc.M == 0 || p->desc.N == 0) return QG_OK;
+    QEpArgs a;
+    memset(&a, 0, sizeof a);
+    for (int k = 0; k < p->ept.n; ++k) {
+        a.e[k] = (const char*)args->e_packed[k];
+        a.scalar[k] = args->e_scalar[k];
+    }
     hipStream_t st = p->ctx->stream;
+    if (fuses_epilogue(p)) {
+        // fused: the MFMA kernel's epilogue runs the chain on the value it has just converted into C's type
+        QMfmaArgs m;
+        memset(&m, 0, sizeof m);
+        m.A = (const int8_t*)packedA;
+        m.B = (const int8_t*)packedB;
+        m.C = packedD;
+        m.Mp = p->pa.rows_p;
+        m.Np = p->pb.rows_p;
+        m.Kp = p->pa.K_p;
+        m.cbytes = p->pc_c.cbytes;
+        m.variant = p->variant;
+        m.to_c = p->an.lin.to_c[0];
+        m.has_ep = 1;
+        m.ep = p->ept;
+        m.epa = a;
+        QG_HIP(qg_launch_mfma(p->LA, p->LB, m, st));
+        return QG_OK;
+    }
+    // not fused: the kernel stores C into the plan's buffer, one linear pass turns it into D
+    const int s = execute_kernel(p, p->cwork, packedA, packedB, nullptr);
+    if (s != QG_OK) return s;
+    QEltwiseArgs g;
+    memset(&g, 0, sizeof g);
+    g.C = (const char*)p->cwork;
+    g.D = (char*)packedD;
+    g.n = p->pc_c.Mp * p->pc_c.Np;
+    g.cbytes = p->pc_c.cbytes;
+    g.t = p->ept;
+    g.a = a;
+    QG_HIP(qg_launch_eltwise(g, st));
+    return QG_OK;
+}
+
+int qgemul_plan_fuses_epilogue(const qgemul_plan* p) { return p && p->has_ep && fuses_epilogue(p) ? 1 : 0; }
+
+int64_t qgemul_packed_e_bytes(const qgemul_plan* p, int stage)
+{
+    if (!p || !p->has_ep || stage < 0 || stage >= p->ept.n || p->ept.st[stage].scalar) return 0;
+    return p->pc.Mp * p->pc.Np * (int64_t)p->ept.st[stage].ebytes;
+}
+
+int qgemul_pack_e(qgemul_plan* p, int stage, const void* src_dev, int64_t ld, void* packed_dev)
+{
+    if (!p || !src_dev || !packed_dev || !p->has_ep || stage < 0 || stage >= p->ept.n || p->ept.st[stage].scalar) return QG_EINVAL;
+    if (ld && ld < p->desc.M) return QG_EINVAL;
+    const qfmt f = p->ep.stage[stage].e;
+    const int src_bytes = (1 + (int)f.I + (int)f.F) <= 32 ? 4 : 8;
+    QG_HIP(qg_launch_pack_e(p->pc, src_dev, ld ? ld : p->desc.M, src_bytes, packed_dev, p->ept.st[stage].ebytes, p->ctx->stream));
+    return QG_OK;
+}
+
+static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB, const qgemul_ep_args*)
+{
+    hipStream_t st = p->ctx->stream;
+    const QCGeom& pcg = p->has_ep ? p->pc_c : p->pc;
     switch (p->info.kernel) {
     case QG_KERNEL_MFMA_I8:
     case QG_KERNEL_MFMA_I8_LIMB: {
         QMfmaArgs a;
+        memset(&a, 0, sizeof a);
         a.A = (const int8_t*)packedA;
         a.B = (const int8_t*)packedB;
         a.C = packedC;
         a.Mp = p->pa.rows_p;
         a.Np = p->pb.rows_p;
         a.Kp = p->pa.K_p;
-        a.cbytes = p->pc.cbytes;
+        a.cbytes = pcg.cbytes;
         a.variant = p->variant;
         a.to_c = p->an.lin.to_c[0];
         QG_HIP(qg_launch_mfma(p->LA, p->LB, a, st));
@@ -407,6 +555,7 @@ int qgemul_execute(qgemul_plan* p, void* packedC, const void* packedA, const voi
     }
     case QG_KERNEL_MFMA_CPLX: {
         QMfmaArgs a;
+        memset(&a, 0, sizeof a);
         a.A = (const int8_t*)packedA;
         a.B = (const int8_t*)packedB;
         a.C = p->workspace;
@@ -438,7 +587,7 @@ int qgemul_execute(qgemul_plan* p, void* packedC, const void* packedA, const voi
     case QG_KERNEL_TREE_I32:
         QG_HIP(qg_launch_tree_fast(p->dev_table, (int)p->desc.n_levels, p->an.split_s, p->an.mul24_ok,
                                    (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : p->an.fast_mode, packedA, packedB, packedC,
-                                   p->desc.M, p->desc.N, p->desc.K, p->pc.cbytes, st));
+                                   p->desc.M, p->desc.N, p->desc.K, pcg.cbytes, st));
         return QG_OK;
     case QG_KERNEL_TREE_CPLX_I32:
         QG_HIP(qg_launch_tree_cplx_fast(p->dev_table, (int)p->desc.n_levels, packedA, packedB, packedC, p->desc.M, p->desc.N,
@@ -447,20 +596,21 @@ int qgemul_execute(qgemul_plan* p, void* packedC, const void* packedA, const voi
     case QG_KERNEL_TREE_I64:
     case QG_KERNEL_TREE_CPLX:
         QG_HIP(qg_launch_tree_generic(p->dev_table, p->desc.is_complex ? 2 : 1, packedA, packedB, packedC, p->desc.M, p->desc.N,
-                                      p->desc.K, p->pa, p->pb, p->pc, st));
+                                      p->desc.K, p->pa, p->pb, pcg, st));
         return QG_OK;
     default:
         return QG_EUNSUPPORTED;
     }
 }
 
-int qgemul_time_execute(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB, int warmup, int iters,
-                        float* avg_ms)
+static int time_execute(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB, const qgemul_ep_args* args,
+                        int warmup, int iters, float* avg_ms)
 {
     if (!p || !avg_ms || iters < 1) return QG_EINVAL;
     hipStream_t st = p->ctx->stream;
+    auto once = [&]() { return p->has_ep ? qgemul_execute_ep(p, packedC, packedA, packedB, args) : qgemul_execute(p, packedC, packedA, packedB); };
     for (int i = 0; i < warmup; ++i) {
-        int s = qgemul_execute(p, packedC, packedA, packedB);
+        int s = once();
         if (s) return s;
     }
     hipEvent_t e0, e1;
@@ -468,7 +618,7 @@ int qgemul_time_execute(qgemul_plan* p, void* packedC, const void* packedA, cons
     QG_HIP(hipEventCreate(&e1));
     QG_HIP(hipEventRecord(e0, st));
     for (int i = 0; i < iters; ++i) {
-        int s = qgemul_execute(p, packedC, packedA, packedB);
+        int s = once();
         if (s) return s;
     }
     QG_HIP(hipEventRecord(e1, st));
@@ -481,7 +631,25 @@ int qgemul_time_execute(qgemul_plan* p, void* packedC, const void* packedA, cons
     return QG_OK;
 }
 
+int qgemul_time_execute(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB, int warmup, int iters,
+                        float* avg_ms)
+{
+    return time_execute(p, packedC, packedA, packedB, nullptr, warmup, iters, avg_ms);
+}
+
+int qgemul_time_execute_ep(qgemul_plan* p, void* packedD, const void* packedA, const void* packedB, const qgemul_ep_args* args,
+                           int warmup, int iters, float* avg_ms)
+{
+    return time_execute(p, packedD, packedA, packedB, args, warmup, iters, avg_ms);
+}
+
 int qgemul_run(const qgemul_desc* d, void* C, const void* A, const void* B, const qgemul_opts* o)
+{
+    return qgemul_run_ep(d, nullptr, C, A, B, nullptr, o);
+}
+
+int qgemul_run_ep(const qgemul_desc* d, const qgemul_epilogue* ep, void* C, const void* A, const void* B, const void* const* E,
+                  const qgemul_opts* o)
 {
     if (!d || !C || !A || !B) return QG_EINVAL;
     qgemul_opts opts;
@@ -491,17 +659,21 @@ int qgemul_run(const qgemul_desc* d, void* C, const void* A, const void* B, cons
     // validate before touching the device so that descriptor errors are reported without a GPU
     {
         qgemul_info info;
-        int st = qgemul_classify(d, opts.flags, &info);
+        int st = qgemul_classify_ep(d, ep, opts.flags, &info);
         if (st != QG_OK) return st;
     }
+    if (ep)
+        for (uint32_t k = 0; k < ep->n_stages; ++k)
+            if (!E || !E[k]) return QG_EINVAL;
     if (d->M == 0 || d->N == 0) return QG_OK;
     qgemul_ctx* ctx = nullptr;
     int st = qgemul_ctx_create(opts.device, &ctx);
     if (st != QG_OK) return st;
     qgemul_plan* p = nullptr;
     void *dA = nullptr, *dB = nullptr, *dC = nullptr, *pA = nullptr, *pB = nullptr, *pC = nullptr;
+    void *dE[QG_MAX_EW] = {nullptr, nullptr, nullptr, nullptr}, *pE[QG_MAX_EW] = {nullptr, nullptr, nullptr, nullptr};
     do {
-        st = qgemul_plan_create(ctx, d, opts.flags, &p);
+        st = qgemul_plan_create_ep(ctx, d, ep, opts.flags, &p);
         if (st) break;
         const int64_t lda = opts.lda ? opts.lda : (d->transA ? d->K : d->M);
         const int64_t ldb = opts.ldb ? opts.ldb : d->K;
@@ -519,12 +691,33 @@ int qgemul_run(const qgemul_desc* d, void* C, const void* A, const void* B, cons
         // the caller's C may have padding between columns (ldc > M): keep those bytes as they are
         if (ldc != d->M && (st = qgemul_memcpy_h2d(ctx, dC, C, bytesC))) break;
         if ((st = qgemul_pack(p, QG_OPERAND_A, dA, lda, pA)) || (st = qgemul_pack(p, QG_OPERAND_B, dB, ldb, pB))) break;
-        if ((st = qgemul_execute(p, pC, pA, pB))) break;
+        if (!ep) {
+            if ((st = qgemul_execute(p, pC, pA, pB))) break;
+        } else {
+            qgemul_ep_args ea;
+            memset(&ea, 0, sizeof ea);
+            for (uint32_t k = 0; k < ep->n_stages && !st; ++k) {
+                const qfmt f = ep->stage[k].e;
+                const size_t eb = (1 + (int)f.I + (int)f.F) <= 32 ? 4 : 8;
+                if (ep->stage[k].e_scalar) {
+                    ea.e_scalar[k] = eb == 4 ? (int64_t) * (const int32_t*)E[k] : *(const int64_t*)E[k];
+                    continue;
+                }
+                const size_t bytesE = (size_t)d->M * (size_t)d->N * eb;
+                if ((st = qgemul_dev_alloc(ctx, bytesE, &dE[k])) || (st = qgemul_dev_alloc(ctx, (size_t)qgemul_packed_e_bytes(p, (int)k), &pE[k])) ||
+                    (st = qgemul_memcpy_h2d(ctx, dE[k], E[k], bytesE)) || (st = qgemul_pack_e(p, (int)k, dE[k], 0, pE[k])))
+                    break;
+                ea.e_packed[k] = pE[k];
+            }
+            if (st) break;
+            if ((st = qgemul_execute_ep(p, pC, pA, pB, &ea))) break;
+        }
         if ((st = qgemul_unpack_c(p, pC, dC, ldc))) break;
         if ((st = qgemul_memcpy_d2h(ctx, C, dC, bytesC))) break;
     } while (0);
     if (ctx) hipStreamSynchronize(ctx->stream);
     hipFree(dA); hipFree(dB); hipFree(dC); hipFree(pA); hipFree(pB); hipFree(pC);
+    for (int k = 0; k < QG_MAX_EW; ++k) { hipFree(dE[k]); hipFree(pE[k]); }
     qgemul_plan_destroy(p);
     qgemul_ctx_destroy(ctx);
     return st;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "qg_eltwise_args.h"
 #include "qg_plan.h"
 
 // geometry of one operand in host (reference) layout as seen by pack / fill / unpack kernels
@@ -39,6 +40,13 @@ struct QCGeom {
     int64_t ldc;            // host leading dimension (elements)
     int32_t elem_bytes, off[2], sb[2];
 };
+
+// element index of (part, m, n) in packed C
+__host__ __device__ inline int64_t qg_c_index(const QCGeom& c, int part, int64_t m, int64_t n)
+{
+    if (c.tm == 0) return ((int64_t)part * c.Mp + m) * c.Np + n;
+    return ((((int64_t)part * (c.Mp / c.tm) + m / c.tm) * (c.Np / c.tn) + n / c.tn) * c.tn + n % c.tn) * c.tm + m % c.tm;
+}
 
 hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const void* src, void* dst, int check_range,
                           int* range_flag, hipStream_t st);
@@ -86,5 +94,12 @@ struct QMfmaArgs {
     int32_t cbytes;
     int32_t variant;
     QStep to_c;
+    int32_t has_ep, pad_;   // fused element-wise epilogue: C below is then packed D (ep.dbytes containers)
+    QEpTable ep;
+    QEpArgs epa;
 };
 hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st);
+
+// element-wise epilogue as its own pass (kernels that do not fuse it) and the operand packer; see qg_eltwise.h
+hipError_t qg_launch_eltwise(const QEltwiseArgs& g, hipStream_t st);
+hipError_t qg_launch_pack_e(const QCGeom& c, const void* src, int64_t ld, int src_bytes, void* dst, int ebytes, hipStream_t st);

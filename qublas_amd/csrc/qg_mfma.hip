@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include "qg_eltwise.h"
 #include "qg_kernels.h"
 #include "qg_step_all.h"
 
@@ -44,7 +45,7 @@ __device__ __forceinline__ int swz(int r)
 
 // LA, LB : int8 limbs per A / B element          BK       : k-tile in bytes
 // WGM x WGN waves per workgroup                  TI x TJ  : 32x32 MFMA tiles per wave
-template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE, int ABL>
+template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE, int ABL, bool EP>   // EP: fused element-wise epilogue
 __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 {
     constexpr int TM = WGM * TI * 32, TN = WGN * TJ * 32;
@@ -213,6 +214,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
             const int col = (wn * TJ + j) * 32 + fr;
             const int row0 = (wm * TI + i) * 32 + 4 * fh;
             const int64_t base = tile_base + (int64_t)col * TM + row0;
+            if constexpr (EP) {
+                // the value just converted into C's element type goes through the element-wise chain and is stored
+                // as D: C itself never reaches memory (qg_eltwise.h); 32-bit arithmetic when the planner allows it
+                // (fused only for chains the planner has bounded by 32 bits: qg_api.hip, fuses_epilogue)
+                int32_t v[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = (int32_t)s[e];
+                qg_ep_apply_runs<int32_t, 4>(v, g.ep, g.epa, base, 8);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) qg_ep_store_run<int32_t>(C, base + 8 * q, g.ep.dbytes, v + 4 * q);
+            } else
             switch (g.cbytes) {
             case 1:
 #pragma unroll
@@ -252,7 +264,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 typedef int v4acc __attribute__((ext_vector_type(4)));
 
 // LA x LB limbs; DBUF: fragments double-buffered across k-tiles (only when the registers allow it)
-template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF>   // TI x TJ tiles of 16x16 per wave
+template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF, bool EP>   // TI x TJ tiles of 16x16 per wave
 __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
 {
     constexpr int BK = 64, NSTAGE = 3;
@@ -393,6 +405,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
             }
         qg_step_all<S, 4 * TJ>(s, st);
         const int row0 = (wm * TI + i) * 16 + 4 * fq;
+        if constexpr (EP) {
+            const int64_t base0 = tile_base + (int64_t)(wn * TJ * 16 + fr) * TM + row0;   // run j starts 16 columns further
+            int32_t v[4 * TJ];
+#pragma unroll
+            for (int e = 0; e < 4 * TJ; ++e) v[e] = (int32_t)s[e];
+            qg_ep_apply_runs<int32_t, TJ>(v, g.ep, g.epa, base0, (int64_t)16 * TM);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) qg_ep_store_run<int32_t>(C, base0 + (int64_t)j * 16 * TM, g.ep.dbytes, v + 4 * j);
+        } else
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const int col = (wn * TJ + j) * 16 + fr;
@@ -419,40 +440,48 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
     }
 }
 
-template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF>
+template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF, bool EP = false>
 hipError_t launch16(const QMfmaArgs& a, hipStream_t st)
 {
+    if constexpr (!EP) {
+        if (a.has_ep) return launch16<LA, LB, WGM, WGN, TI, TJ, DBUF, true>(a, st);
+    }
+    if (a.has_ep && (!EP || !a.ep.bits32)) return hipErrorInvalidValue;
     constexpr int TM = WGM * TI * 16, TN = WGN * TJ * 16;
     const int lds = 3 * (LA * TM + LB * TN) * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF, EP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int64_t blocks = (a.Mp / TM) * (a.Np / TN);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll || a.Kp % 64 || a.Mp % TM || a.Np % TN) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
+    hipLaunchKernelGGL((k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF, EP>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
     return hipGetLastError();
 }
 
-template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE, int ABL = 0>
+template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE, int ABL = 0, bool EP = false>
 hipError_t launch(const QMfmaArgs& a, hipStream_t st)
 {
+    if constexpr (!EP && ABL == 0 && LA == LB && LA != 2) {   // fused variants exist for the 1x1 and 3x3 kernels only
+        if (a.has_ep) return launch<LA, LB, BK, WGM, WGN, TI, TJ, NSTAGE, ABL, true>(a, st);
+    }
+    if (a.has_ep && (!EP || !a.ep.bits32)) return hipErrorInvalidValue;
     constexpr int TM = WGM * TI * 32, TN = WGN * TJ * 32;
     constexpr int STAGE = (LA * TM + LB * TN) * BK;
     const int lds = NSTAGE * STAGE;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mfma<LA, LB, BK, WGM, WGN, TI, TJ, NSTAGE, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_mfma<LA, LB, BK, WGM, WGN, TI, TJ, NSTAGE, ABL, EP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int64_t blocks = (a.Mp / TM) * (a.Np / TN);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll || a.Kp % BK || a.Mp % TM || a.Np % TN) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_mfma<LA, LB, BK, WGM, WGN, TI, TJ, NSTAGE, ABL>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
+    hipLaunchKernelGGL((k_mfma<LA, LB, BK, WGM, WGN, TI, TJ, NSTAGE, ABL, EP>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
     return hipGetLastError();
 }
 

@@ -188,6 +188,71 @@ Val do_cvt(Ctx& c, Val a, qfmt to, QStep* st)
 
 } // namespace
 
+int qg_analyze_ep(qfmt cfmt, const qgemul_epilogue* ep, QEpTable* out, int* max_bits, char* reason, size_t reason_len)
+{
+    memset(out, 0, sizeof *out);
+    g_fmt_bits_seen = 0;
+    QAnalysis* an = new QAnalysis;
+    memset(an, 0, sizeof *an);
+    an->status = QG_OK;
+    Ctx c;
+    c.out = an;
+    auto pow2_bytes = [](qfmt f) {
+        int b = (1 + (int)f.I + (int)f.F + 7) / 8, r = 1;
+        while (r < b) r *= 2;
+        return r;
+    };
+    do {
+        if (!ep || ep->n_stages > QG_MAX_EW) { c.fail(QG_EINVAL, "null epilogue or too many stages"); break; }
+        if (!fmt_ok(c, cfmt) || !fmt_ok(c, ep->d)) break;
+        Val x;
+        x.f = cfmt;
+        x.r = fmt_range(cfmt);
+        bool ok = true;
+        for (uint32_t k = 0; k < ep->n_stages && ok; ++k) {
+            const qgemul_ew_stage& s = ep->stage[k];
+            if (s.op < QG_EW_ADD || s.op > QG_EW_MUL) { c.fail(QG_EINVAL, "unknown element-wise op"); ok = false; break; }
+            if (!fmt_ok(c, s.e) || !fmt_ok(c, s.r)) { ok = false; break; }
+            Val e;
+            e.f = s.e;
+            e.r = fmt_range(s.e);
+            QEpStage& t = out->st[k];
+            t.op = s.op;
+            t.x_first = s.x_first ? 1 : 0;
+            t.scalar = s.e_scalar ? 1 : 0;
+            t.ebytes = pow2_bytes(s.e);
+            const Val& first = t.x_first ? x : e;
+            const Val& second = t.x_first ? e : x;
+            x = s.op == QG_EW_MUL ? do_mul(c, first, second, s.r, &t.node) : do_addsub(c, first, second, s.r, s.op == QG_EW_SUB, &t.node);
+            memset(&t.cvt, 0, sizeof t.cvt);
+            t.cvt.identity = 1;
+            if (k + 1 < ep->n_stages) {
+                if (!fmt_ok(c, s.t)) { ok = false; break; }
+                x = do_cvt(c, x, s.t, &t.cvt);
+            }
+        }
+        if (!ok) break;
+        do_cvt(c, x, ep->d, &out->to_d);
+        out->n = (int)ep->n_stages;
+        out->dbytes = pow2_bytes(ep->d);
+        out->max_bits = c.max_bits;
+        {
+            // 32-bit arithmetic: every intermediate (raw products and aligned operands included) within 32 bits, every
+            // format within 32 storage bits, every rounding shift below 31
+            bool ok32 = c.max_bits <= 32 && g_fmt_bits_seen <= 32 && 1 + (int)cfmt.I + (int)cfmt.F <= 32;
+            auto shift_ok = [](const QStep& q) { return q.identity || q.d <= 30; };
+            for (int k = 0; k < out->n; ++k) ok32 = ok32 && shift_ok(out->st[k].node.q) && shift_ok(out->st[k].cvt) && out->st[k].ebytes <= 4;
+            out->bits32 = (ok32 && shift_ok(out->to_d)) ? 1 : 0;
+        }
+        if (c.max_bits > 62) c.fail(QG_EUNSUPPORTED, "epilogue intermediate wider than 62 bits");
+    } while (0);
+    const int st = an->status;
+    if (reason && reason_len) snprintf(reason, reason_len, "%s", an->reason);
+    if (max_bits) *max_bits = c.max_bits;
+    delete an;
+    return st;
+}
+
 QHostElem qg_host_elem(const qfmt f[2], int is_complex)
 {
     QHostElem L;

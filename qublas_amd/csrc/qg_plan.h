@@ -45,6 +45,23 @@ struct QAnalysis {
 
 void qg_analyze(const qgemul_desc* d, QAnalysis* out);
 
+// fused element-wise epilogue (qgemul_epilogue), pre-resolved for the device: stage k combines the running value x
+// with its operand e (node.sa shifts the FIRST operand of the Qop, node.sb the second), node.q rounds/overflows into
+// the stage's result format; to_d is the destination tensor's converting assignment
+struct QEpStage {
+    int32_t op, x_first, scalar, ebytes;   // ebytes: container of a packed tensor operand (1|2|4|8)
+    QNode node;
+    QStep cvt;                             // assignment to the stage's tensor (identity for the last stage: to_d)
+};
+struct QEpTable {
+    int32_t n, dbytes;                     // stages; container bytes of packed D
+    int32_t bits32, max_bits;              // bits32: every value of the chain (and C itself) fits 32-bit arithmetic
+    QEpStage st[QG_MAX_EW];
+    QStep to_d;
+};
+// validates `ep` against the GEMM's C format; returns QG_OK / QG_EINVAL / QG_EUNSUPPORTED (reason filled)
+int qg_analyze_ep(qfmt c, const qgemul_epilogue* ep, QEpTable* out, int* max_bits, char* reason, size_t reason_len);
+
 // host-layout element geometry (int32/int64 per part; complex = struct {real; imag;})
 struct QHostElem {
     int size, off[2], sb[2];

@@ -66,6 +66,23 @@ class qgemul_opts(C.Structure):
                 ("device", C.c_int32), ("flags", C.c_uint32)]
 
 
+QG_MAX_EW = 4
+EW_ADD, EW_SUB, EW_MUL = 1, 2, 3
+
+
+class qgemul_ew_stage(C.Structure):
+    _fields_ = [("op", C.c_uint8), ("x_first", C.c_uint8), ("e_scalar", C.c_uint8), ("reserved", C.c_uint8),
+                ("e", qfmt), ("r", qfmt), ("t", qfmt)]
+
+
+class qgemul_epilogue(C.Structure):
+    _fields_ = [("n_stages", C.c_uint32), ("reserved", C.c_uint32), ("stage", qgemul_ew_stage * QG_MAX_EW), ("d", qfmt)]
+
+
+class qgemul_ep_args(C.Structure):
+    _fields_ = [("e_packed", C.c_void_p * QG_MAX_EW), ("e_scalar", C.c_int64 * QG_MAX_EW)]
+
+
 class qgemul_info(C.Structure):
     _fields_ = [("cls", C.c_int32), ("supported", C.c_int32), ("max_bits", C.c_int32),
                 ("in_bits", C.c_int32 * 2), ("limbs", C.c_int32 * 2), ("kernel", C.c_int32),
@@ -386,3 +403,46 @@ def lower_reduce(e: Qu, rows: int, length: int, levels=None) -> qgemul_desc:
     levels = list(levels) if levels else []
     return lower(e, ONE, reduce_result_type(e, levels, length), rows, 1, length, add_args=levels, mul_args=e,
                  transposed_a=True)
+
+
+# ---- element-wise epilogue: the lazy tensor operators after a Qgemul ----
+
+@dataclass(frozen=True)
+class Ew:
+    """One lazy tensor operator applied to the running value x (QuBLAS.h:3780-3877, front-ends :4079-4100):
+    op in {"add", "sub", "mul"}; e = the other operand's element type; tags = the operator's own toArgs;
+    x_first False means Qop(e, x); scalar True means e is an isScalar operand (autoCall, :3767-3778);
+    into = element type of the tensor the result is assigned to before the next operator (None: the operator's own
+    result type, i.e. no conversion; ignored for the last stage, whose result goes into D)."""
+    op: str
+    e: "Qu"
+    tags: TagLike = None
+    x_first: bool = True
+    scalar: bool = False
+    into: Optional["Qu"] = None
+
+
+def ew_result(x: "Qu", st: Ew) -> "Qu":
+    first, second = (x, st.e) if st.x_first else (st.e, x)
+    return mul_merge(first, second, st.tags) if st.op == "mul" else add_merge(first, second, st.tags)
+
+
+def lower_epilogue(c: "Qu", stages, d: "Qu") -> qgemul_epilogue:
+    """Resolve the chain D = cvt_d(Qop_n(... Qop_1(C, e_1) ..., e_n)) to the C-ABI struct."""
+    stages = list(stages)
+    if len(stages) > QG_MAX_EW:
+        raise ValueError("too many element-wise stages")
+    ep = qgemul_epilogue()
+    ep.n_stages = len(stages)
+    x = c
+    for k, st in enumerate(stages):
+        r = ew_result(x, st)
+        ep.stage[k].op = {"add": EW_ADD, "sub": EW_SUB, "mul": EW_MUL}[st.op]
+        ep.stage[k].x_first = 1 if st.x_first else 0
+        ep.stage[k].e_scalar = 1 if st.scalar else 0
+        ep.stage[k].e = st.e.c()
+        ep.stage[k].r = r.c()
+        x = st.into if (st.into is not None and k + 1 < len(stages)) else r
+        ep.stage[k].t = x.c()
+    ep.d = d.c()
+    return ep

@@ -79,3 +79,27 @@ def case_expected(j, qoracle):
     else:
         arr[:] = v
     return arr
+
+
+def eltwise_cases():
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLD, "ref_eltwise_*.jsonl.gz"))):
+        out.extend(_records(p))
+    return out
+
+
+def eltwise_epilogue(j):
+    """(qgemul_epilogue, C format, [operand arrays]) of a golden element-wise record."""
+    from qublas_amd.desc import Qu, qgemul_epilogue
+    ep = qgemul_epilogue()
+    ep.n_stages = len(j["stages"])
+    ep.d = Qu.from_tuple(j["d"]).c()
+    E = []
+    for k, s in enumerate(j["stages"]):
+        st = ep.stage[k]
+        st.op, st.x_first, st.e_scalar = s["op"], s["x_first"], s["scalar"]
+        st.e = Qu.from_tuple(s["e"]).c()
+        st.r = Qu.from_tuple(s["r"]).c()
+        st.t = Qu.from_tuple(s["t"]).c()
+        E.append(np.asarray(s["E"], dtype=np.int64))
+    return ep, Qu.from_tuple(j["c"]), E
