@@ -190,7 +190,7 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     return QG_OK;
 }
 
-// Where the chain runs (measurements: profiles/r01u_eltwise.jsonl, chain = scale + bias into C's own type):
+// Where the chain runs (measurements: profiles/r01v_eltwise.jsonl, chain = scale + bias into C's own type):
 //   3x3-limb kernel, 4096^3: plain 0.458 ms, chain fused into the kernel's epilogue 0.473, chain as a pass 0.490
 //   single-limb 256^2-tile kernel, 8192^2 x 4096: plain 0.280, fused 0.503, pass 0.436  (the fused epilogue spills:
 //   128 accumulator registers stay live; and with one workgroup per CU the matrix cores idle meanwhile)
