@@ -294,6 +294,19 @@ int qgemul_time_execute_ep(qgemul_plan* p, void* packedD, const void* packedA, c
 int qgemul_run_ep(const qgemul_desc* d, const qgemul_epilogue* ep, void* D, const void* A, const void* B,
                   const void* const* E, const qgemul_opts* o);
 
+/* ---- BitStream export of the result tensor ----
+ * What  BitStream<tensorProcessT, elemProcessT>(C)  returns in the reference (QuBLAS.h:4811-4827; demo main.cpp:9-18):
+ * per element the low (isS + intB + fracB) bits of its raw value, MSB first (:2433-2438), elements in storage order
+ * (column-major), with the element string's chunks of `elem_chunk` characters reversed (r2l<elem_chunk>, :4593-4611)
+ * and the tensor's chunks of `tensor_chunk` elements reversed (r2l<tensor_chunk>, :4738-4752); chunk 0 = l2r.
+ * The element width must be a multiple of elem_chunk and M*N of tensor_chunk (the reference throws / does not terminate
+ * otherwise): QG_EINVAL.  Real tensors only (a complex element's string carries "(re, im)" punctuation, :2553-2556).
+ * QG_BITS_ASCII writes the M*N*width characters '0' / '1'; QG_BITS_PACKED the same stream 8 characters per byte, first
+ * character in bit 7.  For a plan with an epilogue the tensor is D. */
+enum { QG_BITS_ASCII = 0, QG_BITS_PACKED = 1 };
+int64_t qgemul_bitstream_bytes(const qgemul_plan* p, int format);
+int qgemul_export_bitstream(qgemul_plan* p, const void* packedC, int tensor_chunk, int elem_chunk, int format, void* out_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -388,6 +388,41 @@ void qoracle_cproduct(const qgemul_desc* d, const int64_t x[2], const int64_t y[
     out[1] = (int64_t)p[1];
 }
 
+/* ---- BitStream export of a real tensor ----
+ * Restates BitStream<tensorProcessT, elemProcessT>(tensor) (/root/reference/include/QuBLAS.h:4811-4827):
+ *   element string = the low (isS + intB + fracB) bits of the raw value, MSB first (Qu_s::toString :2433-2438);
+ *   elemProcessT  r2l<e>: the element string's e-character chunks in reverse order (SingleString_s :4593-4611, the string
+ *                 length must be a multiple of e); l2r (e = 0): unchanged;
+ *   tensorProcessT r2l<t>: the elements (storage order) in chunks of t, chunks in reverse order, order inside a chunk kept
+ *                 (TensorString_s<r2l<index>,...>::toString :4738-4752; n must be a multiple of t); l2r (t = 0): unchanged.
+ * out receives n * width characters '0' / '1' (no terminator).  Returns 0, or -1 for an invalid chunk. */
+int qoracle_bitstream(qfmt f, int64_t n, const int64_t* x, int tensor_chunk, int elem_chunk, char* out)
+{
+    const int w = (int)f.I + (int)f.F + (f.S ? 1 : 0);
+    if (w <= 0 || w > 64 || tensor_chunk < 0 || elem_chunk < 0) return -1;
+    if (elem_chunk > 0 && w % elem_chunk) return -1;
+    if (tensor_chunk > 0 && n % tensor_chunk) return -1;
+    char es[64], ts[64];
+    for (int64_t pos = 0; pos < n; ++pos) {
+        int64_t src = pos;
+        if (tensor_chunk > 0) {
+            const int64_t nch = n / tensor_chunk, c = pos / tensor_chunk;
+            src = (nch - 1 - c) * tensor_chunk + pos % tensor_chunk;
+        }
+        const uint64_t v = (uint64_t)x[src];
+        for (int j = 0; j < w; ++j) es[j] = ((v >> (w - 1 - j)) & 1) ? '1' : '0';
+        if (elem_chunk > 0) {
+            const int nch = w / elem_chunk;
+            for (int q = 0; q < nch; ++q)
+                for (int r = 0; r < elem_chunk; ++r) ts[q * elem_chunk + r] = es[(nch - 1 - q) * elem_chunk + r];
+            memcpy(out + pos * w, ts, (size_t)w);
+        } else {
+            memcpy(out + pos * w, es, (size_t)w);
+        }
+    }
+    return 0;
+}
+
 /* ---- element-wise epilogue: the lazy tensor operators applied per element after a Qgemul ----
  * Restates MulExpression / AddExpression / SubExpression::operator[] (/root/reference/include/QuBLAS.h:3795-3798,
  * :3828-3831, :3861-3864: Qop<toArgs...>(autoCall(q1, i), autoCall(q2, i)), a scalar operand used as is

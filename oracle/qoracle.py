@@ -65,6 +65,8 @@ def lib() -> C.CDLL:
         L.qoracle_eltwise.restype = C.c_int
         L.qoracle_eltwise.argtypes = [C.POINTER(qgemul_epilogue), qfmt, C.c_int64, C.POINTER(C.c_int64),
                                       C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.c_int64)]
+        L.qoracle_bitstream.restype = C.c_int
+        L.qoracle_bitstream.argtypes = [qfmt, C.c_int64, C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_char_p]
         L.qoracle_elem_bytes.restype = C.c_int
         L.qoracle_elem_bytes.argtypes = [C.POINTER(qfmt), C.c_int]
         L.qoracle_imag_offset.restype = C.c_int
@@ -123,3 +125,15 @@ def eltwise(ep: qgemul_epilogue, c: Qu, x: np.ndarray, E) -> np.ndarray:
     if st != 0:
         raise RuntimeError(f"qoracle_eltwise failed: {st}")
     return out
+
+
+def bitstream(f: Qu, x: np.ndarray, tensor_chunk: int = 0, elem_chunk: int = 0) -> bytes:
+    """CPU restatement of BitStream<tensorProcessT, elemProcessT>(tensor): x = raw values in storage order; chunk 0 = l2r,
+    k > 0 = r2l<k>.  Returns the '0'/'1' characters."""
+    x = np.ascontiguousarray(x, dtype=np.int64)
+    w = f.intBits + f.fracBits + (1 if f.isSigned else 0)
+    buf = C.create_string_buffer(int(x.size) * w)
+    st = lib().qoracle_bitstream(f.c(), x.size, x.ctypes.data_as(C.POINTER(C.c_int64)), tensor_chunk, elem_chunk, buf)
+    if st != 0:
+        raise ValueError("invalid chunk for this tensor / element width")
+    return buf.raw

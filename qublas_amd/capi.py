@@ -21,6 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libqugemm.so")
 QG_OK, QG_EINVAL, QG_EUNSUPPORTED, QG_EHIP, QG_ERCCL, QG_ERANGE, QG_ENOGPU = 0, -1, -2, -3, -4, -5, -6
 OPT_FORCE_TREE, OPT_CHECK_RANGE, OPT_GENERIC_TREE, OPT_RUNTIME_MODES, OPT_FUSED_EPILOGUE, OPT_UNFUSED_EPILOGUE = 1, 2, 4, 8, 16, 32
 OPERAND_A, OPERAND_B, OPERAND_C = 0, 1, 2
+BITS_ASCII, BITS_PACKED = 0, 1
 KERNEL_NAMES = {0: "none", 1: "mfma_i8", 2: "mfma_i8_limb", 3: "tree_i32", 4: "tree_i64", 5: "tree_cplx", 6: "tree_cplx_i32", 7: "mfma_cplx"}
 
 EXPORTS = [
@@ -31,6 +32,7 @@ EXPORTS = [
     "qgemul_pack", "qgemul_pack_f64", "qgemul_unpack_c", "qgemul_execute", "qgemul_fill_packed", "qgemul_time_execute",
     "qgemul_classify_ep", "qgemul_plan_create_ep", "qgemul_packed_e_bytes", "qgemul_pack_e", "qgemul_execute_ep",
     "qgemul_time_execute_ep", "qgemul_run_ep", "qgemul_plan_fuses_epilogue",
+    "qgemul_bitstream_bytes", "qgemul_export_bitstream",
 ]
 
 _lib = None
@@ -85,6 +87,9 @@ def lib() -> C.CDLL:
         L.qgemul_classify_ep.argtypes = [pd, pe, u32, C.POINTER(qgemul_info)]
         L.qgemul_plan_create_ep.argtypes = [vp, pd, pe, u32, C.POINTER(vp)]
         L.qgemul_plan_fuses_epilogue.argtypes = [vp]
+        L.qgemul_bitstream_bytes.argtypes = [vp, C.c_int]
+        L.qgemul_bitstream_bytes.restype = i64
+        L.qgemul_export_bitstream.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
         L.qgemul_packed_e_bytes.argtypes = [vp, C.c_int]
         L.qgemul_packed_e_bytes.restype = i64
         L.qgemul_pack_e.argtypes = [vp, C.c_int, vp, i64, vp]
@@ -211,6 +216,13 @@ class Plan:
 
     def execute(self, pC: int, pA: int, pB: int):
         _chk(lib().qgemul_execute(self.h, C.c_void_p(pC), C.c_void_p(pA), C.c_void_p(pB)), "qgemul_execute")
+
+    def bitstream_bytes(self, fmt: int = 0) -> int:
+        return int(lib().qgemul_bitstream_bytes(self.h, fmt))
+
+    def export_bitstream(self, pC: int, out_dev: int, tensor_chunk: int = 0, elem_chunk: int = 0, fmt: int = 0):
+        _chk(lib().qgemul_export_bitstream(self.h, C.c_void_p(pC), tensor_chunk, elem_chunk, fmt, C.c_void_p(out_dev)),
+             "qgemul_export_bitstream")
 
     def fuses_epilogue(self) -> bool:
         return bool(lib().qgemul_plan_fuses_epilogue(self.h))

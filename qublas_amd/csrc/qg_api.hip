@@ -603,6 +603,42 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
     }
 }
 
+static int result_width(const qgemul_plan* p)
+{
+    const qfmt f = p->has_ep ? p->ep.d : p->desc.c[0];
+    return (int)f.I + (int)f.F + (f.S ? 1 : 0);
+}
+
+int64_t qgemul_bitstream_bytes(const qgemul_plan* p, int format)
+{
+    if (!p || p->desc.is_complex) return 0;
+    const int64_t bits = p->desc.M * p->desc.N * (int64_t)result_width(p);
+    // the packed form is written with 32-bit atomics: sized to whole words
+    return format == QG_BITS_PACKED ? ((bits + 7) / 8 + 3) / 4 * 4 : bits;
+}
+
+int qgemul_export_bitstream(qgemul_plan* p, const void* packedC, int tensor_chunk, int elem_chunk, int format, void* out_dev)
+{
+    if (!p || !packedC || !out_dev || (format != QG_BITS_ASCII && format != QG_BITS_PACKED)) return QG_EINVAL;
+    if (p->desc.is_complex) return QG_EUNSUPPORTED;
+    const int w = result_width(p);
+    const int64_t n = p->desc.M * p->desc.N;
+    if (w <= 0 || tensor_chunk < 0 || elem_chunk < 0) return QG_EINVAL;
+    if (elem_chunk > 0 && w % elem_chunk) return QG_EINVAL;      // the reference throws (QuBLAS.h:4599-4602)
+    if (tensor_chunk > 0 && n % tensor_chunk) return QG_EINVAL;  // the reference's loop does not terminate (:4745)
+    QBitsArgs a;
+    memset(&a, 0, sizeof a);
+    a.c = p->pc;
+    a.packed = (const char*)packedC;
+    a.out = (char*)out_dev;
+    a.width = w;
+    a.tensor_chunk = tensor_chunk;
+    a.elem_chunk = elem_chunk;
+    a.packed_bits = format == QG_BITS_PACKED;
+    QG_HIP(qg_launch_bitstream(a, p->ctx->stream));
+    return QG_OK;
+}
+
 static int time_execute(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB, const qgemul_ep_args* args,
                         int warmup, int iters, float* avg_ms)
 {

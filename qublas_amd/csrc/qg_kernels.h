@@ -103,3 +103,12 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st);
 // element-wise epilogue as its own pass (kernels that do not fuse it) and the operand packer; see qg_eltwise.h
 hipError_t qg_launch_eltwise(const QEltwiseArgs& g, hipStream_t st);
 hipError_t qg_launch_pack_e(const QCGeom& c, const void* src, int64_t ld, int src_bytes, void* dst, int ebytes, hipStream_t st);
+
+// BitStream export of packed C (qg_pack.hip): n = M*N elements of `width` characters each
+struct QBitsArgs {
+    QCGeom c;
+    const char* packed;
+    char* out;
+    int32_t width, tensor_chunk, elem_chunk, packed_bits;
+};
+hipError_t qg_launch_bitstream(const QBitsArgs& a, hipStream_t st);

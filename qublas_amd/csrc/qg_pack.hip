@@ -184,7 +184,61 @@ __global__ __launch_bounds__(256) void k_cplx_combine(QCplxCombine g)
     store_container(g.C, g.M * g.N + m * g.N + n, g.cbytes, qg_step<int64_t>(im, g.to_c[1]));
 }
 
+// BitStream export (QuBLAS.h:4811-4827): thread = one output element position.  pos -> source element (tensor-level
+// chunk reversal) -> its raw value -> `width` characters, MSB first, element-level chunk reversal -> out[pos*width ...].
+// ASCII: consecutive lanes write consecutive width-byte runs.  Packed: the stream is M*N*width bits; a thread ORs its
+// bits into the bytes they fall into (atomicOr on 32-bit words, output zeroed by the launcher).
+__global__ __launch_bounds__(256) void k_bitstream(QBitsArgs g)
+{
+    const int64_t n = g.c.M * g.c.N;
+    const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pos >= n) return;
+    int64_t src = pos;
+    if (g.tensor_chunk > 0) {
+        const int64_t nch = n / g.tensor_chunk, ch = pos / g.tensor_chunk;
+        src = (nch - 1 - ch) * g.tensor_chunk + pos % g.tensor_chunk;
+    }
+    const uint64_t v = (uint64_t)load_container(g.packed, qg_c_index(g.c, 0, src % g.c.M, src / g.c.M), g.c.cbytes);
+    const int w = g.width;
+    // bits of the element string after the element-level reversal, first character in bit w-1 of `e`
+    uint64_t e = 0;
+    if (g.elem_chunk > 0) {
+        const int nch = w / g.elem_chunk;
+        const uint64_t mask = g.elem_chunk >= 64 ? ~0ull : ((1ull << g.elem_chunk) - 1);
+        for (int q = 0; q < nch; ++q)   // output chunk q (from the left) = source chunk nch-1-q (from the left)
+            e |= ((v >> (q * g.elem_chunk)) & mask) << ((nch - 1 - q) * g.elem_chunk);
+    } else {
+        e = w >= 64 ? v : (v & ((1ull << w) - 1));
+    }
+    if (!g.packed_bits) {
+        char* o = g.out + pos * w;
+        for (int j = 0; j < w; ++j) o[j] = ((e >> (w - 1 - j)) & 1) ? '1' : '0';
+        return;
+    }
+    uint32_t* o32 = (uint32_t*)g.out;
+    const int64_t b0 = pos * w;
+    for (int j = 0; j < w; ++j) {
+        if (!((e >> (w - 1 - j)) & 1)) continue;
+        const int64_t b = b0 + j;                    // stream bit index: byte b/8, bit 7 - b%8 (little-endian words)
+        atomicOr(o32 + (b >> 5), 1u << (((b >> 3) & 3) * 8 + (7 - (b & 7))));
+    }
+}
+
 } // namespace
+
+hipError_t qg_launch_bitstream(const QBitsArgs& a, hipStream_t st)
+{
+    const int64_t n = a.c.M * a.c.N;
+    if (n <= 0) return hipSuccess;
+    const int64_t blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
+    if (a.packed_bits) {
+        const int64_t bytes = ((n * a.width + 7) / 8 + 3) / 4 * 4;
+        if (hipError_t e = hipMemsetAsync(a.out, 0, (size_t)bytes, st); e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_bitstream, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
 
 hipError_t qg_launch_cplx_combine(const QCplxCombine& g, hipStream_t st)
 {

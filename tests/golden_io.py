@@ -103,3 +103,10 @@ def eltwise_epilogue(j):
         st.t = Qu.from_tuple(s["t"]).c()
         E.append(np.asarray(s["E"], dtype=np.int64))
     return ep, Qu.from_tuple(j["c"]), E
+
+
+def bitstream_cases():
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLD, "ref_bitstream_*.jsonl.gz"))):
+        out.extend(_records(p))
+    return out
