@@ -396,7 +396,19 @@ template <class T, class... Rest> struct pick_ta<T, Rest...> : pick_ta<Rest...> 
 
 // lower a Qgemul call to the C-ABI descriptor (pure host computation, no device access)
 template <typename... Tags, size_t CM, size_t CN, size_t AR, size_t AC, size_t BKd, size_t BN, class EC, class EA, class EB>
-qgemul_desc Qgemul_lower(const Qu_s<dim<CM, CN>, EC>&, const Qu_s<dim<AR, AC>, EA>&, const Qu_s<dim<BKd, BN>, EB>&)
+qgemul_desc Qgemul_lower_types(std::type_identity<Qu_s<dim<CM, CN>, EC>>, std::type_identity<Qu_s<dim<AR, AC>, EA>>,
+                               std::type_identity<Qu_s<dim<BKd, BN>, EB>>);
+
+template <typename... Tags, class TC, class TA, class TB>
+qgemul_desc Qgemul_lower(const TC&, const TA&, const TB&)
+{
+    return Qgemul_lower_types<Tags...>(std::type_identity<TC>{}, std::type_identity<TA>{}, std::type_identity<TB>{});
+}
+
+// (only the operand TYPES enter the lowering)
+template <typename... Tags, size_t CM, size_t CN, size_t AR, size_t AC, size_t BKd, size_t BN, class EC, class EA, class EB>
+qgemul_desc Qgemul_lower_types(std::type_identity<Qu_s<dim<CM, CN>, EC>>, std::type_identity<Qu_s<dim<AR, AC>, EA>>,
+                               std::type_identity<Qu_s<dim<BKd, BN>, EB>>)
 {
     using namespace detail;
     constexpr bool ta = pick_ta<Tags...>::value;
@@ -443,6 +455,96 @@ void Qgemul(TC& C, const TA& A, const TB& B)
     const qgemul_desc d = Qgemul_lower<Tags...>(C, A, B);
     const int st = qgemul_run(&d, C.data.data(), A.data.data(), B.data.data(), nullptr);
     if (st != QG_OK) throw std::runtime_error(std::string("Qgemul: ") + qgemul_strerror(st));
+}
+
+// ------------------------------------------------------------------ element-wise operators after the GEMM (SURVEY.md §8-f "next" #2)
+// The reference's lazy tensor operators Qmul / Qadd / Qsub<tags…>(tensor, tensor | scalar) (QuBLAS.h:3780-3877,
+// front-ends :4079-4100) applied to a Qgemul result:
+//     Qgemul<…>(C, A, B);   Qu<dim<M,N>, T1> t = Qmul<t1…>(C, s);   Qu<dim<M,N>, DT> D = Qadd<t2…>(t, Bias);
+// written as ONE call that never materialises C or t:
+//     Qgemul<…, QgemulResult<CT>>(D, A, B, ThenMul<T1, t1…>(s), ThenAdd<void, t2…>(Bias));
+// QgemulResult<CT> names the element type the Qgemul result WOULD have (C's type above).  Then{Mul,Add,Sub}<Into, tags…>(e)
+// is Qop<tags…>(x, e) with x the running value; ThenRsub is Qsub<tags…>(e, x).  Into = the element type of the tensor
+// the operator's result is assigned to before the next operator (void: the operator's own result type); the last
+// operator's result is assigned to D.  e is a tensor of D's shape or a scalar.  Real GEMMs only.
+template <class CT> struct QgemulResult {};
+
+namespace detail {
+template <int OP, bool XFIRST, class Into, class Operand, typename... Tags>
+struct EwStage {
+    const Operand& e;
+    static constexpr int op = OP;
+    static constexpr bool x_first = XFIRST;
+    static constexpr bool scalar = requires { Operand::fmt; };   // scalars carry a format, tensors an elem_t
+    static constexpr Fmt efmt = [] { if constexpr (requires { Operand::fmt; }) return Operand::fmt; else return Operand::elem_t::fmt; }();
+    static constexpr Fmt result(Fmt x)
+    {
+        const Fmt a = XFIRST ? x : efmt, b = XFIRST ? efmt : x;
+        return OP == QG_EW_MUL ? merge_mul(a, b, parse<Tags...>::value) : merge_add(a, b, parse<Tags...>::value);
+    }
+    static constexpr Fmt into(Fmt r) { if constexpr (std::is_void_v<Into>) return r; else return Into::fmt; }
+};
+template <class... Tags> struct pick_result { using type = void; };
+template <class CT, class... Rest> struct pick_result<QgemulResult<CT>, Rest...> { using type = CT; };
+template <class T, class... Rest> struct pick_result<T, Rest...> : pick_result<Rest...> {};
+
+template <class... Stages>
+constexpr qgemul_epilogue lower_chain(Fmt c, Fmt d)
+{
+    static_assert(sizeof...(Stages) <= QG_MAX_EW, "at most QG_MAX_EW element-wise operators");
+    qgemul_epilogue ep{};
+    ep.n_stages = sizeof...(Stages);
+    Fmt x = c;
+    uint32_t k = 0;
+    ([&] {
+        const Fmt r = Stages::result(x);
+        ep.stage[k].op = uint8_t(Stages::op);
+        ep.stage[k].x_first = Stages::x_first;
+        ep.stage[k].e_scalar = Stages::scalar;
+        ep.stage[k].e = Stages::efmt.c();
+        ep.stage[k].r = r.c();
+        x = Stages::into(r);
+        ep.stage[k].t = x.c();
+        ++k;
+    }(), ...);
+    ep.d = d.c();
+    return ep;
+}
+} // namespace detail
+
+template <class Into = void, typename... Tags, class Operand> auto ThenMul(const Operand& e) { return detail::EwStage<QG_EW_MUL, true, Into, Operand, Tags...>{e}; }
+template <class Into = void, typename... Tags, class Operand> auto ThenAdd(const Operand& e) { return detail::EwStage<QG_EW_ADD, true, Into, Operand, Tags...>{e}; }
+template <class Into = void, typename... Tags, class Operand> auto ThenSub(const Operand& e) { return detail::EwStage<QG_EW_SUB, true, Into, Operand, Tags...>{e}; }
+template <class Into = void, typename... Tags, class Operand> auto ThenRsub(const Operand& e) { return detail::EwStage<QG_EW_SUB, false, Into, Operand, Tags...>{e}; }
+
+// the chain's C-ABI form (pure host computation)
+template <typename... Tags, class TD, class... Stages>
+constexpr qgemul_epilogue Qgemul_lower_epilogue(const TD&, const Stages&...)
+{
+    using CT = typename detail::pick_result<Tags...>::type;
+    static_assert(!std::is_void_v<CT>, "Qgemul with element-wise operators needs QgemulResult<CT>: the element type of the Qgemul result");
+    static_assert(!CT::is_complex && !TD::elem_t::is_complex, "element-wise operators: real GEMMs only");
+    return detail::lower_chain<Stages...>(CT::fmt, TD::elem_t::fmt);
+}
+
+// D = the element-wise chain applied to A' * B
+template <typename... Tags, class TD, class TA, class TB, class S0, class... Stages>
+void Qgemul(TD& D, const TA& A, const TB& B, const S0& s0, const Stages&... st)
+{
+    using CT = typename detail::pick_result<Tags...>::type;
+    static_assert(!std::is_void_v<CT>, "Qgemul with element-wise operators needs QgemulResult<CT>");
+    const qgemul_desc d = Qgemul_lower_types<Tags...>(std::type_identity<Qu_s<typename TD::size, CT>>{}, std::type_identity<TA>{}, std::type_identity<TB>{});
+    const qgemul_epilogue ep = Qgemul_lower_epilogue<Tags...>(D, s0, st...);
+    auto ptr = [](const auto& stage) -> const void* {
+        if constexpr (std::remove_cvref_t<decltype(stage)>::scalar) return &stage.e.data;
+        else {
+            static_assert(std::is_same_v<typename std::remove_cvref_t<decltype(stage.e)>::size, typename TD::size>, "a tensor operand has D's shape");
+            return stage.e.data.data();
+        }
+    };
+    const void* E[QG_MAX_EW] = {ptr(s0), ptr(st)...};
+    const int rc = qgemul_run_ep(&d, &ep, D.data.data(), A.data.data(), B.data.data(), E, nullptr);
+    if (rc != QG_OK) throw std::runtime_error(std::string("Qgemul: ") + qgemul_strerror(rc));
 }
 
 // ------------------------------------------------------------------ Qreduce (SURVEY.md §8-f "next" #1)

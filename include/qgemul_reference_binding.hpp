@@ -145,7 +145,8 @@ void fill_levels(qgemul_desc& d)
 
 // lower a Qgemul call on reference tensor types to the C-ABI descriptor (no device access)
 template <typename... Tags, size_t CM, size_t CN, size_t AR, size_t AC, size_t BK, size_t BN, class EC, class EA, class EB>
-qgemul_desc Qgemul_lower(const Qu_s<dim<CM, CN>, EC>&, const Qu_s<dim<AR, AC>, EA>&, const Qu_s<dim<BK, BN>, EB>&)
+qgemul_desc Qgemul_lower_types(std::type_identity<Qu_s<dim<CM, CN>, EC>>, std::type_identity<Qu_s<dim<AR, AC>, EA>>,
+                               std::type_identity<Qu_s<dim<BK, BN>, EB>>)
 {
     using namespace qgemul_detail;
     constexpr bool ta = pick_ta<Tags...>::value;
@@ -170,6 +171,12 @@ qgemul_desc Qgemul_lower(const Qu_s<dim<CM, CN>, EC>&, const Qu_s<dim<AR, AC>, E
     return d;
 }
 
+template <typename... Tags, class TC, class TA, class TB>
+qgemul_desc Qgemul_lower(const TC&, const TA&, const TB&)
+{
+    return Qgemul_lower_types<Tags...>(std::type_identity<TC>{}, std::type_identity<TA>{}, std::type_identity<TB>{});
+}
+
 // the README entry point: C = A' * B with per-product and per-tree-node quantisation
 template <typename... Tags, class TC, class TA, class TB>
 void Qgemul(TC& C, const TA& A, const TB& B)
@@ -177,6 +184,88 @@ void Qgemul(TC& C, const TA& A, const TB& B)
     const qgemul_desc d = Qgemul_lower<Tags...>(C, A, B);
     const int st = qgemul_run(&d, C.data.data(), A.data.data(), B.data.data(), nullptr);
     if (st != QG_OK) throw std::runtime_error(std::string("Qgemul: ") + qgemul_strerror(st));
+}
+
+// ---- element-wise operators after the GEMM (the header's lazy tensor operators, QuBLAS.h:3780-3877, :4079-4100) ----
+//     Qgemul<…>(C, A, B);   Qu<dim<M,N>, T1> t = Qmul<t1…>(C, s);   Qu<dim<M,N>, DT> D = Qadd<t2…>(t, Bias);
+// as ONE call that never stores C or t:
+//     Qgemul<…, QgemulResult<CT>>(D, A, B, ThenMul<T1, t1…>(s), ThenAdd<void, t2…>(Bias));
+// Every operator's result type is decltype of the header's own scalar Qmul / Qadd / Qsub<tags…> on the running element
+// type and the operand's element type, so the chain resolves exactly as the three statements above do.
+template <class CT> struct QgemulResult {};
+
+namespace qgemul_detail {
+template <int OP, bool XFIRST, class Into, class Operand, typename... Tags>
+struct EwStage {
+    const Operand& e;
+    static constexpr int op = OP;
+    static constexpr bool x_first = XFIRST;
+    static constexpr bool scalar = isScalar<Operand>;
+    template <class O, bool = isScalar<O>> struct elem { using type = O; };
+    template <class O> struct elem<O, false> { using type = typename O::elem_t; };
+    using e_t = typename elem<Operand>::type;
+    template <class X> static auto apply(const X& x, const e_t& y)
+    {
+        if constexpr (OP == QG_EW_MUL) { if constexpr (XFIRST) return Qmul<Tags...>(x, y); else return Qmul<Tags...>(y, x); }
+        else if constexpr (OP == QG_EW_ADD) { if constexpr (XFIRST) return Qadd<Tags...>(x, y); else return Qadd<Tags...>(y, x); }
+        else { if constexpr (XFIRST) return Qsub<Tags...>(x, y); else return Qsub<Tags...>(y, x); }
+    }
+    template <class X> using r_t = decltype(apply(std::declval<X>(), std::declval<e_t>()));
+    template <class X> using next_t = std::conditional_t<std::is_void_v<Into>, r_t<X>, Into>;
+};
+template <class... Tags> struct pick_result { using type = void; };
+template <class CT, class... Rest> struct pick_result<QgemulResult<CT>, Rest...> { using type = CT; };
+template <class T, class... Rest> struct pick_result<T, Rest...> : pick_result<Rest...> {};
+
+template <class X> void fill_chain(qgemul_epilogue&, uint32_t) {}
+template <class X, class S0, class... Ss>
+void fill_chain(qgemul_epilogue& ep, uint32_t k)
+{
+    using r_t = typename S0::template r_t<X>;
+    using n_t = typename S0::template next_t<X>;
+    ep.stage[k].op = uint8_t(S0::op);
+    ep.stage[k].x_first = S0::x_first;
+    ep.stage[k].e_scalar = S0::scalar;
+    ep.stage[k].e = fmt_of<typename S0::e_t>();
+    ep.stage[k].r = fmt_of<r_t>();
+    ep.stage[k].t = fmt_of<n_t>();
+    fill_chain<n_t, Ss...>(ep, k + 1);
+}
+} // namespace qgemul_detail
+
+template <class Into = void, typename... Tags, class Operand> auto ThenMul(const Operand& e) { return qgemul_detail::EwStage<QG_EW_MUL, true, Into, Operand, Tags...>{e}; }
+template <class Into = void, typename... Tags, class Operand> auto ThenAdd(const Operand& e) { return qgemul_detail::EwStage<QG_EW_ADD, true, Into, Operand, Tags...>{e}; }
+template <class Into = void, typename... Tags, class Operand> auto ThenSub(const Operand& e) { return qgemul_detail::EwStage<QG_EW_SUB, true, Into, Operand, Tags...>{e}; }
+template <class Into = void, typename... Tags, class Operand> auto ThenRsub(const Operand& e) { return qgemul_detail::EwStage<QG_EW_SUB, false, Into, Operand, Tags...>{e}; }
+
+template <typename... Tags, class TD, class... Stages>
+qgemul_epilogue Qgemul_lower_epilogue(const TD&, const Stages&...)
+{
+    using CT = typename qgemul_detail::pick_result<Tags...>::type;
+    static_assert(!std::is_void_v<CT>, "Qgemul with element-wise operators needs QgemulResult<CT>: the element type of the Qgemul result");
+    static_assert(sizeof...(Stages) <= QG_MAX_EW, "at most QG_MAX_EW element-wise operators");
+    static_assert(!CT::is_complex && !TD::elem_t::is_complex, "element-wise operators: real GEMMs only");
+    qgemul_epilogue ep{};
+    ep.n_stages = sizeof...(Stages);
+    qgemul_detail::fill_chain<CT, Stages...>(ep, 0);
+    ep.d = qgemul_detail::fmt_of<typename TD::elem_t>();
+    return ep;
+}
+
+template <typename... Tags, class TD, class TA, class TB, class S0, class... Stages>
+void Qgemul(TD& D, const TA& A, const TB& B, const S0& s0, const Stages&... st)
+{
+    using CT = typename qgemul_detail::pick_result<Tags...>::type;
+    static_assert(!std::is_void_v<CT>, "Qgemul with element-wise operators needs QgemulResult<CT>");
+    const qgemul_desc d = Qgemul_lower_types<Tags...>(std::type_identity<Qu_s<typename TD::size, CT>>{}, std::type_identity<TA>{}, std::type_identity<TB>{});
+    const qgemul_epilogue ep = Qgemul_lower_epilogue<Tags...>(D, s0, st...);
+    auto ptr = [](const auto& stage) -> const void* {
+        if constexpr (std::remove_cvref_t<decltype(stage)>::scalar) return &stage.e.data.data;   // ArbiInt<N>::data, QuBLAS.h:353
+        else return stage.e.data.data();
+    };
+    const void* E[QG_MAX_EW] = {ptr(s0), ptr(st)...};
+    const int rc = qgemul_run_ep(&d, &ep, D.data.data(), A.data.data(), B.data.data(), E, nullptr);
+    if (rc != QG_OK) throw std::runtime_error(std::string("Qgemul: ") + qgemul_strerror(rc));
 }
 
 } // namespace QuBLAS

@@ -95,5 +95,20 @@ int main()
     if (q2.toDouble() != 16.0) return 1;
     Qu<dim<4, 4>, e43> m1 = {1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0, 9.0, 10.0, 11.0, 12.0, 13.0, 14.0, 15.0, 15.5};
     if (m1[1, 2].toDouble() != 10.0) return 2;  // column-major, like the reference
+    {   // element-wise chains: the operators of three golden cases (tests/golden/ref_eltwise_*)
+        using c238 = Qu<intBits<23>, fracBits<8>>;
+        using b106 = Qu<intBits<10>, fracBits<6>>;
+        using s34 = Qu<intBits<3>, fracBits<4>>;
+        using d124 = Qu<intBits<12>, fracBits<4>, QuMode<RND::CONV>, OfMode<SAT::SMGN>>;
+        using d88z = Qu<intBits<8>, fracBits<8>, QuMode<TRN::TCPL>, OfMode<SAT::ZERO>>;
+        using d62w = Qu<intBits<6>, fracBits<2>, QuMode<RND::ZERO>, OfMode<WRP::TCPL>>;
+        Qu<dim<4, 4>, d124> D;
+        Qu<dim<4, 4>, b106> Bias;
+        s34 s;
+        print_epilogue("scale_then_bias", Qgemul_lower_epilogue<QgemulResult<c238>>(D, ThenMul<Qu<intBits<24>, fracBits<8>>, intBits<24>, fracBits<8>>(s), ThenAdd<>(Bias)));
+        print_epilogue("scale_into_narrow_then_bias", Qgemul_lower_epilogue<QgemulResult<c238>>(D, ThenMul<d88z>(s), ThenAdd<void, d124>(Bias)));
+        Qu<dim<4, 4>, d62w> D2;
+        print_epilogue("sub_efirst_tags_wrap", Qgemul_lower_epilogue<QgemulResult<c238>>(D2, ThenRsub<void, fracBits<2>, QuMode<RND::CONV>>(Bias)));
+    }
     return 0;
 }

@@ -19,3 +19,15 @@ inline void print_desc(const char* name, const qgemul_desc& d)
     for (unsigned l = 0; l < d.n_levels; ++l) { if (l) std::printf(","); std::printf("["); print_fmt(d.level[0][l]); std::printf(","); print_fmt(d.level[1][l]); std::printf("]"); }
     std::printf("]}\n");
 }
+
+// an element-wise chain in the shape of the golden records of tests/golden/ref_eltwise_*
+inline void print_epilogue(const char* name, const qgemul_epilogue& ep)
+{
+    std::printf("{\"epilogue\":\"%s\",\"stages\":[", name);
+    for (unsigned k = 0; k < ep.n_stages; ++k) {
+        const qgemul_ew_stage& s = ep.stage[k];
+        std::printf("%s{\"op\":%d,\"x_first\":%d,\"scalar\":%d,\"e\":", k ? "," : "", s.op, s.x_first, s.e_scalar);
+        print_fmt(s.e); std::printf(",\"r\":"); print_fmt(s.r); std::printf(",\"t\":"); print_fmt(s.t); std::printf("}");
+    }
+    std::printf("],\"d\":"); print_fmt(ep.d); std::printf("}\n");
+}

@@ -57,5 +57,20 @@ int main()
         probe<cw, c55, c55, 4, 4, 8, false, QgemulMulArgs<BasicComplexMul<intBits<12>, OfMode<SAT::ZERO>, bdT<tB>>>>("c55_basic_loosetags_4x4x8_full");
         probe<cw, c55, c55, 8, 8, 64, false>("c55_basic_default_8x8x64_full_wideC");
     }
+    {   // element-wise chains: the operators of three golden cases (tests/golden/ref_eltwise_*), resolved by the binding
+        using c238 = Qu<intBits<23>, fracBits<8>>;
+        using b106 = Qu<intBits<10>, fracBits<6>>;
+        using s34 = Qu<intBits<3>, fracBits<4>>;
+        using d124 = Qu<intBits<12>, fracBits<4>, QuMode<RND::CONV>, OfMode<SAT::SMGN>>;
+        using d88z = Qu<intBits<8>, fracBits<8>, QuMode<TRN::TCPL>, OfMode<SAT::ZERO>>;
+        using d62w = Qu<intBits<6>, fracBits<2>, QuMode<RND::ZERO>, OfMode<WRP::TCPL>>;
+        Qu<dim<4, 4>, d124> D;
+        Qu<dim<4, 4>, b106> Bias;
+        s34 s;
+        print_epilogue("scale_then_bias", Qgemul_lower_epilogue<QgemulResult<c238>>(D, ThenMul<Qu<intBits<24>, fracBits<8>>, intBits<24>, fracBits<8>>(s), ThenAdd<>(Bias)));
+        print_epilogue("scale_into_narrow_then_bias", Qgemul_lower_epilogue<QgemulResult<c238>>(D, ThenMul<d88z>(s), ThenAdd<void, d124>(Bias)));
+        Qu<dim<4, 4>, d62w> D2;
+        print_epilogue("sub_efirst_tags_wrap", Qgemul_lower_epilogue<QgemulResult<c238>>(D2, ThenRsub<void, fracBits<2>, QuMode<RND::CONV>>(Bias)));
+    }
     return 0;
 }

@@ -53,3 +53,41 @@ def test_standalone_header_runs_on_gpu(tmp_path):
     assert _check(lines) == 4
     q = [json.loads(l) for l in lines if '"qreduce"' in l]
     assert q and q[0]["C"] == [80]
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs AMD clang (C++23)")
+def test_standalone_header_elementwise_chain_on_gpu(tmp_path, oracle):
+    """Qgemul<…, QgemulResult<CT>>(D, A, B, ThenMul<…>(s), ThenAdd<>(Bias), ThenRsub<…>(off)) through QuBLAS_amd.h:
+    the C++ lowering must resolve the formats the Python mirror resolves, and D must be the oracle's."""
+    import numpy as np
+    from qublas_amd.desc import Ew, Qu, RND, SAT, TRN, Tags, lower, lower_epilogue
+    exe = tmp_path / "amd_header_ep_run"
+    lib = os.path.join(ROOT, "qublas_amd")
+    subprocess.check_call([CLANG, "-std=c++23", "-O1", "-w", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "binding", "amd_header_ep_run.cpp"), "-o", str(exe), "-L" + lib, "-lqugemm",
+                           "-Wl,-rpath," + lib])
+    r = json.loads(subprocess.check_output([str(exe)], text=True).strip().splitlines()[-1])
+    assert "error" not in r, r
+    e88 = Qu(8, 8, True, TRN.TCPL, SAT.ZERO)
+    ct, t1, bt, st = Qu(15, 8), Qu(16, 8), Qu(10, 6), Qu(3, 3)
+    dt = Qu(12, 4, True, RND.CONV, SAT.SMGN)
+    M, N, K = r["M"], r["N"], r["K"]
+    d = lower(e88, e88, ct, M, N, K, mul_args=Tags(17, 16), add_args=[Qu(29, 16)])
+    ep = lower_epilogue(ct, [Ew("mul", st, Tags(16, 8), scalar=True, into=t1), Ew("add", bt),
+                             Ew("sub", st, Tags(QuMode=RND.CONV), x_first=False, scalar=True)], dt)
+    tup = lambda f: [f.I, f.F, f.S, f.Q, f.O]
+    assert r["n_stages"] == 3 and r["d"] == tup(ep.d)
+    for k in range(3):
+        assert r[f"r{k}"] == tup(ep.stage[k].r) and r[f"op{k}"] == [ep.stage[k].op, ep.stage[k].x_first, ep.stage[k].e_scalar]
+        if k < 2:
+            assert r[f"t{k}"] == tup(ep.stage[k].t)
+    i = np.arange(M * K, dtype=np.uint64)
+    A = ((i * np.uint64(2654435761)) % np.uint64(8192)).astype(np.int64) - 4096
+    i = np.arange(K * N, dtype=np.uint64)
+    B = ((i * np.uint64(40503) + np.uint64(7)) % np.uint64(8192)).astype(np.int64) - 4096
+    i = np.arange(M * N, dtype=np.uint64)
+    bias = ((i * np.uint64(97)) % np.uint64(131072)).astype(np.int64) - 65536
+    C = oracle.gemm(d, A.astype(np.int32), B.astype(np.int32), ct).astype(np.int64)
+    exp = oracle.eltwise(ep, ct, C, [np.array([13]), bias, np.array([-20])])
+    assert r["D"] == exp.tolist()
+    assert len(set(r["D"])) > 20

@@ -110,11 +110,30 @@ def test_reference_binding_lowering(tmp_path):
     """include/qgemul_reference_binding.hpp compiled against the REAL reference header."""
     gold = golden_by_name()
     recs = _probe("ref_binding_probe.cpp", ["-I/root/reference/include"], tmp_path)
+    eps = [r for r in recs if "epilogue" in r]
+    recs = [r for r in recs if "epilogue" not in r]
     assert len(recs) >= 12
     for r in recs:
         j = gold[r["name"]]
         for k in KEYS:
             assert r[k] == j[k], (r["name"], k)
+    _check_epilogues(eps)
+
+
+def _check_epilogues(eps):
+    """the Then* front-ends must resolve the operators of the golden element-wise cases to the formats the reference's
+    own tensor operators reported (tests/golden/ref_eltwise_*)"""
+    import golden_io as G
+    gold = {j["name"]: j for j in G.eltwise_cases()}
+    assert len(eps) == 3
+    for r in eps:
+        j = gold[r["epilogue"]]
+        assert r["d"] == j["d"] and len(r["stages"]) == len(j["stages"])
+        for k, (a, b) in enumerate(zip(r["stages"], j["stages"])):
+            for key in ("op", "x_first", "scalar", "e", "r"):
+                assert a[key] == b[key], (r["epilogue"], k, key)
+            if k + 1 < len(j["stages"]):
+                assert a["t"] == b["t"], (r["epilogue"], k)
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="needs AMD clang (C++23)")
@@ -122,8 +141,11 @@ def test_standalone_header_lowering(tmp_path):
     """include/QuBLAS_amd.h (own tag API, no reference header) lowers the same tags to the same formats."""
     gold = golden_by_name()
     recs = _probe("amd_header_probe.cpp", [], tmp_path)
+    eps = [r for r in recs if "epilogue" in r]
+    recs = [r for r in recs if "epilogue" not in r]
     assert len(recs) >= 12
     for r in recs:
         j = gold[r["name"]]
         for k in KEYS:
             assert r[k] == j[k], (r["name"], k)
+    _check_epilogues(eps)
