@@ -495,6 +495,11 @@ QMfmaCfg qg_mfma_pick(int LA, int LB, int64_t M, int64_t N)
         // 256x256 tiles halve the L2->LDS traffic per MAC; use them once they fill the 256 CUs
         const int64_t big = ((M + 255) / 256) * ((N + 255) / 256);
         if (big >= 256) return QMfmaCfg{2, 256, 256, 64};
+        // small problems: 64x64 tiles once 128x128 ones would leave more than half of the 256 CUs without a workgroup
+        // (1024^2: 64 -> 256 workgroups)
+        const int64_t mid = ((M + 127) / 128) * ((N + 127) / 128);
+        static const bool no_small = getenv("QG_NO_SMALL_TILES") != nullptr;   // A/B switch for tools/measure_small.py
+        if (!no_small && mid <= 128 && ((M + 63) / 64) * ((N + 63) / 64) > mid) return QMfmaCfg{5, 64, 64, 64};
         return QMfmaCfg{1, 128, 128, 64};
     }
     return QMfmaCfg{3, 128, 128, 64};
@@ -536,6 +541,7 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
     if (LA == 1 && LB == 1) {
         // single limb: v_mfma_i32_16x16x64_i8 measured 8 % faster than 32x32x32 at the same tiles
         // (0.283 vs 0.308 ms at 8192x8192x4096, profiles/r01n_ablation_mfma_shape.log); QG_ABLATE=32 keeps the other
+        if (a.variant == 5) return launch<1, 1, 64, 2, 2, 1, 1, 3>(a, st);   // 64x64 tiles, one 32x32 MFMA tile per wave
         if (ablation() == 32) return a.variant == 2 ? launch<1, 1, 64, 2, 4, 4, 2, 3>(a, st) : launch<1, 1, 64, 2, 2, 2, 2, 3>(a, st);
         if (a.variant == 2) return launch16<1, 1, 2, 4, 8, 4, true>(a, st);
         return launch<1, 1, 64, 2, 2, 2, 2, 3>(a, st);  // 128x128 tiles (small problems): the 32x32x32 kernel is the faster one there
