@@ -22,7 +22,7 @@ QG_OK, QG_EINVAL, QG_EUNSUPPORTED, QG_EHIP, QG_ERCCL, QG_ERANGE, QG_ENOGPU = 0, 
 OPT_FORCE_TREE, OPT_CHECK_RANGE, OPT_GENERIC_TREE, OPT_RUNTIME_MODES, OPT_FUSED_EPILOGUE, OPT_UNFUSED_EPILOGUE = 1, 2, 4, 8, 16, 32
 OPERAND_A, OPERAND_B, OPERAND_C = 0, 1, 2
 BITS_ASCII, BITS_PACKED = 0, 1
-KERNEL_NAMES = {0: "none", 1: "mfma_i8", 2: "mfma_i8_limb", 3: "tree_i32", 4: "tree_i64", 5: "tree_cplx", 6: "tree_cplx_i32", 7: "mfma_cplx"}
+KERNEL_NAMES = {0: "none", 1: "mfma_i8", 2: "mfma_i8_limb", 3: "tree_i32", 4: "tree_i64", 5: "tree_cplx", 6: "tree_cplx_i32", 7: "mfma_cplx", 8: "gemv_i32"}
 
 EXPORTS = [
     "qgemul_classify", "qgemul_strerror", "qgemul_abi_version", "qgemul_last_hip_error", "qgemul_run",

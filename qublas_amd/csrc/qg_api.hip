@@ -143,7 +143,8 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
         }
     } else {
         const bool fast = !(flags & QG_OPT_GENERIC_TREE);
-        kernel = d->is_complex ? ((an->cplx_fast_ok && fast) ? QG_KERNEL_TREE_CPLX_I32 : QG_KERNEL_TREE_CPLX) : ((an->tree_fast_ok && !(flags & QG_OPT_GENERIC_TREE)) ? QG_KERNEL_TREE_I32 : QG_KERNEL_TREE_I64);
+        kernel = d->is_complex ? ((an->cplx_fast_ok && fast) ? QG_KERNEL_TREE_CPLX_I32 : QG_KERNEL_TREE_CPLX)
+                               : ((an->gemv_ok && fast) ? QG_KERNEL_GEMV_I32 : (an->tree_fast_ok && fast) ? QG_KERNEL_TREE_I32 : QG_KERNEL_TREE_I64);
         *pa = QPackedGeom{d->M, d->K, info->in_bits[0] <= 32 ? 4 : 8, 0, 0, 0};
         *pb = QPackedGeom{d->N, d->K, info->in_bits[1] <= 32 ? 4 : 8, 0, 0, 0};
         pc->Mp = d->M;
@@ -588,6 +589,10 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
         QG_HIP(qg_launch_tree_fast(p->dev_table, (int)p->desc.n_levels, p->an.split_s, p->an.mul24_ok,
                                    (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : p->an.fast_mode, packedA, packedB, packedC,
                                    p->desc.M, p->desc.N, p->desc.K, pcg.cbytes, st));
+        return QG_OK;
+    case QG_KERNEL_GEMV_I32:
+        QG_HIP(qg_launch_gemv(p->dev_table, (int)p->desc.n_levels, p->an.gemv_b_bit, packedA, packedB, packedC, p->desc.M, p->desc.K,
+                              pcg.cbytes, st));
         return QG_OK;
     case QG_KERNEL_TREE_CPLX_I32:
         QG_HIP(qg_launch_tree_cplx_fast(p->dev_table, (int)p->desc.n_levels, packedA, packedB, packedC, p->desc.M, p->desc.N,

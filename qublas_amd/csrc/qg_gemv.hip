@@ -1,0 +1,235 @@
+// qg_gemv.hip — exact tree-order evaluation for ONE output column (N = 1): the batched Qreduce / fixed-point GEMV of
+// SURVEY.md §8-f #1 (Qreduce<L…>(v), /root/reference/include/QuBLAS.h:4960-4990, :5014-5018; as a Qgemul the
+// operand B is the vector, for Qreduce the constant 1).  HBM-bound byte work: every row of packed A (K int32 values) is
+// read once, so the kernel is laid out for coalesced reads and for as few quantising instructions per leaf as the exact
+// tree allows; the GEMM tree kernels would spend a 32-column tile on the single column.
+//
+// One wave owns one row at a time.  A row is consumed in segments of SEG = 64 * CH leaves (CH = 2^q <= 32 per lane):
+//   * the segment is fetched with lane-linear 16-byte loads (fully coalesced) one segment AHEAD into registers, written
+//     to the wave's private LDS image and read back chunk-wise, so that lane j holds the CH CONSECUTIVE leaves
+//     [j*CH, (j+1)*CH) — the image pads every chunk by 16 bytes, which makes the chunk reads bank-conflict free;
+//   * products are quantised per leaf (Qmul, QuBLAS.h:3152-3170) — for a 0/1-valued B of the Qreduce lowering the
+//     product is a select;
+//   * q tree levels run inside the lane on register arrays (the wave-uniform mode switches hoisted around the arrays,
+//     qg_step_all.h), 6 more across the lanes (lane 2s*i takes its partner s lanes up), which leaves the segment's
+//     partial result — a node of level q+6 — in lane 0; segments are combined by a binary counter over the remaining
+//     levels.  Every node is the reference's Qadd of two equal-format children in the reference's order.
+// Requirements (planner): real descriptor, N = 1, K = 2^p >= 256, every value except the unrounded product within 31
+// bits.  When the whole vector is one segment, B is staged once per workgroup in the same padded image; longer
+// vectors are re-read per segment from L2.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "qg_kernels.h"
+#include "qg_step_all.h"
+
+namespace {
+
+struct QGemvArgs {
+    const QTreeTable* tab;
+    const int32_t* A;   // [M][K], K contiguous
+    const int32_t* B;   // [K]
+    char* C;            // [M] containers of cbytes
+    int64_t M, K;
+    int32_t cbytes, n_levels, b_is_bit, pad_;
+};
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// The per-level table is read through the CONSTANT address space: the kernel stores a result per row, and behind a
+// possibly-aliasing global store the compiler would otherwise re-read every (wave-uniform) table field with per-lane
+// vector loads instead of scalar loads.  The table is written once by the host before the launch.
+typedef const __attribute__((address_space(4))) QTreeTable* CTab;
+typedef const __attribute__((address_space(4))) QStep* CStep;
+__device__ __forceinline__ QStep load_step(CStep p)
+{
+    // the opaque zero keeps the (loop-invariant) scalar loads of ALL levels from being hoisted out of the row loop, where
+    // they would hold some 10 scalar registers per level and spill; each use re-reads its 40 bytes through the scalar cache
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
+    p += zero;
+    QStep s;
+    s.d = p->d; s.Q = p->Q; s.O = p->O; s.W = p->W; s.S = p->S; s.identity = p->identity; s.lo = p->lo; s.hi = p->hi;
+    return s;
+}
+
+constexpr int WAVES = 16;  // 16 waves x one 8 KB segment prefetched in registers = 128 KB in flight per CU
+constexpr int MAXUP = 20;   // levels above a segment (K < 2^31)
+
+// node of level l: acc (LEFT child) + x, quantised by the level's add format, then stored into the level buffer's type
+// (children share one format: no alignment shift in a real GEMM tree)
+template <int N>
+__device__ __forceinline__ void node_all(int (&acc)[N], const int (&x)[N], CTab tab, int level)
+{
+#pragma unroll
+    for (int o = 0; o < N; ++o) acc[o] += x[o];
+    qg_step_all<int, N>(acc, load_step(&tab->level_add[0][level].q));   // (level_cvt is the identity in a real GEMM tree)
+}
+
+// in-lane levels: v[0..CNT) -> v[0..CNT/2) ... -> v[0]
+template <int CNT>
+__device__ __forceinline__ int lane_tree(int (&v)[CNT], CTab tab, int level)
+{
+    if constexpr (CNT == 1) {
+        return v[0];
+    } else {
+        int h[CNT / 2];   // (arrays of exact size, indexed only by unrolled loops: registers, never scratch)
+#pragma unroll
+        for (int o = 0; o < CNT / 2; ++o) h[o] = v[2 * o] + v[2 * o + 1];   // left child + right child, in the tree's order
+        qg_step_all<int, CNT / 2>(h, load_step(&tab->level_add[0][level].q));
+        return lane_tree<CNT / 2>(h, tab, level + 1);
+    }
+}
+
+template <int CH>   // leaves per lane and segment
+__global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
+{
+    constexpr int Q = CH == 32 ? 5 : CH == 16 ? 4 : CH == 8 ? 3 : 2;
+    static_assert(CH <= 32 && CH >= 4, "leaves per lane");
+    constexpr int SEG = 64 * CH;                 // leaves per segment
+    constexpr int LOADS = CH / 4;                // 16-byte loads per lane and segment
+    constexpr int CHUNK = CH * 4 + 16;           // padded chunk pitch in bytes
+    constexpr int IMG = 64 * CHUNK;              // one padded segment image
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const CTab tab = (CTab)g.tab;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* bimg = smem;                                    // B image when the whole vector is one segment; else B is read from L2
+    const int64_t nseg = g.K / SEG;
+    const bool b_in_lds = nseg == 1;
+    char* mine = smem + (b_in_lds ? IMG : 0) + wave * IMG;
+
+    // padded image offset of the 16-byte piece p (= 4 leaves) of a segment: chunk p / LOADS, slot p % LOADS
+    auto img_off = [&](int p) { return (p / LOADS) * CHUNK + (p % LOADS) * 16; };
+
+    if (b_in_lds) {
+        for (int64_t p = threadIdx.x; p < nseg * (SEG / 4); p += 64 * WAVES) {
+            const int64_t s = p / (SEG / 4);
+            *(v4i*)(bimg + s * IMG + img_off((int)(p % (SEG / 4)))) = *(const v4i*)(g.B + p * 4);
+        }
+        __syncthreads();
+    }
+
+    // binary counter over the levels above a segment (only vectors longer than one segment use it): per wave in LDS, so
+    // that it can be indexed at run time; lane 0 holds the real partial results and is the only writer
+    __shared__ int upbuf[WAVES][MAXUP];
+    int* up = &upbuf[wave][0];
+    const int64_t wstride = (int64_t)gridDim.x * WAVES;
+    int64_t row = (int64_t)blockIdx.x * WAVES + wave;
+    v4i nxt[LOADS];
+    auto fetch = [&](int64_t r, int64_t s) {
+        const int32_t* src = g.A + r * g.K + s * SEG + lane * 4;
+#pragma unroll
+        for (int t = 0; t < LOADS; ++t) nxt[t] = *(const v4i*)(src + t * 256);
+    };
+    if (row < g.M) fetch(row, 0);
+    QNode pnode;
+    pnode.sa = pnode.sb = 0;
+    pnode.q = load_step(&tab->mul[0].q);
+    const QStep c_cvt = load_step(&tab->c_cvt[0]);
+    for (; row < g.M; row += wstride) {
+        int root = 0;
+        for (int64_t s = 0; s < nseg; ++s) {
+            // publish the prefetched segment in the wave's image, start fetching the next one
+#pragma unroll
+            for (int t = 0; t < LOADS; ++t) *(v4i*)(mine + img_off(t * 64 + lane)) = nxt[t];
+            {
+                int64_t nr = row, ns = s + 1;
+                if (ns == nseg) { ns = 0; nr = row + wstride; }
+                if (nr < g.M) fetch(nr, ns);
+            }
+            int v[CH];
+            if (g.b_is_bit) {
+#pragma unroll
+                for (int t = 0; t < LOADS; ++t) {
+                    const v4i a = *(const v4i*)(mine + lane * CHUNK + t * 16);
+                    v4i b;
+                    if (b_in_lds) b = *(const v4i*)(bimg + lane * CHUNK + t * 16);
+                    else b = *(const v4i*)(g.B + s * SEG + lane * CH + t * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * t + e] = b[e] ? a[e] : 0;   // Qmul(a, 0|1) into a's own format: exact
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < LOADS; ++t) {
+                    const v4i a = *(const v4i*)(mine + lane * CHUNK + t * 16);
+                    v4i b;
+                    if (b_in_lds) b = *(const v4i*)(bimg + lane * CHUNK + t * 16);
+                    else b = *(const v4i*)(g.B + s * SEG + lane * CH + t * 4);
+                    int64_t p[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) p[e] = (int64_t)a[e] * (int64_t)b[e];
+                    qg_step_all<int64_t, 4>(p, pnode.q);                          // Qmul: round + overflow into the product format
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * t + e] = (int)p[e];
+                }
+            }
+            // across the lanes: level Q + i pairs lane j (left) with lane j + 2^i
+            int x[1] = {lane_tree<CH>(v, tab, 0)};
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                int y[1] = {__shfl_down(x[0], 1 << i)};
+                node_all<1>(x, y, tab, Q + i);
+            }
+            // x[0] in lane 0 = the segment's node of level Q + 6; carry it into the counter
+            const int base = Q + 6;
+            bool parked = false;   // wave-uniform
+            for (int u = 0; u < MAXUP && !parked; ++u) {
+                if (base + u >= g.n_levels) { root = x[0]; parked = true; }
+                else if (((s >> u) & 1) == 0) { if (lane == 0) up[u] = x[0]; parked = true; }
+                else {
+                    int l[1] = {up[u]};
+                    node_all<1>(l, x, tab, base + u);
+                    x[0] = l[0];
+                }
+            }
+        }
+        int r[1] = {root};
+        qg_step_all<int, 1>(r, c_cvt);
+        if (lane == 0) {
+            switch (g.cbytes) {
+            case 1: ((int8_t*)g.C)[row] = (int8_t)r[0]; break;
+            case 2: ((int16_t*)g.C)[row] = (int16_t)r[0]; break;
+            case 4: ((int32_t*)g.C)[row] = r[0]; break;
+            default: ((int64_t*)g.C)[row] = (int64_t)r[0]; break;
+            }
+        }
+    }
+}
+
+template <int CH>
+hipError_t launch_gemv(const QGemvArgs& g, hipStream_t st)
+{
+    constexpr int IMG = 64 * (CH * 4 + 16);
+    const int64_t nseg = g.K / (64 * CH);
+    const int lds = IMG * ((nseg == 1 ? 1 : 0) + WAVES);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemv<CH>, hipFuncAttributeMaxDynamicSharedMemorySize, IMG * (1 + WAVES));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    int64_t blocks = (g.M + WAVES - 1) / WAVES;
+    if (blocks > 256 * 8) blocks = 256 * 8;   // rows beyond that are walked by the grid-stride loop
+    hipLaunchKernelGGL(k_gemv<CH>, dim3((unsigned)blocks), dim3(64 * WAVES), lds, st, g);
+    return hipGetLastError();
+}
+
+} // namespace
+
+hipError_t qg_launch_gemv(const QTreeTable* dev_table, int n_levels, int b_is_bit, const void* A, const void* B, void* C, int64_t M,
+                          int64_t K, int cbytes, hipStream_t st)
+{
+    if (M <= 0) return hipSuccess;
+    if (K < 256 || (K & (K - 1)) || n_levels < 8 || n_levels > 12 + MAXUP) return hipErrorInvalidValue;
+    QGemvArgs g{dev_table, (const int32_t*)A, (const int32_t*)B, (char*)C, M, K, cbytes, n_levels, b_is_bit, 0};
+    // (64 leaves per lane were measured first: v[64] plus the 64 prefetch registers spill, 0.68 ms for 65536 x 4096)
+    // leaves per lane: 16 measured best at 65536 x 4096 (0.277 ms, 3.9 TB/s; 32 leaves 0.48 ms: the prefetch registers
+    // spill under the 128-register cap of 16 waves); QG_GEMV_CH overrides for A/B runs (tools/measure_reduce.py)
+    static const int force_ch = getenv("QG_GEMV_CH") ? atoi(getenv("QG_GEMV_CH")) : 0;
+    const int ch = force_ch ? force_ch : 16;
+    if (ch >= 32 && K >= 2048) return launch_gemv<32>(g, st);
+    if (ch >= 16 && K >= 1024) return launch_gemv<16>(g, st);
+    if (ch >= 8 && K >= 512) return launch_gemv<8>(g, st);
+    return launch_gemv<4>(g, st);
+}

@@ -38,6 +38,8 @@ struct QAnalysis {
     int mul24_ok;            // multiplies fit v_mul_i32_i24
     int cplx_fast_ok;        // the 32-bit complex tree kernel applies
     int fast_mode;           // 0 runtime modes; 1 one format everywhere, TCPL + SAT::ZERO; 2 TCPL + SAT::TCPL
+    int gemv_ok;             // the one-column 32-bit tree kernel applies (N = 1, K = 2^p >= 256)
+    int gemv_b_bit;          // ... and B is a 0/1 vector whose product with a is a itself (the Qreduce lowering)
     char reason[96];
     QTreeTable tree;
     QLinearEpilogue lin;

@@ -1,0 +1,85 @@
+"""GPU parity of the one-column tree kernel (qg_gemv.hip; SURVEY.md 8-f #1: batched Qreduce / fixed-point GEMV) against
+the CPU restatement, through the C-ABI.  N = 1, K = 2^p >= 256; every product and every tree node quantised in the
+reference's order.  Bit-exact."""
+import numpy as np
+import pytest
+
+from qublas_amd import capi
+from qublas_amd.desc import Qu, RND, SAT, TRN, WRP, Tags, lower, lower_reduce
+
+pytestmark = pytest.mark.gpu
+
+E88 = Qu(8, 8, True, TRN.TCPL, SAT.ZERO)
+E43 = Qu(4, 3)
+
+
+def _check(oracle, d, ea, eb, ec, *, dist=0, expect="gemv_i32", flags=0, ones=False):
+    info = capi.classify(d, flags)
+    assert capi.KERNEL_NAMES[info.kernel] == expect, (capi.KERNEL_NAMES[info.kernel], info.reason)
+    M, K = d.M, d.K
+    A = oracle.fill(ea, M * K, 5, dist)
+    B = np.ones(K, dtype=np.int32) if ones else oracle.fill(eb, K, 6, dist)
+    got = capi.run(d, np.zeros(M, dtype=oracle.host_dtype(ec)), A, B, flags=flags)
+    exp = oracle.gemm(d, A, B, ec, nthreads=8)
+    assert np.array_equal(got, exp)
+    return got
+
+
+@pytest.mark.parametrize("K", [256, 512, 1024, 2048, 4096, 8192, 65536])
+def test_batched_qreduce_default_levels(oracle, K):
+    """Qreduce<>(v) of `rows` vectors: every pair add quantised into the element type (TRN::TCPL / SAT::ZERO)."""
+    rows = 777 if K <= 8192 else 40
+    got = _check(oracle, lower_reduce(E88, rows, K), E88, None, E88, dist=1, ones=True)
+    assert len(np.unique(got)) > 8
+
+
+@pytest.mark.parametrize("K", [256, 4096, 16384])
+@pytest.mark.parametrize("levels", [[Qu(12, 6, True, RND.CONV, SAT.SMGN)],
+                                    [Qu(9, 8, True, RND.ZERO, SAT.TCPL), Qu(11, 5, True, RND.INF, WRP.TCPL), Qu(14, 3, True, TRN.SMGN, SAT.ZERO)]],
+                         ids=["one_level_type", "three_level_types"])
+def test_batched_qreduce_level_lists(oracle, K, levels):
+    _check(oracle, lower_reduce(E88, 300, K, levels), E88, None, levels[-1], ones=True)
+
+
+def test_qreduce_rows_are_masked_by_a_zero_one_vector(oracle):
+    """the Qreduce lowering's B is a 0/1 vector: zeros drop leaves exactly (product a*0 = 0 in a's format)"""
+    d = lower_reduce(E88, 500, 1024, [Qu(14, 8)])
+    A = oracle.fill(E88, 500 * 1024, 5, 0)
+    B = (np.arange(1024) % 3 != 0).astype(np.int32)
+    got = capi.run(d, np.zeros(500, dtype=np.int32), A, B)
+    assert np.array_equal(got, oracle.gemm(d, A, B, Qu(14, 8), nthreads=8))
+
+
+@pytest.mark.parametrize("ta", [False, True])
+@pytest.mark.parametrize("K", [256, 2048, 32768])
+def test_gemv_general_vector(oracle, K, ta):
+    """C[M x 1] = A * b with a real vector b: products rounded into the default product format, default tree levels"""
+    M = 513
+    _check(oracle, lower(E43, E43, Qu(12, 3), M, 1, K, transposed_a=ta), E43, E43, Qu(12, 3))
+    pm = Qu(5, 4, True, RND.INF, SAT.TCPL)
+    _check(oracle, lower(E43, E43, Qu(12, 3), M, 1, K, mul_args=pm, add_args=[Qu(8, 4, True, RND.CONV, SAT.SMGN)], transposed_a=ta), E43, E43, Qu(12, 3))
+
+
+def test_gemv_wide_products(oracle):
+    """int<8,8> x int<8,8>: 34-bit unrounded products, formed in 64 bits, rounded into 17-bit values"""
+    got = _check(oracle, lower(E88, E88, Qu(15, 8), 300, 1, 4096), E88, E88, Qu(15, 8), dist=1)
+    assert len(np.unique(got)) > 8
+
+
+def test_kernel_choice_is_invariant(oracle):
+    """the one-column kernel, the 32-column tree kernel's path (GENERIC_TREE) and (for a linear-class descriptor) the MFMA
+    kernel agree"""
+    d = lower_reduce(E43, 400, 1024, [Qu(16, 3)])           # exact levels: linear class -> MFMA by default
+    assert capi.KERNEL_NAMES[capi.classify(d).kernel] == "mfma_i8"
+    A = oracle.fill(E43, 400 * 1024, 5, 0)
+    B = np.ones(1024, dtype=np.int32)
+    outs = [capi.run(d, np.zeros(400, dtype=np.int32), A, B, flags=f) for f in (0, capi.OPT_FORCE_TREE, capi.OPT_FORCE_TREE | capi.OPT_GENERIC_TREE)]
+    assert capi.KERNEL_NAMES[capi.classify(d, capi.OPT_FORCE_TREE).kernel] == "gemv_i32"
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+    assert np.array_equal(outs[0], oracle.gemm(d, A, B, Qu(16, 3), nthreads=8))
+
+
+def test_non_power_of_two_and_short_vectors_use_the_general_kernels(oracle):
+    for K in (255, 1000, 128):
+        d = lower_reduce(E88, 64, K)
+        assert capi.KERNEL_NAMES[capi.classify(d).kernel] in ("tree_i32", "tree_i64")
