@@ -595,7 +595,8 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
                               pcg.cbytes, st));
         return QG_OK;
     case QG_KERNEL_TREE_CPLX_I32:
-        QG_HIP(qg_launch_tree_cplx_fast(p->dev_table, (int)p->desc.n_levels, packedA, packedB, packedC, p->desc.M, p->desc.N,
+        QG_HIP(qg_launch_tree_cplx_fast(p->dev_table, (int)p->desc.n_levels, (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : p->an.cplx_fixed_ok,
+                                        packedA, packedB, packedC, p->desc.M, p->desc.N,
                                         p->desc.K, p->pc.cbytes, st));
         return QG_OK;
     case QG_KERNEL_TREE_I64:

@@ -455,6 +455,21 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     out->gemv_ok = (!cx && d->N == 1 && d->K >= 256 && (d->K & (d->K - 1)) == 0 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     out->gemv_b_bit = (out->gemv_ok && d->b[0].I == 1 && d->b[0].F == 0 && !d->b[0].S && same(d->mul[0], d->a[0])) ? 1 : 0;
     out->cplx_fast_ok = (cx && d->K >= 32 && (d->K & (d->K - 1)) == 0 && d->n_levels <= 16 && c.max_bits <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
+    // fixed-mode variant of the complex kernel (BASELINE configuration 5's "RND + SAT"): every sub-operation and every tree
+    // step either the identity, or an exact left shift / a rounding shift with RND::POS_INF, followed by SAT::TCPL, so a
+    // step is (v + 2^(d-1)) >> d (or v << -d) and one clamp
+    out->cplx_fixed_ok = 0;
+    if (out->cplx_fast_ok) {
+        auto ok = [](const QStep& q) {
+            return q.identity || (q.d >= -29 && q.d <= 29 && q.O == QG_SAT_TCPL && (q.d <= 0 || q.Q == QG_RND_POS_INF));
+        };
+        bool all = true;
+        const int ns = d->cmul == QG_CMUL_TF ? 8 : 6;
+        for (int i = 0; i < ns; ++i) all = all && ok(T.mul[i].q);
+        for (int p = 0; p < 2; ++p)
+            for (uint32_t l = 0; l < d->n_levels; ++l) all = all && ok(T.level_add[p][l].q) && ok(T.level_cvt[p][l]);
+        out->cplx_fixed_ok = all ? 1 : 0;
+    }
     if (!out->linear_ok)
         snprintf(out->reason, sizeof out->reason, "%s",
                  "a product or tree node may round or overflow: exact tree evaluation");

@@ -25,7 +25,29 @@ constexpr int KC = 32;
 constexpr int TMB = 32, TNB = 32;  // 16x16 threads x (2x2)
 constexpr int PITCH = KC + 4;
 
-template <int N>
+// one quantising step on N values.  FIXED: the planner has shown every step of this descriptor to be the identity or
+// "RND::POS_INF by d >= 0 bits, then SAT::TCPL" (QAnalysis::cplx_fixed_ok) — round-half-up is (v + 2^(d-1)) >> d and the
+// saturation one clamp, 3 VALU instructions instead of the 6-7 of the runtime-mode form and no scalar branch ladder.
+template <bool FIXED, int N>
+__device__ __forceinline__ void step_n(int (&v)[N], const QStep& s)
+{
+    if constexpr (FIXED) {
+        if (s.identity) return;
+        const int lo = (int)s.lo, hi = (int)s.hi;
+        if (s.d >= 0) {
+            const int t = (1 << s.d) >> 1;
+#pragma unroll
+            for (int o = 0; o < N; ++o) v[o] = min(max((v[o] + t) >> s.d, lo), hi);
+        } else {   // exact left shift (e.g. a product of a fracBits<-3> part brought to fracBits<3>)
+#pragma unroll
+            for (int o = 0; o < N; ++o) v[o] = min(max((int)((unsigned)v[o] << (-s.d)), lo), hi);
+        }
+    } else {
+        qg_step_all<int, N>(v, s);
+    }
+}
+
+template <bool FIXED, int N>
 __device__ __forceinline__ void addsub_n(int (&out)[N], const int (&x)[N], const int (&y)[N], const QNode& n, bool sub)
 {
 #pragma unroll
@@ -33,25 +55,25 @@ __device__ __forceinline__ void addsub_n(int (&out)[N], const int (&x)[N], const
         const int xs = (int)((unsigned)x[o] << n.sa), ys = (int)((unsigned)y[o] << n.sb);
         out[o] = sub ? xs - ys : xs + ys;
     }
-    qg_step_all<int, N>(out, n.q);
+    step_n<FIXED, N>(out, n.q);
 }
 
-template <int N>
+template <bool FIXED, int N>
 __device__ __forceinline__ void mul_n(int (&out)[N], const int (&x)[N], const int (&y)[N], const QNode& n)
 {
 #pragma unroll
     for (int o = 0; o < N; ++o) out[o] = x[o] * y[o];
-    qg_step_all<int, N>(out, n.q);
+    step_n<FIXED, N>(out, n.q);
 }
 
 // tree node of level l for one part: children share a format, so no alignment shift
-template <int N>
+template <bool FIXED, int N>
 __device__ __forceinline__ void node_n(int (&v)[N], const int (&x)[N], const QTreeTable* __restrict__ t, int part, int l)
 {
 #pragma unroll
     for (int o = 0; o < N; ++o) v[o] = x[o] + v[o];
-    qg_step_all<int, N>(v, t->level_add[part][l].q);
-    qg_step_all<int, N>(v, t->level_cvt[part][l]);
+    step_n<FIXED, N>(v, t->level_add[part][l].q);
+    step_n<FIXED, N>(v, t->level_cvt[part][l]);
 }
 
 struct QTreeCplxArgs {
@@ -63,7 +85,7 @@ struct QTreeCplxArgs {
     int32_t cbytes;
 };
 
-template <int MAXL>
+template <int MAXL, bool FIXED>
 __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
 {
     __shared__ __attribute__((aligned(16))) int sA[2][TMB][PITCH];
@@ -141,27 +163,27 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
                         }
                     if (tf) {
                         int ab2[2], ba2[2], cd2[2];
-                        addsub_n<2>(ab2, ar, ai, tab->mul[QG_T_AB], false);  // (a+b), per A element
-                        addsub_n<2>(ba2, ai, ar, tab->mul[QG_T_BA], true);   // (b-a), per A element
-                        addsub_n<2>(cd2, br, bi, tab->mul[QG_T_CD], false);  // (c+d), per B element
+                        addsub_n<FIXED, 2>(ab2, ar, ai, tab->mul[QG_T_AB], false);  // (a+b), per A element
+                        addsub_n<FIXED, 2>(ba2, ai, ar, tab->mul[QG_T_BA], true);   // (b-a), per A element
+                        addsub_n<FIXED, 2>(cd2, br, bi, tab->mul[QG_T_CD], false);  // (c+d), per B element
                         int ab[4], ba[4], cd[4], PA[4], PB[4], PC[4];
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
 #pragma unroll
                             for (int j = 0; j < 2; ++j) { ab[i * 2 + j] = ab2[i]; ba[i * 2 + j] = ba2[i]; cd[i * 2 + j] = cd2[j]; }
-                        mul_n<4>(PA, ab, yr, tab->mul[QG_T_A]);
-                        mul_n<4>(PB, cd, xi, tab->mul[QG_T_B]);
-                        mul_n<4>(PC, ba, yi, tab->mul[QG_T_C]);
-                        addsub_n<4>(v[0], PA, PB, tab->mul[QG_T_RE], true);
-                        addsub_n<4>(v[1], PB, PC, tab->mul[QG_T_IM], true);
+                        mul_n<FIXED, 4>(PA, ab, yr, tab->mul[QG_T_A]);
+                        mul_n<FIXED, 4>(PB, cd, xi, tab->mul[QG_T_B]);
+                        mul_n<FIXED, 4>(PC, ba, yi, tab->mul[QG_T_C]);
+                        addsub_n<FIXED, 4>(v[0], PA, PB, tab->mul[QG_T_RE], true);
+                        addsub_n<FIXED, 4>(v[1], PB, PC, tab->mul[QG_T_IM], true);
                     } else {
                         int ac[4], bd[4], ad[4], bc[4];
-                        mul_n<4>(ac, xr, yr, tab->mul[QG_B_AC]);
-                        mul_n<4>(bd, xi, yi, tab->mul[QG_B_BD]);
-                        mul_n<4>(ad, xr, yi, tab->mul[QG_B_AD]);
-                        mul_n<4>(bc, xi, yr, tab->mul[QG_B_BC]);
-                        addsub_n<4>(v[0], ac, bd, tab->mul[QG_B_RE], true);
-                        addsub_n<4>(v[1], ad, bc, tab->mul[QG_B_IM], false);
+                        mul_n<FIXED, 4>(ac, xr, yr, tab->mul[QG_B_AC]);
+                        mul_n<FIXED, 4>(bd, xi, yi, tab->mul[QG_B_BD]);
+                        mul_n<FIXED, 4>(ad, xr, yi, tab->mul[QG_B_AD]);
+                        mul_n<FIXED, 4>(bc, xi, yr, tab->mul[QG_B_BC]);
+                        addsub_n<FIXED, 4>(v[0], ac, bd, tab->mul[QG_B_RE], true);
+                        addsub_n<FIXED, 4>(v[1], ad, bc, tab->mul[QG_B_IM], false);
                     }
                     // ---- lower four levels (compile-time leaf index)
 #pragma unroll
@@ -170,22 +192,22 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
 #pragma unroll
                             for (int o = 0; o < 4; ++o) low[p][0][o] = v[p][o];
                         } else {
-                            node_n<4>(v[p], low[p][0], tab, p, 0);
+                            node_n<FIXED, 4>(v[p], low[p][0], tab, p, 0);
                             if ((kk & 2) == 0) {
 #pragma unroll
                                 for (int o = 0; o < 4; ++o) low[p][1][o] = v[p][o];
                             } else {
-                                node_n<4>(v[p], low[p][1], tab, p, 1);
+                                node_n<FIXED, 4>(v[p], low[p][1], tab, p, 1);
                                 if ((kk & 4) == 0) {
 #pragma unroll
                                     for (int o = 0; o < 4; ++o) low[p][2][o] = v[p][o];
                                 } else {
-                                    node_n<4>(v[p], low[p][2], tab, p, 2);
+                                    node_n<FIXED, 4>(v[p], low[p][2], tab, p, 2);
                                     if ((kk & 8) == 0) {
 #pragma unroll
                                         for (int o = 0; o < 4; ++o) low[p][3][o] = v[p][o];
                                     } else {
-                                        node_n<4>(v[p], low[p][3], tab, p, 3);
+                                        node_n<FIXED, 4>(v[p], low[p][3], tab, p, 3);
                                     }
                                 }
                             }
@@ -205,8 +227,8 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
                             for (int o = 0; o < 4; ++o) up[p][u][o] = v[p][o];
                         parked = true;
                     } else {
-                        node_n<4>(v[0], up[0][u], tab, 0, 4 + u);
-                        node_n<4>(v[1], up[1][u], tab, 1, 4 + u);
+                        node_n<FIXED, 4>(v[0], up[0][u], tab, 0, 4 + u);
+                        node_n<FIXED, 4>(v[1], up[1][u], tab, 1, 4 + u);
                     }
                 }
             }
@@ -236,7 +258,7 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
 
 } // namespace
 
-hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, const void* A, const void* B, void* C, int64_t M,
+hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, int fixed, const void* A, const void* B, void* C, int64_t M,
                                     int64_t N, int64_t K, int cbytes, hipStream_t st)
 {
     if (K % KC != 0 || n_levels < 5 || n_levels > 16) return hipErrorInvalidValue;
@@ -244,7 +266,12 @@ hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, c
     const int64_t blocks = ((M + TMB - 1) / TMB) * ((N + TNB - 1) / TNB);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
-    if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12>), dim3((unsigned)blocks), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((k_tree_cplx<16>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    if (fixed) {
+        if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_tree_cplx<16, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    } else {
+        if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12, false>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_tree_cplx<16, false>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    }
     return hipGetLastError();
 }

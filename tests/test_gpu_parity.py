@@ -180,6 +180,24 @@ def test_config5_complex_tf(oracle):
     _vs_oracle(oracle, c5, c5, wide, 70, 33, 256, dist=0, mul_args=BasicComplexMul(), transposed_a=True, expect_kernel="tree_cplx_i32")
 
 
+def test_complex_fixed_mode_variant(oracle):
+    """BASELINE configuration 5's formats ("RND + SAT": RND::POS_INF + SAT::TCPL everywhere) take the fixed-mode variant of
+    the complex kernel ((v + 2^(d-1)) >> d, one clamp); the runtime-mode variant (QG_OPT_RUNTIME_MODES), the generic
+    64-bit kernel and the oracle must all give the same matrix — narrow and wide C, TF and Basic, level types too."""
+    r = Qu(6, 3, True, RND.POS_INF, SAT.TCPL)
+    i = Qu(6, -3, True, RND.POS_INF, SAT.TCPL)
+    c5 = Qcomplex(r, i)
+    wide = Qcomplex(Qu(18, 6, True, RND.POS_INF), Qu(18, 6, True, RND.POS_INF))
+    lv = Qcomplex(Qu(9, 2, True, RND.POS_INF, SAT.TCPL), Qu(10, 0, True, RND.POS_INF, SAT.TCPL))
+    for ec, dist, kw in ((c5, 0, dict(mul_args=TFComplexMul())), (wide, 1, dict(mul_args=TFComplexMul())),
+                         (wide, 1, dict(mul_args=BasicComplexMul())), (wide, 0, dict(mul_args=TFComplexMul(), add_args=[lv])),
+                         (c5, 1, dict(mul_args=BasicComplexMul(), add_args=[lv, lv]))):
+        a = _vs_oracle(oracle, c5, c5, ec, 70, 37, 512, dist=dist, expect_kernel="tree_cplx_i32", **kw)
+        b = _vs_oracle(oracle, c5, c5, ec, 70, 37, 512, dist=dist, flags=capi.OPT_RUNTIME_MODES, expect_kernel="tree_cplx_i32", **kw)
+        c = _vs_oracle(oracle, c5, c5, ec, 70, 37, 512, dist=dist, flags=capi.OPT_GENERIC_TREE, expect_kernel="tree_cplx", **kw)
+        assert fields_equal(a, b) and fields_equal(a, c)
+
+
 def test_complex_fast_kernel_tags_and_levels(oracle):
     """Complex 32-bit kernel with per-sub-op tags (incl. the crossed cdbT/badT use) and complex level types."""
     r55 = Qu(5, 5)

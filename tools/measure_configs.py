@@ -35,6 +35,10 @@ CASES = [
 
 
 def main():
+    only = os.environ.get("ONLY")   # substring filter on the configuration name
+    global CASES
+    if only:
+        CASES = [c for c in CASES if only in c[0]]
     out = []
     with capi.Context(0) as ctx:
         for name, d, iters in CASES:
@@ -54,6 +58,8 @@ def main():
             for p in (pA, pB, pC):
                 ctx.free(p)
             plan.close()
+    if only:
+        return
     # the drop-in call with HOST buffers (qgemul_run): H2D + pack + GEMM + unpack + D2H + alloc/free, wall time
     import time
     import numpy as np
