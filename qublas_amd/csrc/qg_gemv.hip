@@ -14,7 +14,8 @@
 //     qg_step_all.h), 6 more across the lanes (lane 2s*i takes its partner s lanes up), which leaves the segment's
 //     partial result — a node of level q+6 — in lane 0; segments are combined by a binary counter over the remaining
 //     levels.  Every node is the reference's Qadd of two equal-format children in the reference's order.
-// Requirements (planner): real descriptor, N = 1, K = 2^p >= 256, every value except the unrounded product within 31
+// Rows of 16 .. 128 leaves take k_gemv_short (below), which needs no LDS.
+// Requirements (planner): real descriptor, N = 1, K = 2^p >= 16, every value except the unrounded product within 31
 // bits.  When the whole vector is one segment, B is staged once per workgroup in the same padded image; longer
 // vectors are re-read per segment from L2.
 #include <hip/hip_runtime.h>
@@ -197,6 +198,95 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
     }
 }
 
+// Short rows (K = 16 .. 128): a row is K/4 lanes wide, so one 16-byte load per lane covers 256/K whole rows and the lane's
+// four values are already consecutive leaves — no LDS.  Two levels inside the lane, log2(K) - 2 across the lanes of the
+// row's group; U row groups are processed together so that the (wave-uniform) mode switches are paid once per U values.
+template <int KK>
+__global__ __launch_bounds__(256) void k_gemv_short(QGemvArgs g)
+{
+    constexpr int LPR = KK / 4;        // lanes per row
+    constexpr int RPL = 64 / LPR;      // rows per wave-wide load
+    constexpr int U = 4;               // loads in flight per lane
+    constexpr int XL = KK == 16 ? 2 : KK == 32 ? 3 : KK == 64 ? 4 : 5;   // levels across lanes
+    const CTab tab = (CTab)g.tab;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const int sub = lane % LPR, rl = lane / LPR;
+    const v4i b = *(const v4i*)(g.B + sub * 4);
+    QNode pnode;
+    pnode.sa = pnode.sb = 0;
+    pnode.q = load_step(&tab->mul[0].q);
+    const QStep c_cvt = load_step(&tab->c_cvt[0]);
+    const int64_t groups = (g.M + RPL - 1) / RPL;            // groups of RPL rows
+    for (int64_t g0 = wave * U; g0 < groups; g0 += nwaves * U) {
+        v4i a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = (g0 + u) * RPL + rl;
+            a[u] = row < g.M ? *(const v4i*)(g.A + row * KK + sub * 4) : v4i{0, 0, 0, 0};
+        }
+        int l0[2 * U];   // level-0 inputs pairwise: (p0 + p1), (p2 + p3) per load
+        {
+            int p[4 * U];
+            if (g.b_is_bit) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) p[4 * u + e] = b[e] ? a[u][e] : 0;
+            } else {
+                int64_t w[4 * U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[4 * u + e] = (int64_t)a[u][e] * (int64_t)b[e];
+                qg_step_all<int64_t, 4 * U>(w, pnode.q);
+#pragma unroll
+                for (int o = 0; o < 4 * U; ++o) p[o] = (int)w[o];
+            }
+#pragma unroll
+            for (int o = 0; o < 2 * U; ++o) l0[o] = p[2 * o] + p[2 * o + 1];
+        }
+        qg_step_all<int, 2 * U>(l0, load_step(&tab->level_add[0][0].q));
+        int x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = l0[2 * u] + l0[2 * u + 1];
+        qg_step_all<int, U>(x, load_step(&tab->level_add[0][1].q));
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            int y[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) y[u] = __shfl_down(x[u], 1 << i);
+            node_all<U>(x, y, tab, 2 + i);
+        }
+        qg_step_all<int, U>(x, c_cvt);
+        if (sub == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t row = (g0 + u) * RPL + rl;
+                if (row < g.M) {
+                    switch (g.cbytes) {
+                    case 1: ((int8_t*)g.C)[row] = (int8_t)x[u]; break;
+                    case 2: ((int16_t*)g.C)[row] = (int16_t)x[u]; break;
+                    case 4: ((int32_t*)g.C)[row] = x[u]; break;
+                    default: ((int64_t*)g.C)[row] = (int64_t)x[u]; break;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int KK>
+hipError_t launch_gemv_short(const QGemvArgs& g, hipStream_t st)
+{
+    constexpr int RPL = 64 / (KK / 4);
+    const int64_t groups = (g.M + RPL - 1) / RPL;
+    int64_t blocks = (groups + 15) / 16;          // 4 waves x U = 4 groups per block pass
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_gemv_short<KK>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+    return hipGetLastError();
+}
+
 template <int CH>
 hipError_t launch_gemv(const QGemvArgs& g, hipStream_t st)
 {
@@ -221,8 +311,15 @@ hipError_t qg_launch_gemv(const QTreeTable* dev_table, int n_levels, int b_is_bi
                           int64_t K, int cbytes, hipStream_t st)
 {
     if (M <= 0) return hipSuccess;
-    if (K < 256 || (K & (K - 1)) || n_levels < 8 || n_levels > 12 + MAXUP) return hipErrorInvalidValue;
+    if (K < 16 || (K & (K - 1)) || n_levels < 4 || n_levels > 12 + MAXUP) return hipErrorInvalidValue;
     QGemvArgs g{dev_table, (const int32_t*)A, (const int32_t*)B, (char*)C, M, K, cbytes, n_levels, b_is_bit, 0};
+    switch (K) {
+    case 16: return launch_gemv_short<16>(g, st);
+    case 32: return launch_gemv_short<32>(g, st);
+    case 64: return launch_gemv_short<64>(g, st);
+    case 128: return launch_gemv_short<128>(g, st);
+    default: break;
+    }
     // (64 leaves per lane were measured first: v[64] plus the 64 prefetch registers spill, 0.68 ms for 65536 x 4096)
     // leaves per lane: 16 measured best at 65536 x 4096 (0.277 ms, 3.9 TB/s; 32 leaves 0.48 ms: the prefetch registers
     // spill under the 128-register cap of 16 waves); QG_GEMV_CH overrides for A/B runs (tools/measure_reduce.py)

@@ -1,5 +1,5 @@
 """GPU parity of the one-column tree kernel (qg_gemv.hip; SURVEY.md 8-f #1: batched Qreduce / fixed-point GEMV) against
-the CPU restatement, through the C-ABI.  N = 1, K = 2^p >= 256; every product and every tree node quantised in the
+the CPU restatement, through the C-ABI.  N = 1, K = 2^p >= 16; every product and every tree node quantised in the
 reference's order.  Bit-exact."""
 import numpy as np
 import pytest
@@ -25,7 +25,7 @@ def _check(oracle, d, ea, eb, ec, *, dist=0, expect="gemv_i32", flags=0, ones=Fa
     return got
 
 
-@pytest.mark.parametrize("K", [256, 512, 1024, 2048, 4096, 8192, 65536])
+@pytest.mark.parametrize("K", [16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 65536])
 def test_batched_qreduce_default_levels(oracle, K):
     """Qreduce<>(v) of `rows` vectors: every pair add quantised into the element type (TRN::TCPL / SAT::ZERO)."""
     rows = 777 if K <= 8192 else 40
@@ -33,7 +33,7 @@ def test_batched_qreduce_default_levels(oracle, K):
     assert len(np.unique(got)) > 8
 
 
-@pytest.mark.parametrize("K", [256, 4096, 16384])
+@pytest.mark.parametrize("K", [16, 64, 128, 256, 4096, 16384])
 @pytest.mark.parametrize("levels", [[Qu(12, 6, True, RND.CONV, SAT.SMGN)],
                                     [Qu(9, 8, True, RND.ZERO, SAT.TCPL), Qu(11, 5, True, RND.INF, WRP.TCPL), Qu(14, 3, True, TRN.SMGN, SAT.ZERO)]],
                          ids=["one_level_type", "three_level_types"])
@@ -51,7 +51,7 @@ def test_qreduce_rows_are_masked_by_a_zero_one_vector(oracle):
 
 
 @pytest.mark.parametrize("ta", [False, True])
-@pytest.mark.parametrize("K", [256, 2048, 32768])
+@pytest.mark.parametrize("K", [16, 32, 128, 256, 2048, 32768])
 def test_gemv_general_vector(oracle, K, ta):
     """C[M x 1] = A * b with a real vector b: products rounded into the default product format, default tree levels"""
     M = 513
@@ -80,6 +80,6 @@ def test_kernel_choice_is_invariant(oracle):
 
 
 def test_non_power_of_two_and_short_vectors_use_the_general_kernels(oracle):
-    for K in (255, 1000, 128):
+    for K in (255, 1000, 8, 24):
         d = lower_reduce(E88, 64, K)
         assert capi.KERNEL_NAMES[capi.classify(d).kernel] in ("tree_i32", "tree_i64")
