@@ -61,6 +61,29 @@ int main()
             Qgemul<QgemulMulArgs<intBits<9>, fracBits<6>>, QgemulAddArgs<Qu<intBits<19>, fracBits<6>>>>(c, a, b);
             print_matrix("e43_L_33x17x128_full_wideC", c, 33 * 17);
         }
+        {   // element-wise operators after the GEMM through the binding's Then* front-ends, with the operands of the golden
+            // record "scale_then_bias" (tests/golden/ref_eltwise_2, oracle/ref_cases_eltwise.cpp case2: seeds 31/32/33,
+            // dist 1): X * 1 with K = 1 reproduces the record's tensor, so D must be the record's D
+            using c238 = Qu<intBits<23>, fracBits<8>>;
+            using one_t = Qu<intBits<1>, fracBits<0>, isSigned<false>>;
+            using s34 = Qu<intBits<3>, fracBits<4>>;
+            using b106 = Qu<intBits<10>, fracBits<6>>;
+            using t1 = Qu<intBits<24>, fracBits<8>>;
+            using d124 = Qu<intBits<12>, fracBits<4>, QuMode<RND::CONV>, OfMode<SAT::SMGN>>;
+            Qu<dim<96, 1>, c238> x;
+            Qu<dim<1, 1>, one_t> one;
+            Qu<dim<96, 1>, b106> bias;
+            Qu<dim<96, 1>, d124> d;
+            fill_synth(x, 96, 31, 1);
+            one.data[0].data.data = 1;
+            fill_synth(bias, 96, 33, 1);
+            s34 s;
+            s.data.data = refdrv::synth<s34>(32, 1, 0, 0);
+            Qgemul<QgemulMulArgs<c238>, QgemulResult<c238>>(d, x, one, ThenMul<t1, intBits<24>, fracBits<8>>(s), ThenAdd<>(bias));
+            std::printf("{\"epilogue\":\"scale_then_bias\",\"D\":[");
+            for (size_t e = 0; e < 96; ++e) std::printf("%s%lld", e ? "," : "", (long long)d.data[e].data.data);
+            std::printf("]}\n");
+        }
     } catch (const std::exception& e) {
         std::printf("{\"error\":\"%s\"}\n", e.what());
         return 3;

@@ -38,7 +38,12 @@ def test_reference_header_binding_runs_on_gpu():
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/ref_binding_demo was not built (needs the reference header, build container only)")
     out = subprocess.check_output([exe], text=True)
-    assert _check(out.strip().splitlines()) == 4
+    lines = out.strip().splitlines()
+    assert _check([l for l in lines if '"epilogue"' not in l]) == 4
+    # the Then* front-ends on the reference's own types: D of the golden element-wise record, bit for bit
+    ep = [json.loads(l) for l in lines if '"epilogue"' in l]
+    gold = {j["name"]: j for j in G.eltwise_cases()}
+    assert len(ep) == 1 and ep[0]["D"] == gold[ep[0]["epilogue"]]["D"]
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="needs AMD clang (C++23)")
