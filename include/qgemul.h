@@ -193,6 +193,9 @@ int qgemul_last_hip_error(void);
 /* ---- one-shot entry: what Qgemul<…>(C, A, B) calls.  Host pointers in reference layout;
  *      C is fully overwritten; the call is synchronous (QuBLAS is synchronous, single-threaded). */
 int qgemul_run(const qgemul_desc* d, void* C, const void* A, const void* B, const qgemul_opts* o);
+/* qgemul_run / qgemul_run_ep keep a cache per calling thread (context, the plan of the last descriptor, grow-only device
+ * buffers) so that calls in a loop cost microseconds, not milliseconds; this frees the calling thread's cache. */
+void qgemul_run_release(void);
 
 /* ---- resident-data API (benchmarks, multi-GPU row shards, repeated calls) ---- */
 typedef struct qgemul_ctx qgemul_ctx;   /* one per host thread / device; owns streams + workspace */

@@ -32,7 +32,7 @@ EXPORTS = [
     "qgemul_pack", "qgemul_pack_f64", "qgemul_unpack_c", "qgemul_execute", "qgemul_fill_packed", "qgemul_time_execute",
     "qgemul_classify_ep", "qgemul_plan_create_ep", "qgemul_packed_e_bytes", "qgemul_pack_e", "qgemul_execute_ep",
     "qgemul_time_execute_ep", "qgemul_run_ep", "qgemul_plan_fuses_epilogue",
-    "qgemul_bitstream_bytes", "qgemul_export_bitstream",
+    "qgemul_bitstream_bytes", "qgemul_export_bitstream", "qgemul_run_release",
 ]
 
 _lib = None
@@ -87,6 +87,8 @@ def lib() -> C.CDLL:
         L.qgemul_classify_ep.argtypes = [pd, pe, u32, C.POINTER(qgemul_info)]
         L.qgemul_plan_create_ep.argtypes = [vp, pd, pe, u32, C.POINTER(vp)]
         L.qgemul_plan_fuses_epilogue.argtypes = [vp]
+        L.qgemul_run_release.argtypes = []
+        L.qgemul_run_release.restype = None
         L.qgemul_bitstream_bytes.argtypes = [vp, C.c_int]
         L.qgemul_bitstream_bytes.restype = i64
         L.qgemul_export_bitstream.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
@@ -109,6 +111,11 @@ def classify(desc: qgemul_desc, flags: int = 0) -> qgemul_info:
     info = qgemul_info()
     _chk(lib().qgemul_classify(C.byref(desc), flags, C.byref(info)), "qgemul_classify")
     return info
+
+
+def run_release():
+    """free the calling thread's qgemul_run cache (context, plan, device buffers)"""
+    lib().qgemul_run_release()
 
 
 def classify_ep_status(desc: qgemul_desc, ep: qgemul_epilogue, flags: int = 0):

@@ -690,6 +690,57 @@ int qgemul_run(const qgemul_desc* d, void* C, const void* A, const void* B, cons
     return qgemul_run_ep(d, nullptr, C, A, B, nullptr, o);
 }
 
+// ---- the one-shot call keeps a per-thread cache: context, the plan of the last descriptor, grow-only device buffers ----
+// The reference is a synchronous library that user code calls in loops; creating a stream, a plan table and eight device
+// allocations per call cost 2.9 ms for the README's 4x4x4 example (tools/measure_run_latency.py).  The cache belongs to
+// the calling thread and is never touched by another one; qgemul_run_release() frees it.  (Nothing is freed at thread or
+// process exit: HIP may already be shut down when thread-local destructors run.)
+namespace {
+struct RunCache {
+    qgemul_ctx* ctx = nullptr;
+    int device = -2;
+    qgemul_plan* plan = nullptr;
+    qgemul_desc pd;
+    qgemul_epilogue pe;
+    bool has_pe = false;
+    uint32_t pflags = 0;
+    enum { NBUF = 6 + 2 * QG_MAX_EW };
+    void* buf[NBUF] = {};
+    size_t cap[NBUF] = {};
+};
+thread_local RunCache g_run;
+
+int cache_buffer(RunCache& c, int i, size_t bytes, void** out)
+{
+    if (bytes > c.cap[i]) {
+        if (c.buf[i]) {
+            hipStreamSynchronize(c.ctx->stream);
+            hipFree(c.buf[i]);
+            c.buf[i] = nullptr;
+            c.cap[i] = 0;
+        }
+        const size_t want = bytes < 4096 ? 4096 : bytes;
+        hipError_t e = hipMalloc(&c.buf[i], want);
+        if (e != hipSuccess) { g_last_hip = (int)e; return QG_EHIP; }
+        c.cap[i] = want;
+    }
+    *out = c.buf[i];
+    return QG_OK;
+}
+} // namespace
+
+void qgemul_run_release(void)
+{
+    RunCache& c = g_run;
+    if (c.ctx) hipStreamSynchronize(c.ctx->stream);
+    if (c.plan) qgemul_plan_destroy(c.plan);
+    for (int i = 0; i < RunCache::NBUF; ++i) { if (c.buf[i]) hipFree(c.buf[i]); c.buf[i] = nullptr; c.cap[i] = 0; }
+    if (c.ctx) qgemul_ctx_destroy(c.ctx);
+    c.plan = nullptr;
+    c.ctx = nullptr;
+    c.device = -2;
+}
+
 int qgemul_run_ep(const qgemul_desc* d, const qgemul_epilogue* ep, void* C, const void* A, const void* B, const void* const* E,
                   const qgemul_opts* o)
 {
@@ -698,8 +749,11 @@ int qgemul_run_ep(const qgemul_desc* d, const qgemul_epilogue* ep, void* C, cons
     memset(&opts, 0, sizeof opts);
     opts.device = -1;
     if (o) opts = *o;
-    // validate before touching the device so that descriptor errors are reported without a GPU
-    {
+    RunCache& c = g_run;
+    const bool same_plan = c.plan && c.pflags == opts.flags && memcmp(&c.pd, d, sizeof *d) == 0 && c.has_pe == (ep != nullptr) &&
+                           (!ep || memcmp(&c.pe, ep, sizeof *ep) == 0) && (opts.device < 0 || opts.device == c.device);
+    if (!same_plan) {
+        // validate before touching the device so that descriptor errors are reported without a GPU
         qgemul_info info;
         int st = qgemul_classify_ep(d, ep, opts.flags, &info);
         if (st != QG_OK) return st;
@@ -708,15 +762,28 @@ int qgemul_run_ep(const qgemul_desc* d, const qgemul_epilogue* ep, void* C, cons
         for (uint32_t k = 0; k < ep->n_stages; ++k)
             if (!E || !E[k]) return QG_EINVAL;
     if (d->M == 0 || d->N == 0) return QG_OK;
-    qgemul_ctx* ctx = nullptr;
-    int st = qgemul_ctx_create(opts.device, &ctx);
-    if (st != QG_OK) return st;
-    qgemul_plan* p = nullptr;
-    void *dA = nullptr, *dB = nullptr, *dC = nullptr, *pA = nullptr, *pB = nullptr, *pC = nullptr;
-    void *dE[QG_MAX_EW] = {nullptr, nullptr, nullptr, nullptr}, *pE[QG_MAX_EW] = {nullptr, nullptr, nullptr, nullptr};
+    int st = QG_OK;
+    if (!c.ctx || (opts.device >= 0 && opts.device != c.device)) {
+        qgemul_run_release();
+        st = qgemul_ctx_create(opts.device, &c.ctx);
+        if (st != QG_OK) { c.ctx = nullptr; return st; }
+        c.device = c.ctx->device;
+    } else {
+        QG_HIP(hipSetDevice(c.device));
+    }
+    qgemul_ctx* ctx = c.ctx;
+    if (!same_plan) {
+        if (c.plan) { qgemul_plan_destroy(c.plan); c.plan = nullptr; }
+        st = qgemul_plan_create_ep(ctx, d, ep, opts.flags, &c.plan);
+        if (st != QG_OK) { c.plan = nullptr; return st; }
+        c.pd = *d;
+        c.has_pe = ep != nullptr;
+        if (ep) c.pe = *ep;
+        c.pflags = opts.flags;
+    }
+    qgemul_plan* p = c.plan;
+    void *dA, *dB, *dC, *pA, *pB, *pC;
     do {
-        st = qgemul_plan_create_ep(ctx, d, ep, opts.flags, &p);
-        if (st) break;
         const int64_t lda = opts.lda ? opts.lda : (d->transA ? d->K : d->M);
         const int64_t ldb = opts.ldb ? opts.ldb : d->K;
         const int64_t ldc = opts.ldc ? opts.ldc : d->M;
@@ -724,14 +791,16 @@ int qgemul_run_ep(const qgemul_desc* d, const qgemul_epilogue* ep, void* C, cons
         const size_t bytesA = (size_t)(((d->transA ? d->M : d->K) - 1) * lda + (d->transA ? d->K : d->M)) * p->ha.size;
         const size_t bytesB = (size_t)((d->N - 1) * ldb + d->K) * p->hb.size;
         const size_t bytesC = (size_t)((d->N - 1) * ldc + d->M) * p->hc.size;
-        if ((st = qgemul_dev_alloc(ctx, bytesA, &dA)) || (st = qgemul_dev_alloc(ctx, bytesB, &dB)) ||
-            (st = qgemul_dev_alloc(ctx, bytesC, &dC)) || (st = qgemul_dev_alloc(ctx, (size_t)p->info.packed_bytes[0], &pA)) ||
-            (st = qgemul_dev_alloc(ctx, (size_t)p->info.packed_bytes[1], &pB)) ||
-            (st = qgemul_dev_alloc(ctx, (size_t)p->info.packed_bytes[2], &pC)))
+        if ((st = cache_buffer(c, 0, bytesA, &dA)) || (st = cache_buffer(c, 1, bytesB, &dB)) || (st = cache_buffer(c, 2, bytesC, &dC)) ||
+            (st = cache_buffer(c, 3, (size_t)p->info.packed_bytes[0], &pA)) || (st = cache_buffer(c, 4, (size_t)p->info.packed_bytes[1], &pB)) ||
+            (st = cache_buffer(c, 5, (size_t)p->info.packed_bytes[2], &pC)))
             break;
-        if ((st = qgemul_memcpy_h2d(ctx, dA, A, bytesA)) || (st = qgemul_memcpy_h2d(ctx, dB, B, bytesB))) break;
+        hipStream_t s = ctx->stream;
+        // everything below is queued on the context's stream; ONE synchronisation at the end (the source buffers are the
+        // caller's and the call is synchronous, so they stay valid until then)
+        if (hipMemcpyAsync(dA, A, bytesA, hipMemcpyHostToDevice, s) != hipSuccess || hipMemcpyAsync(dB, B, bytesB, hipMemcpyHostToDevice, s) != hipSuccess) { st = QG_EHIP; break; }
         // the caller's C may have padding between columns (ldc > M): keep those bytes as they are
-        if (ldc != d->M && (st = qgemul_memcpy_h2d(ctx, dC, C, bytesC))) break;
+        if (ldc != d->M && hipMemcpyAsync(dC, C, bytesC, hipMemcpyHostToDevice, s) != hipSuccess) { st = QG_EHIP; break; }
         if ((st = qgemul_pack(p, QG_OPERAND_A, dA, lda, pA)) || (st = qgemul_pack(p, QG_OPERAND_B, dB, ldb, pB))) break;
         if (!ep) {
             if ((st = qgemul_execute(p, pC, pA, pB))) break;
@@ -746,22 +815,21 @@ int qgemul_run_ep(const qgemul_desc* d, const qgemul_epilogue* ep, void* C, cons
                     continue;
                 }
                 const size_t bytesE = (size_t)d->M * (size_t)d->N * eb;
-                if ((st = qgemul_dev_alloc(ctx, bytesE, &dE[k])) || (st = qgemul_dev_alloc(ctx, (size_t)qgemul_packed_e_bytes(p, (int)k), &pE[k])) ||
-                    (st = qgemul_memcpy_h2d(ctx, dE[k], E[k], bytesE)) || (st = qgemul_pack_e(p, (int)k, dE[k], 0, pE[k])))
+                void *dE, *pE;
+                if ((st = cache_buffer(c, 6 + 2 * (int)k, bytesE, &dE)) || (st = cache_buffer(c, 7 + 2 * (int)k, (size_t)qgemul_packed_e_bytes(p, (int)k), &pE)))
                     break;
-                ea.e_packed[k] = pE[k];
+                if (hipMemcpyAsync(dE, E[k], bytesE, hipMemcpyHostToDevice, s) != hipSuccess) { st = QG_EHIP; break; }
+                if ((st = qgemul_pack_e(p, (int)k, dE, 0, pE))) break;
+                ea.e_packed[k] = pE;
             }
             if (st) break;
             if ((st = qgemul_execute_ep(p, pC, pA, pB, &ea))) break;
         }
         if ((st = qgemul_unpack_c(p, pC, dC, ldc))) break;
-        if ((st = qgemul_memcpy_d2h(ctx, C, dC, bytesC))) break;
+        if (hipMemcpyAsync(C, dC, bytesC, hipMemcpyDeviceToHost, s) != hipSuccess) { st = QG_EHIP; break; }
     } while (0);
-    if (ctx) hipStreamSynchronize(ctx->stream);
-    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(pA); hipFree(pB); hipFree(pC);
-    for (int k = 0; k < QG_MAX_EW; ++k) { hipFree(dE[k]); hipFree(pE[k]); }
-    qgemul_plan_destroy(p);
-    qgemul_ctx_destroy(ctx);
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (st == QG_OK && e != hipSuccess) { g_last_hip = (int)e; st = QG_EHIP; }
     return st;
 }
 
