@@ -750,6 +750,10 @@ int qgemul_run_ep(const qgemul_desc* d, const qgemul_epilogue* ep, void* C, cons
     opts.device = -1;
     if (o) opts = *o;
     RunCache& c = g_run;
+    if (opts.device < 0 && c.ctx) {   // "current device": follow hipSetDevice calls the caller made between two calls
+        int cur = c.device;
+        if (hipGetDevice(&cur) == hipSuccess) opts.device = cur;
+    }
     const bool same_plan = c.plan && c.pflags == opts.flags && memcmp(&c.pd, d, sizeof *d) == 0 && c.has_pe == (ep != nullptr) &&
                            (!ep || memcmp(&c.pe, ep, sizeof *ep) == 0) && (opts.device < 0 || opts.device == c.device);
     if (!same_plan) {

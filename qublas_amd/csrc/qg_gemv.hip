@@ -311,7 +311,7 @@ hipError_t qg_launch_gemv(const QTreeTable* dev_table, int n_levels, int b_is_bi
                           int64_t K, int cbytes, hipStream_t st)
 {
     if (M <= 0) return hipSuccess;
-    if (K < 16 || (K & (K - 1)) || n_levels < 4 || n_levels > 12 + MAXUP) return hipErrorInvalidValue;
+    if (K < 16 || (K & (K - 1)) || n_levels < 4 || n_levels > 10 + MAXUP) return hipErrorInvalidValue;
     QGemvArgs g{dev_table, (const int32_t*)A, (const int32_t*)B, (char*)C, M, K, cbytes, n_levels, b_is_bit, 0};
     switch (K) {
     case 16: return launch_gemv_short<16>(g, st);

@@ -452,7 +452,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         if (one && W + 1 + T.mul[0].q.d <= 30) out->fast_mode = pf.O == QG_SAT_ZERO ? 1 : 2;
     }
     // one-column kernel (qg_gemv.hip): products are formed in 64 bits, everything else in 32
-    out->gemv_ok = (!cx && d->N == 1 && d->K >= 16 && (d->K & (d->K - 1)) == 0 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
+    out->gemv_ok = (!cx && d->N == 1 && d->K >= 16 && d->n_levels <= 30 && (d->K & (d->K - 1)) == 0 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     out->gemv_b_bit = (out->gemv_ok && d->b[0].I == 1 && d->b[0].F == 0 && !d->b[0].S && same(d->mul[0], d->a[0])) ? 1 : 0;
     out->cplx_fast_ok = (cx && d->K >= 32 && (d->K & (d->K - 1)) == 0 && d->n_levels <= 16 && c.max_bits <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     // fixed-mode variant of the complex kernel (BASELINE configuration 5's "RND + SAT"): every sub-operation and every tree
