@@ -156,6 +156,9 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     info->limbs[1] = LB;
     info->packed_bytes[0] = (int64_t)parts * (pa->limbs ? pa->limbs : 1) * pa->rows_p * pa->K_p * pa->cbytes;
     info->packed_bytes[1] = (int64_t)parts * (pb->limbs ? pb->limbs : 1) * pb->rows_p * pb->K_p * pb->cbytes;
+    // multi-limb operands carry their plane mask in a trailer behind the planes (QPackedGeom::trailer)
+    if (pa->limbs > 1) { pa->trailer = info->packed_bytes[0]; info->packed_bytes[0] += QG_TRAILER_BYTES; }
+    if (pb->limbs > 1) { pb->trailer = info->packed_bytes[1]; info->packed_bytes[1] += QG_TRAILER_BYTES; }
     info->packed_bytes[2] = (int64_t)parts * pc->Mp * pc->Np * pc->cbytes;
     *pLA = LA;
     *pLB = LB;
@@ -494,6 +497,8 @@ int qgemul_execute_ep(qgemul_plan* p, void* packedD, const void* packedA, const 
         m.cbytes = p->pc_c.cbytes;
         m.variant = p->variant;
         m.to_c = p->an.lin.to_c[0];
+        m.maskA = p->pa.trailer ? (const uint32_t*)((const char*)packedA + p->pa.trailer) : nullptr;
+        m.maskB = p->pb.trailer ? (const uint32_t*)((const char*)packedB + p->pb.trailer) : nullptr;
         m.has_ep = 1;
         m.ep = p->ept;
         m.epa = a;
@@ -551,6 +556,8 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
         a.cbytes = pcg.cbytes;
         a.variant = p->variant;
         a.to_c = p->an.lin.to_c[0];
+        a.maskA = p->pa.trailer ? (const uint32_t*)((const char*)packedA + p->pa.trailer) : nullptr;
+        a.maskB = p->pb.trailer ? (const uint32_t*)((const char*)packedB + p->pb.trailer) : nullptr;
         QG_HIP(qg_launch_mfma(p->LA, p->LB, a, st));
         return QG_OK;
     }
@@ -565,6 +572,8 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
         a.Kp = p->pa.K_p;
         a.cbytes = 8;
         a.variant = p->variant;
+        a.maskA = p->pa.trailer ? (const uint32_t*)((const char*)packedA + p->pa.trailer) : nullptr;
+        a.maskB = p->pb.trailer ? (const uint32_t*)((const char*)packedB + p->pb.trailer) : nullptr;
         memset(&a.to_c, 0, sizeof a.to_c);
         a.to_c.identity = 1;  // raw 64-bit dot products
         QG_HIP(qg_launch_mfma(p->LA, p->LB, a, st));

@@ -30,7 +30,13 @@ struct QPackedGeom {
     int32_t cbytes;         // container bytes (tree layout), 1 for limb layout
     int32_t limbs;          // 0 = tree layout, >0 = limb layout
     int32_t tr, bk;         // limb layout: rows per tile, k bytes per tile
+    // limb layout with limbs > 1: the planes are followed by a 256-byte trailer whose first word is the OR over all
+    // elements of (1 << l) for every limb l that is non-zero somewhere ("plane mask", written by the pack kernels).  The
+    // MFMA kernel skips the products of planes that are zero everywhere: data that stays inside [-32640, 32639] never
+    // touches the third int8 limb of a 17-bit format, and 4 instead of 9 products are exact for it.
+    int64_t trailer;        // byte offset of the trailer (0: none)
 };
+enum { QG_TRAILER_BYTES = 256 };
 
 struct QCGeom {
     int64_t M, N, Mp, Np;   // logical / padded extents of packed C
@@ -98,6 +104,8 @@ struct QMfmaArgs {
     int32_t cbytes;
     int32_t variant;
     QStep to_c;
+    const uint32_t* maskA;  // plane masks of the packed operands (QPackedGeom::trailer); nullptr: all planes
+    const uint32_t* maskB;
     int32_t has_ep, pad_;   // fused element-wise epilogue: C below is then packed D (ep.dbytes containers)
     QEpTable ep;
     QEpArgs epa;

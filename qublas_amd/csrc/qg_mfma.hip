@@ -45,9 +45,22 @@ __device__ __forceinline__ int swz(int r)
 
 // LA, LB : int8 limbs per A / B element          BK       : k-tile in bytes
 // WGM x WGN waves per workgroup                  TI x TJ  : 32x32 MFMA tiles per wave
-template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE, int ABL, bool EP>   // EP: fused element-wise epilogue
+// SA, SB: limb planes STORED per operand (>= LA, LB).  Multi-limb operands carry a plane mask in their trailer
+// (QPackedGeom::trailer): a plane that is zero in the whole operand contributes nothing, so 17-bit data that stays inside
+// [-32640, 32639] never touches the third int8 limb and its product needs 4 limb products instead of 9 — exactly.  For 3 x 3
+// stored planes the launcher starts TWO kernels back to back, <3,3> and <2,2 on 3,3-plane storage>; each reads the masks and
+// returns in its first instructions unless it is the one that fits, so the choice is made on the device from data that
+// travels with the packed operand (no host read-back, no stale host state).  (One kernel with a run-time-masked MFMA
+// sequence was measured: it spills and runs 2.4x slower than the full sequence.)
+template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE, int ABL, bool EP, int SA = LA, int SB = LB>   // EP: fused element-wise epilogue
 __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 {
+    if constexpr (SA == 3 && SB == 3 && ABL == 0) {
+        const unsigned ma = g.maskA ? (unsigned)__builtin_amdgcn_readfirstlane(*g.maskA) : 7u;
+        const unsigned mb = g.maskB ? (unsigned)__builtin_amdgcn_readfirstlane(*g.maskB) : 7u;
+        const bool two_planes_suffice = ((ma | mb) & 4u) == 0;
+        if (two_planes_suffice != (LA == 2)) return;   // the other kernel of this launch pair does the work
+    }
     constexpr int TM = WGM * TI * 32, TN = WGN * TJ * 32;
     constexpr int NWAVES = WGM * WGN;
     constexpr int NW = LA + LB - 1;            // limb weights
@@ -83,16 +96,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
     // operands are pre-tiled: block (row tile, k tile) of A is LA*TM*BK contiguous bytes that are
     // already the swizzled LDS image; same for B.  A stage is two linear copies.
     const int nk = (int)(g.Kp / BK);
-    constexpr int A_BYTES = LA * TM * BK, B_BYTES = LB * TN * BK;
+    constexpr int A_BYTES = LA * TM * BK, B_BYTES = LB * TN * BK;       // copied per stage (the first LA / LB planes)
+    constexpr int A_STORED = SA * TM * BK, B_STORED = SB * TN * BK;     // stride of a (row tile, k tile) block in memory
     constexpr int A_PIECES = A_BYTES / 1024;
-    const int8_t* Ag = g.A + (int64_t)tile_m * nk * A_BYTES + lane * 16;
-    const int8_t* Bg = g.B + (int64_t)tile_n * nk * B_BYTES + lane * 16;
+    const int8_t* Ag = g.A + (int64_t)tile_m * nk * A_STORED + lane * 16;
+    const int8_t* Bg = g.B + (int64_t)tile_n * nk * B_STORED + lane * 16;
 
     auto issue = [&](int stage, int kt) {
         char* sbase = smem + stage * STAGE;
         const int kts = ABL == 6 ? 0 : kt;  // diagnostic: re-read k-tile 0 (cache hits) to separate DMA cost from traffic cost
-        const int8_t* a = Ag + (int64_t)kts * A_BYTES;
-        const int8_t* b = Bg + (int64_t)kts * B_BYTES;
+        const int8_t* a = Ag + (int64_t)kts * A_STORED;
+        const int8_t* b = Bg + (int64_t)kts * B_STORED;
 #pragma unroll
         for (int pi = 0; pi < PPW; ++pi) {
             const int p = wave + NWAVES * pi;       // wave-uniform piece id
@@ -482,6 +496,20 @@ hipError_t launch(const QMfmaArgs& a, hipStream_t st)
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll || a.Kp % BK || a.Mp % TM || a.Np % TN) return hipErrorInvalidValue;
     hipLaunchKernelGGL((k_mfma<LA, LB, BK, WGM, WGN, TI, TJ, NSTAGE, ABL, EP>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
+    if constexpr (LA == 3 && LB == 3 && ABL == 0) {
+        static const bool no_partner = getenv("QG_NO_PLANE_MASK") != nullptr;   // A/B switch (tools/measure_masked.py); full-range data only!
+        if ((a.maskA || a.maskB) && !no_partner) {
+            // the partner for operands whose third limb planes are empty: 2 x 2 limbs read from the 3-plane storage
+            constexpr int lds2 = NSTAGE * (2 * TM + 2 * TN) * BK;
+            static bool attr_set2 = false;
+            if (!attr_set2) {
+                hipError_t e = hipFuncSetAttribute((const void*)k_mfma<2, 2, BK, WGM, WGN, TI, TJ, NSTAGE, ABL, EP, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+                if (e != hipSuccess) return e;
+                attr_set2 = true;
+            }
+            hipLaunchKernelGGL((k_mfma<2, 2, BK, WGM, WGN, TI, TJ, NSTAGE, ABL, EP, 3, 3>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds2, st, a);
+        }
+    }
     return hipGetLastError();
 }
 

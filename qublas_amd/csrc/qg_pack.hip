@@ -66,8 +66,9 @@ __device__ __forceinline__ int64_t quantize_f64(double v, int W, int S, int F, i
 }
 
 // write one logical value (r,k,part) into the packed operand
-__device__ __forceinline__ void put_packed(const QPackedGeom& p, char* dst, int part, int64_t r, int64_t k, int64_t v)  // r, k: indices inside the part
+__device__ __forceinline__ unsigned put_packed(const QPackedGeom& p, char* dst, int part, int64_t r, int64_t k, int64_t v)  // r, k: indices inside the part
 {
+    unsigned mask = 0;   // bit l: limb l of this value is non-zero
     if (p.limbs == 0) {
         store_container(dst, ((int64_t)part * p.rows_p + r) * p.K_p + k, p.cbytes, v);
     } else {
@@ -84,9 +85,11 @@ __device__ __forceinline__ void put_packed(const QPackedGeom& p, char* dst, int 
         for (int l = 0; l < p.limbs; ++l) {
             int64_t d = (int64_t)(int8_t)(v & 0xff); // balanced digit in [-128,127]
             ((int8_t*)dst)[((blk + l) * p.tr + rl) * p.bk + slot * 16 + (kl & 15)] = (int8_t)d;
+            mask |= d ? (1u << l) : 0u;
             v = (v - d) >> 8;
         }
     }
+    return mask;
 }
 
 // tile = 64 (k) x 64 (r); 256 threads.  The fast host axis is r when g.rs == 1 (non-transposed A)
@@ -126,9 +129,15 @@ __global__ __launch_bounds__(256) void k_pack(QOperandGeom g, QPackedGeom p, con
         else tile[tx][i] = v;         // tile[k_local][r_local] with tx = k_local
     }
     __syncthreads();
+    unsigned mask = 0;
     for (int i = ty; i < 64; i += 4) {
         int64_t r = tr * 64 + i, k = tk * 64 + tx;
-        if (r < p.rows_p && k < p.K_p) put_packed(p, dst, part, r, k, tile[tx][i]);
+        if (r < p.rows_p && k < p.K_p) mask |= put_packed(p, dst, part, r, k, tile[tx][i]);
+    }
+    if (p.trailer) {   // plane mask of the operand: one atomic per wave that saw a non-zero limb
+#pragma unroll
+        for (int o = 32; o; o >>= 1) mask |= __shfl_xor(mask, o);
+        if (tx == 0 && mask) atomicOr((unsigned*)(dst + p.trailer), mask);
     }
     if (bad) atomicOr(flag, 1);
 }
@@ -248,12 +257,18 @@ hipError_t qg_launch_cplx_combine(const QCplxCombine& g, hipStream_t st)
     return hipGetLastError();
 }
 
+static hipError_t zero_trailer(const QPackedGeom& p, void* dst, hipStream_t st)
+{
+    return p.trailer ? hipMemsetAsync((char*)dst + p.trailer, 0, QG_TRAILER_BYTES, st) : hipSuccess;
+}
+
 hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const void* src, void* dst, int check_range,
                           int* range_flag, hipStream_t st)
 {
     int64_t blocks = ((p.K_p + 63) / 64) * ((p.rows_p + 63) / 64) * g.parts;
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
+    if (hipError_t e = zero_trailer(p, dst, st); e != hipSuccess) return e;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)blocks), dim3(256), 0, st, g, p, (const char*)src, (char*)dst, check_range,
                        range_flag, 0, 0ull, 0);
     return hipGetLastError();
@@ -264,6 +279,7 @@ hipError_t qg_launch_pack_f64(const QOperandGeom& g, const QPackedGeom& p, const
     int64_t blocks = ((p.K_p + 63) / 64) * ((p.rows_p + 63) / 64) * g.parts;
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
+    if (hipError_t e = zero_trailer(p, dst, st); e != hipSuccess) return e;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)blocks), dim3(256), 0, st, g, p, (const char*)src, (char*)dst, 0, (int*)nullptr, 2, 0ull, 0);
     return hipGetLastError();
 }
@@ -273,6 +289,7 @@ hipError_t qg_launch_fill(const QOperandGeom& g, const QPackedGeom& p, uint64_t 
     int64_t blocks = ((p.K_p + 63) / 64) * ((p.rows_p + 63) / 64) * g.parts;
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
+    if (hipError_t e = zero_trailer(p, dst, st); e != hipSuccess) return e;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)blocks), dim3(256), 0, st, g, p, (const char*)nullptr, (char*)dst, 0,
                        (int*)nullptr, 1, seed, dist);
     return hipGetLastError();

@@ -313,3 +313,28 @@ def test_complex_linear_class_on_mfma(oracle):
     B8 = BasicComplexMul(acT=Qu(9, 6), bdT=Qu(9, 6), adT=Qu(9, 6), bcT=Qu(9, 6), acbdT=Qu(11, 6), adbcT=Qu(11, 6))
     l8 = Qcomplex(Qu(22, 6), Qu(22, 6))
     _vs_oracle(oracle, c8, c8, Qcomplex(Qu(16, 3), Qu(16, 3)), 300, 200, 1024, mul_args=B8, add_args=[l8], expect_kernel="mfma_cplx")
+
+
+@pytest.mark.parametrize("amax,bmax", [(32639, 32639), (32640, 32639), (32639, 32640), (65535, 127), (127, 127), (0, 65535)])
+def test_limb_plane_mask_dispatch(oracle, amax, bmax):
+    """3x3-limb operands carry a plane mask; when the third int8 limb plane of BOTH operands is empty (all values inside
+    [-32640, 32639]) a 2x2-limb kernel does the work, otherwise the 3x3 one — chosen on the device.  Values sit exactly on
+    the boundary: 32639 is the largest two-limb value, 32640 / -32641 need the third limb."""
+    M, N, K = 192, 130, 256
+    wide = Qu(26, 8)
+    d = lower(E88Z, E88Z, wide, M, N, K, mul_args=Tags(17, 16), add_args=[Qu(29, 16)])
+    assert capi.KERNEL_NAMES[capi.classify(d).kernel] == "mfma_i8_limb"
+    rng = np.random.default_rng(amax * 7 + bmax)
+
+    def operand(n, vmax):
+        x = rng.integers(-vmax - 1, vmax + 1, n, dtype=np.int64) if vmax else np.zeros(n, dtype=np.int64)
+        if vmax:
+            x[:4] = [vmax, -vmax - 1, vmax, 0]      # the extremes are present
+        return np.clip(x, E88Z.raw_min, E88Z.raw_max).astype(np.int32)
+    A, B = operand(M * K, amax), operand(K * N, bmax)
+    got = run_gpu(d, A, B, wide, oracle)
+    assert np.array_equal(got, oracle.gemm(d, A, B, wide, nthreads=8))
+    # re-packing other data into the SAME cached device buffers must not leave a stale mask behind
+    A2 = operand(M * K, 65535)
+    got2 = run_gpu(d, A2, B, wide, oracle)
+    assert np.array_equal(got2, oracle.gemm(d, A2, B, wide, nthreads=8))
