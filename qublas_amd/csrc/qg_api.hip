@@ -145,8 +145,12 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
         const bool fast = !(flags & QG_OPT_GENERIC_TREE);
         kernel = d->is_complex ? ((an->cplx_fast_ok && fast) ? QG_KERNEL_TREE_CPLX_I32 : QG_KERNEL_TREE_CPLX)
                                : ((an->gemv_ok && fast) ? QG_KERNEL_GEMV_I32 : (an->tree_fast_ok && fast) ? QG_KERNEL_TREE_I32 : QG_KERNEL_TREE_I64);
-        *pa = QPackedGeom{d->M, d->K, info->in_bits[0] <= 32 ? 4 : 8, 0, 0, 0};
-        *pb = QPackedGeom{d->N, d->K, info->in_bits[1] <= 32 ? 4 : 8, 0, 0, 0};
+        // the 32-bit tree kernels walk a perfect binary tree: their operands are zero-padded along K to 2^n_levels leaves
+        // (a node whose right child is a zero leaf / zero subtree is the reference's converting copy of an odd leftover)
+        const int64_t Kt = (kernel == QG_KERNEL_TREE_I32 || kernel == QG_KERNEL_TREE_CPLX_I32 || kernel == QG_KERNEL_GEMV_I32)
+                               ? ((int64_t)1 << d->n_levels) : d->K;
+        *pa = QPackedGeom{d->M, Kt, info->in_bits[0] <= 32 ? 4 : 8, 0, 0, 0};
+        *pb = QPackedGeom{d->N, Kt, info->in_bits[1] <= 32 ? 4 : 8, 0, 0, 0};
         pc->Mp = d->M;
         pc->Np = d->N;
         pc->tm = pc->tn = 0;
@@ -597,16 +601,16 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
     case QG_KERNEL_TREE_I32:
         QG_HIP(qg_launch_tree_fast(p->dev_table, (int)p->desc.n_levels, p->an.split_s, p->an.mul24_ok,
                                    (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : p->an.fast_mode, packedA, packedB, packedC,
-                                   p->desc.M, p->desc.N, p->desc.K, pcg.cbytes, st));
+                                   p->desc.M, p->desc.N, p->pa.K_p, pcg.cbytes, st));
         return QG_OK;
     case QG_KERNEL_GEMV_I32:
-        QG_HIP(qg_launch_gemv(p->dev_table, (int)p->desc.n_levels, p->an.gemv_b_bit, packedA, packedB, packedC, p->desc.M, p->desc.K,
+        QG_HIP(qg_launch_gemv(p->dev_table, (int)p->desc.n_levels, p->an.gemv_b_bit, packedA, packedB, packedC, p->desc.M, p->pa.K_p,
                               pcg.cbytes, st));
         return QG_OK;
     case QG_KERNEL_TREE_CPLX_I32:
         QG_HIP(qg_launch_tree_cplx_fast(p->dev_table, (int)p->desc.n_levels, (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : p->an.cplx_fixed_ok,
                                         packedA, packedB, packedC, p->desc.M, p->desc.N,
-                                        p->desc.K, p->pc.cbytes, st));
+                                        p->pa.K_p, p->pc.cbytes, st));
         return QG_OK;
     case QG_KERNEL_TREE_I64:
     case QG_KERNEL_TREE_CPLX:

@@ -426,7 +426,9 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     // unrounded product fits 31 bits, and the product is either directly 32-bit or splittable at
     // its rounding shift
     out->tree_fast_ok = 0;
-    if (!cx && d->K >= 32 && (d->K & (d->K - 1)) == 0 && d->n_levels <= 16 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) {
+    // (any K with 5..16 levels: the packed operands are zero-padded to 2^n_levels leaves — a node whose right child is a
+    // zero is the reference's converting copy of an odd leftover, QuBLAS.h:4977-4980)
+    if (!cx && d->n_levels >= 5 && d->n_levels <= 16 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) {
         const int bitsA = 1 + (int)d->a[0].I + (int)d->a[0].F, bitsB = 1 + (int)d->b[0].I + (int)d->b[0].F;
         const int sh = T.mul[0].q.d;
         int bh = bitsB - sh;
@@ -452,9 +454,9 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         if (one && W + 1 + T.mul[0].q.d <= 30) out->fast_mode = pf.O == QG_SAT_ZERO ? 1 : 2;
     }
     // one-column kernel (qg_gemv.hip): products are formed in 64 bits, everything else in 32
-    out->gemv_ok = (!cx && d->N == 1 && d->K >= 16 && d->n_levels <= 30 && (d->K & (d->K - 1)) == 0 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
+    out->gemv_ok = (!cx && d->N == 1 && d->n_levels >= 4 && d->n_levels <= 30 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     out->gemv_b_bit = (out->gemv_ok && d->b[0].I == 1 && d->b[0].F == 0 && !d->b[0].S && same(d->mul[0], d->a[0])) ? 1 : 0;
-    out->cplx_fast_ok = (cx && d->K >= 32 && (d->K & (d->K - 1)) == 0 && d->n_levels <= 16 && c.max_bits <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
+    out->cplx_fast_ok = (cx && d->n_levels >= 5 && d->n_levels <= 16 && c.max_bits <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     // fixed-mode variant of the complex kernel (BASELINE configuration 5's "RND + SAT"): every sub-operation and every tree
     // step either the identity, or an exact left shift / a rounding shift with RND::POS_INF, followed by SAT::TCPL, so a
     // step is (v + 2^(d-1)) >> d (or v << -d) and one clamp

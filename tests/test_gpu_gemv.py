@@ -79,7 +79,19 @@ def test_kernel_choice_is_invariant(oracle):
     assert np.array_equal(outs[0], oracle.gemm(d, A, B, Qu(16, 3), nthreads=8))
 
 
-def test_non_power_of_two_and_short_vectors_use_the_general_kernels(oracle):
-    for K in (255, 1000, 8, 24):
+@pytest.mark.parametrize("K", [9, 17, 100, 255, 1000, 5000])
+def test_any_length(oracle, K):
+    """lengths that are not powers of two: operands zero-padded to 2^ceil(log2 K) leaves (a node with a zero right child is
+    the reference's converting copy of an odd leftover); default levels and a level list that rounds for real"""
+    _check(oracle, lower_reduce(E88, 333, K), E88, None, E88, dist=1, ones=True)
+    lv = [Qu(9, 8, True, RND.ZERO, SAT.TCPL), Qu(11, 5, True, RND.INF, WRP.TCPL), Qu(14, 3, True, TRN.SMGN, SAT.ZERO)]
+    d = lower_reduce(E88, 333, K, lv)
+    _check(oracle, d, E88, None, Qu.from_tuple([d.c[0].I, d.c[0].F, d.c[0].S, d.c[0].Q, d.c[0].O]), ones=True)
+    _check(oracle, lower(E43, E43, Qu(12, 3), 100, 1, K), E43, E43, Qu(12, 3))
+
+
+def test_very_short_vectors_use_the_general_kernels(oracle):
+    for K in (1, 2, 5, 8):
         d = lower_reduce(E88, 64, K)
-        assert capi.KERNEL_NAMES[capi.classify(d).kernel] in ("tree_i32", "tree_i64")
+        assert capi.KERNEL_NAMES[capi.classify(d).kernel] != "gemv_i32"
+        _check(oracle, d, E88, None, E88, dist=1, ones=True, expect=capi.KERNEL_NAMES[capi.classify(d).kernel])

@@ -176,7 +176,8 @@ def test_config5_complex_tf(oracle):
     b = _vs_oracle(oracle, c5, c5, wide, 64, 48, 2048, dist=1, mul_args=TFComplexMul(), flags=capi.OPT_GENERIC_TREE,
                    expect_kernel="tree_cplx")
     assert fields_equal(a, b)
-    _vs_oracle(oracle, c5, c5, wide, 40, 24, 100, dist=1, mul_args=BasicComplexMul(), transposed_a=True, expect_kernel="tree_cplx")
+    _vs_oracle(oracle, c5, c5, wide, 40, 24, 100, dist=1, mul_args=BasicComplexMul(), transposed_a=True, expect_kernel="tree_cplx_i32")   # K = 100: zero-padded to 128 leaves
+    _vs_oracle(oracle, c5, c5, wide, 40, 24, 13, dist=1, mul_args=BasicComplexMul(), transposed_a=True, expect_kernel="tree_cplx")      # 4 levels: general kernel
     _vs_oracle(oracle, c5, c5, wide, 70, 33, 256, dist=0, mul_args=BasicComplexMul(), transposed_a=True, expect_kernel="tree_cplx_i32")
 
 
@@ -338,3 +339,25 @@ def test_limb_plane_mask_dispatch(oracle, amax, bmax):
     A2 = operand(M * K, 65535)
     got2 = run_gpu(d, A2, B, wide, oracle)
     assert np.array_equal(got2, oracle.gemm(d, A2, B, wide, nthreads=8))
+
+
+@pytest.mark.parametrize("K", [17, 33, 100, 255, 257, 1000, 1023, 1025, 3000])
+def test_any_k_on_the_32bit_tree_kernels(oracle, K):
+    """K need not be a power of two: the 32-bit tree kernels run on operands zero-padded to 2^ceil(log2 K) leaves, where a
+    node whose right child is zero IS the reference's converting copy of an odd leftover (QuBLAS.h:4977-4980).  Against the
+    oracle (which implements the leftover rule literally) and against the general 64-bit kernel, with level types that
+    round and saturate for real, real and complex."""
+    lv = [Qu(9, 6, True, RND.CONV, SAT.SMGN), Qu(11, 4, True, RND.ZERO, SAT.TCPL), Qu(12, 2, True, TRN.SMGN, WRP.TCPL)]
+    for kw in (dict(), dict(mul_args=Qu(5, 4, True, RND.INF, SAT.TCPL), add_args=lv)):
+        a = _vs_oracle(oracle, E43, E43, W16, 37, 21, K, expect_kernel="tree_i32", **kw)
+        b = _vs_oracle(oracle, E43, E43, W16, 37, 21, K, flags=capi.OPT_GENERIC_TREE, expect_kernel="tree_i64", **kw)
+        assert np.array_equal(a, b)
+    _vs_oracle(oracle, E88Z, E88Z, E88Z, 20, 33, K, dist=1, expect_kernel="tree_i32")      # biased SAT::ZERO fixed-mode variant
+    r55 = Qu(5, 5)
+    c55 = Qcomplex(r55, r55)
+    wide = Qcomplex(Qu(18, 6, True, RND.POS_INF), Qu(18, 6, True, RND.POS_INF))
+    l1 = Qcomplex(Qu(12, 4, True, RND.CONV, SAT.SMGN), Qu(11, 6, True, TRN.SMGN, SAT.ZERO))
+    if K <= 1025:
+        a = _vs_oracle(oracle, c55, c55, wide, 9, 7, K, mul_args=TFComplexMul(), add_args=[l1], expect_kernel="tree_cplx_i32")
+        b = _vs_oracle(oracle, c55, c55, wide, 9, 7, K, mul_args=TFComplexMul(), add_args=[l1], flags=capi.OPT_GENERIC_TREE, expect_kernel="tree_cplx")
+        assert fields_equal(a, b)
