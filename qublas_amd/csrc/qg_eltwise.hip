@@ -2,7 +2,7 @@
 //
 //  * k_eltwise: the qgemul_epilogue chain as a pass over packed C -> packed D, for the kernels that do not fuse it
 //    (the exact tree kernels).  C, the tensor operands and D share ONE index space (the plan's packed-C layout),
-//    so the pass is linear in memory: every lane handles 4 consecutive elements.  HBM-bound:
+//    so the pass is linear in memory: every lane handles 16 consecutive elements.  HBM-bound:
 //    (cbytes + sum ebytes + dbytes) bytes per element.
 //  * k_pack_e: a tensor operand in reference layout (column-major M x N, QuBLAS.h:2680-2692) -> that index space.
 #include <hip/hip_runtime.h>
@@ -24,23 +24,28 @@ __device__ __forceinline__ void store_one(char* dst, int64_t idx, int bytes, int
 
 __global__ __launch_bounds__(256) void k_eltwise(QEltwiseArgs g)
 {
-    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    // 16 consecutive elements per lane (4 runs of 4): enough independent loads in flight per lane for 1-byte containers too
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
     if (i0 >= g.n) return;
-    if (i0 + 4 <= g.n) {
+    if (i0 + 16 <= g.n) {
         if (g.t.bits32) {
-            int32_t v[4];
-            qg_ep_load_run<4, int32_t>(g.C, i0, g.cbytes, v);
-            qg_ep_apply_runs<int32_t, 1>(v, g.t, g.a, i0, 0);
-            qg_ep_store_run<int32_t>(g.D, i0, g.t.dbytes, v);
+            int32_t v[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) qg_ep_load_run<4, int32_t>(g.C, i0 + 4 * q, g.cbytes, v + 4 * q);
+            qg_ep_apply_runs<int32_t, 4>(v, g.t, g.a, i0, 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) qg_ep_store_run<int32_t>(g.D, i0 + 4 * q, g.t.dbytes, v + 4 * q);
         } else {
-            int64_t v[4];
-            qg_ep_load_run<4, int64_t>(g.C, i0, g.cbytes, v);
-            qg_ep_apply_runs<int64_t, 1>(v, g.t, g.a, i0, 0);
-            qg_ep_store_run<int64_t>(g.D, i0, g.t.dbytes, v);
+            int64_t v[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) qg_ep_load_run<4, int64_t>(g.C, i0 + 4 * q, g.cbytes, v + 4 * q);
+            qg_ep_apply_runs<int64_t, 4>(v, g.t, g.a, i0, 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) qg_ep_store_run<int64_t>(g.D, i0 + 4 * q, g.t.dbytes, v + 4 * q);
         }
         return;
     }
-    for (int64_t i = i0; i < g.n; ++i) {   // tail of a packed C whose size is not a multiple of 4
+    for (int64_t i = i0; i < g.n; ++i) {   // tail of a packed C whose size is not a multiple of 16
         int64_t v[1] = {qg_ep_load_one(g.C, i, g.cbytes)};
         for (int k = 0; k < g.t.n; ++k) {
             int64_t e[1] = {g.t.st[k].scalar ? g.a.scalar[k] : qg_ep_load_one(g.a.e[k], i, g.t.st[k].ebytes)};
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(256) void k_pack_e(QCGeom c, const char* __restrict
 hipError_t qg_launch_eltwise(const QEltwiseArgs& g, hipStream_t st)
 {
     if (g.n <= 0) return hipSuccess;
-    const int64_t blocks = (g.n + 1023) / 1024;
+    const int64_t blocks = (g.n + 4095) / 4096;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_eltwise, dim3((unsigned)blocks), dim3(256), 0, st, g);
     return hipGetLastError();
