@@ -668,20 +668,20 @@ static int time_execute(qgemul_plan* p, void* packedC, const void* packedA, cons
         int s = once();
         if (s) return s;
     }
-    hipEvent_t e0, e1;
-    QG_HIP(hipEventCreate(&e0));
-    QG_HIP(hipEventCreate(&e1));
-    QG_HIP(hipEventRecord(e0, st));
-    for (int i = 0; i < iters; ++i) {
-        int s = once();
-        if (s) return s;
-    }
-    QG_HIP(hipEventRecord(e1, st));
-    QG_HIP(hipEventSynchronize(e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = QG_OK;
     float ms = 0;
-    QG_HIP(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    hipError_t he = hipEventCreate(&e0);
+    if (he == hipSuccess) he = hipEventCreate(&e1);
+    if (he == hipSuccess) he = hipEventRecord(e0, st);
+    for (int i = 0; he == hipSuccess && rc == QG_OK && i < iters; ++i) rc = once();
+    if (he == hipSuccess && rc == QG_OK) he = hipEventRecord(e1, st);
+    if (he == hipSuccess && rc == QG_OK) he = hipEventSynchronize(e1);
+    if (he == hipSuccess && rc == QG_OK) he = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) hipEventDestroy(e0);   // (released on every path)
+    if (e1) hipEventDestroy(e1);
+    if (he != hipSuccess) { g_last_hip = (int)he; return QG_EHIP; }
+    if (rc != QG_OK) return rc;
     *avg_ms = ms / (float)iters;
     return QG_OK;
 }
