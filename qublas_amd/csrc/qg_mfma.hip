@@ -231,6 +231,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
         }
         cur = nx;
     }
+    // the branch-free refill leaves LDS-DMA transfers of the clamped tile in flight: they must have landed before this
+    // workgroup can end and its LDS be handed to another one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // epilogue: recombine limb weights, ONE round + overflow into C, store.
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5),
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 typedef int v4acc __attribute__((ext_vector_type(4)));
 
 // LA x LB limbs; DBUF: fragments double-buffered across k-tiles (only when the registers allow it)
-template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF, bool EP>   // TI x TJ tiles of 16x16 per wave
+template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF, bool EP, bool HINT = true>   // TI x TJ tiles of 16x16 per wave
 __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
 {
     constexpr int BK = 64, NSTAGE = 3;
@@ -417,17 +420,29 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
             for (int h = 0; h < 2; ++h) {
                 const int k = kt + h;
                 if (k < nk) {
-                    if (k + 1 < nk) {
+                    // branch-free body (past the end: the last tile is fetched once more into a stage nobody reads again, and
+                    // fragments are read from it in vain) so that DMA issues, fragment reads and MFMAs share one basic block
+                    // and interleave_hint can spread them
+                    if constexpr (HINT) {
                         publish();
-                        if (k + 2 < nk) issue(st2, k + 2);
+                        issue(st2, k + 2 < nk ? k + 2 : nk - 1);
                         load_frags(DBUF ? (h ^ 1) : 0, smem + st1 * STAGE);
+                        mfmas(DBUF ? h : 0);
+                        interleave_hint<LA * LB * TI * TJ, LA * TI + LB * TJ, PPW>(std::make_integer_sequence<int, LA * LB * TI * TJ>{});
+                    } else {   // the compiler's own issue order (A/B: QG_NO_HINT16)
+                        if (k + 1 < nk) {
+                            publish();
+                            if (k + 2 < nk) issue(st2, k + 2);
+                            load_frags(DBUF ? (h ^ 1) : 0, smem + st1 * STAGE);
+                        }
+                        mfmas(DBUF ? h : 0);
                     }
-                    mfmas(DBUF ? h : 0);
                     st1 = st2;
                     st2 = (st1 + 1) % 3;
                 }
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // in-flight LDS-DMA of the clamped refill must land before the workgroup ends
     }
 
     // epilogue: recombine limb weights, one round + overflow into C, store runs of 4 rows (column-major tile)
@@ -484,9 +499,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
     }
 }
 
-template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF, bool EP = false>
+template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF, bool EP = false, bool HINT = true>
 hipError_t launch16(const QMfmaArgs& a, hipStream_t st)
 {
+    if constexpr (HINT && !EP) {
+        static const bool no_hint = getenv("QG_NO_HINT16") != nullptr;
+        if (no_hint && !a.has_ep) return launch16<LA, LB, WGM, WGN, TI, TJ, DBUF, false, false>(a, st);
+    }
     if constexpr (!EP) {
         if (a.has_ep) return launch16<LA, LB, WGM, WGN, TI, TJ, DBUF, true>(a, st);
     }
@@ -495,14 +514,14 @@ hipError_t launch16(const QMfmaArgs& a, hipStream_t st)
     const int lds = 3 * (LA * TM + LB * TN) * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF, EP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF, EP, HINT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int64_t blocks = (a.Mp / TM) * (a.Np / TN);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll || a.Kp % 64 || a.Mp % TM || a.Np % TN) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF, EP>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
+    hipLaunchKernelGGL((k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF, EP, HINT>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
     return hipGetLastError();
 }
 
