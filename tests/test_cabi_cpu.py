@@ -116,3 +116,11 @@ def test_int32_kernels_need_32bit_formats():
     assert capi.KERNEL_NAMES[capi.classify(d).kernel] == "tree_i64"
     d = lower(e, e, Qu(16, 3), 64, 64, 64, add_args=[Qu(20, 3)])
     assert capi.KERNEL_NAMES[capi.classify(d).kernel] == "tree_i32"
+
+
+def test_smoke_expectations_hold_without_a_gpu():
+    """__graft_entry__.smoke() asserts which kernel each of its cases runs on; the planner decides that on the host, so the
+    expectations are checked here too (a planner change once turned the smoke red only on the GPU box)."""
+    import __graft_entry__ as g
+    for kernel, d, *_ in g.smoke_cases():
+        assert capi.KERNEL_NAMES[capi.classify(d).kernel] == kernel
