@@ -361,3 +361,37 @@ def test_any_k_on_the_32bit_tree_kernels(oracle, K):
         a = _vs_oracle(oracle, c55, c55, wide, 9, 7, K, mul_args=TFComplexMul(), add_args=[l1], expect_kernel="tree_cplx_i32")
         b = _vs_oracle(oracle, c55, c55, wide, 9, 7, K, mul_args=TFComplexMul(), add_args=[l1], flags=capi.OPT_GENERIC_TREE, expect_kernel="tree_cplx")
         assert fields_equal(a, b)
+
+
+def test_one_shot_call_from_several_threads(oracle):
+    """qgemul_run keeps a cache per calling thread (context, plan, device buffers): concurrent callers with different
+    descriptors must neither crash nor see each other's buffers; alternating descriptors in one thread re-plans."""
+    import threading
+    specs = [(E43, W16, 96, 80, 128, dict(mul_args=Tags(9, 6), add_args=[Qu(19, 6)])),
+             (E88Z, Qu(24, 8), 64, 72, 192, dict(mul_args=Tags(17, 16), add_args=[Qu(29, 16)])),
+             (E88Z, E88Z, 40, 56, 100, dict()),
+             (E43, E43, 33, 17, 77, dict())]
+    jobs = []
+    for e, ec, M, N, K, kw in specs:
+        d = lower(e, e, ec, M, N, K, **kw)
+        A, B = oracle.fill(e, M * K, 11, 0), oracle.fill(e, K * N, 12, 0)
+        jobs.append((d, A, B, ec, oracle.gemm(d, A, B, ec, nthreads=4)))
+    errors = []
+
+    def worker(order):
+        try:
+            for _ in range(6):
+                for i in order:
+                    d, A, B, ec, exp = jobs[i]
+                    got = run_gpu(d, A, B, ec, oracle)
+                    if not np.array_equal(got, exp):
+                        errors.append(("mismatch", i))
+            capi.run_release()
+        except Exception as ex:   # noqa: BLE001
+            errors.append(repr(ex))
+    threads = [threading.Thread(target=worker, args=(o,)) for o in ([0, 1, 2, 3], [3, 2, 1, 0], [1, 1, 3, 0], [2, 0, 2, 1])]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
