@@ -579,6 +579,11 @@ QMfmaCfg qg_mfma_pick(int LA, int LB, int64_t M, int64_t N)
         if (!no_small && mid <= 128 && ((M + 63) / 64) * ((N + 63) / 64) > mid) return QMfmaCfg{5, 64, 64, 64};
         return QMfmaCfg{1, 128, 128, 64};
     }
+    {   // limb kernels: the same small-problem rule (1024^2 outputs: 64 -> 256 workgroups)
+        static const bool no_small = getenv("QG_NO_SMALL_TILES") != nullptr;
+        const int64_t mid = ((M + 127) / 128) * ((N + 127) / 128);
+        if (!no_small && mid <= 128 && ((M + 63) / 64) * ((N + 63) / 64) > mid) return QMfmaCfg{6, 64, 64, 64};
+    }
     return QMfmaCfg{3, 128, 128, 64};
 }
 
@@ -623,6 +628,19 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
         if (ablation() == 32) return a.variant == 2 ? launch<1, 1, 64, 2, 4, 4, 2, 3>(a, st) : launch<1, 1, 64, 2, 2, 2, 2, 3>(a, st);
         if (a.variant == 2) return launch16<1, 1, 2, 4, 8, 4, true>(a, st);
         return launch<1, 1, 64, 2, 2, 2, 2, 3>(a, st);  // 128x128 tiles (small problems): the 32x32x32 kernel is the faster one there
+    }
+    if (a.variant == 6) {   // 64x64 tiles, 4 waves, one 32x32 MFMA tile per wave
+        switch (LA * 10 + LB) {
+        case 12: return launch<1, 2, 64, 2, 2, 1, 1, 3>(a, st);
+        case 21: return launch<2, 1, 64, 2, 2, 1, 1, 3>(a, st);
+        case 22: return launch<2, 2, 64, 2, 2, 1, 1, 3>(a, st);
+        case 13: return launch<1, 3, 64, 2, 2, 1, 1, 3>(a, st);
+        case 31: return launch<3, 1, 64, 2, 2, 1, 1, 3>(a, st);
+        case 23: return launch<2, 3, 64, 2, 2, 1, 1, 3>(a, st);
+        case 32: return launch<3, 2, 64, 2, 2, 1, 1, 3>(a, st);
+        case 33: return launch<3, 3, 64, 2, 2, 1, 1, 3>(a, st);
+        default: return hipErrorInvalidValue;
+        }
     }
     switch (LA * 10 + LB) {
     case 12: return launch<1, 2, 64, 2, 4, 2, 1, 3>(a, st);
