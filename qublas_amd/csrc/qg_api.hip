@@ -147,7 +147,8 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
                                : ((an->gemv_ok && fast) ? QG_KERNEL_GEMV_I32 : (an->tree_fast_ok && fast) ? QG_KERNEL_TREE_I32 : QG_KERNEL_TREE_I64);
         // the 32-bit tree kernels walk a perfect binary tree: their operands are zero-padded along K to 2^n_levels leaves
         // (a node whose right child is a zero leaf / zero subtree is the reference's converting copy of an odd leftover)
-        const int64_t Kt = (kernel == QG_KERNEL_TREE_I32 || kernel == QG_KERNEL_TREE_CPLX_I32 || kernel == QG_KERNEL_GEMV_I32)
+        const bool t64 = kernel == QG_KERNEL_TREE_I64 && an->tree64_ok && fast;   // the 2x2-per-lane 64-bit kernel, not the general one
+        const int64_t Kt = (kernel == QG_KERNEL_TREE_I32 || kernel == QG_KERNEL_TREE_CPLX_I32 || kernel == QG_KERNEL_GEMV_I32 || t64)
                                ? ((int64_t)1 << d->n_levels) : d->K;
         *pa = QPackedGeom{d->M, Kt, info->in_bits[0] <= 32 ? 4 : 8, 0, 0, 0};
         *pb = QPackedGeom{d->N, Kt, info->in_bits[1] <= 32 ? 4 : 8, 0, 0, 0};
@@ -613,6 +614,12 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
                                         p->pa.K_p, p->pc.cbytes, st));
         return QG_OK;
     case QG_KERNEL_TREE_I64:
+        if (p->an.tree64_ok && !(p->flags & QG_OPT_GENERIC_TREE)) {
+            QG_HIP(qg_launch_tree64(p->dev_table, (int)p->desc.n_levels, packedA, packedB, packedC, p->desc.M, p->desc.N, p->pa.K_p,
+                                    p->pa.cbytes, p->pb.cbytes, pcg.cbytes, st));
+            return QG_OK;
+        }
+        [[fallthrough]];
     case QG_KERNEL_TREE_CPLX:
         QG_HIP(qg_launch_tree_generic(p->dev_table, p->desc.is_complex ? 2 : 1, packedA, packedB, packedC, p->desc.M, p->desc.N,
                                       p->desc.K, p->pa, p->pb, pcg, st));

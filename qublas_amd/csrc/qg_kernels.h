@@ -82,6 +82,10 @@ hipError_t qg_launch_tree_generic(const QTreeTable* dev_table, int parts, const 
 hipError_t qg_launch_tree_fast(const QTreeTable* dev_table, int n_levels, int split_s, int mul24, int mode, const void* A, const void* B,
                                void* C, int64_t M, int64_t N, int64_t K, int cbytes, hipStream_t st);
 
+// exact tree evaluation, real descriptors with 5..16 levels and 64-bit values (A, B packed as int32 or int64, K = 2^n_levels)
+hipError_t qg_launch_tree64(const QTreeTable* dev_table, int n_levels, const void* A, const void* B, void* C, int64_t M, int64_t N,
+                            int64_t K, int abytes, int bbytes, int cbytes, hipStream_t st);
+
 // exact tree evaluation of ONE output column (batched Qreduce / GEMV): A [M][K] int32, B [K] int32
 hipError_t qg_launch_gemv(const QTreeTable* dev_table, int n_levels, int b_is_bit, const void* A, const void* B, void* C, int64_t M,
                           int64_t K, int cbytes, hipStream_t st);

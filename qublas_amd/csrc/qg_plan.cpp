@@ -453,6 +453,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         const int W = (int)pf.I + (int)pf.F;
         if (one && W + 1 + T.mul[0].q.d <= 30) out->fast_mode = pf.O == QG_SAT_ZERO ? 1 : 2;
     }
+    out->tree64_ok = (!cx && d->n_levels >= 5 && d->n_levels <= 16) ? 1 : 0;   // (max_bits <= 62 was checked above)
     // one-column kernel (qg_gemv.hip): products are formed in 64 bits, everything else in 32
     out->gemv_ok = (!cx && d->N == 1 && d->n_levels >= 4 && d->n_levels <= 30 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     out->gemv_b_bit = (out->gemv_ok && d->b[0].I == 1 && d->b[0].F == 0 && !d->b[0].S && same(d->mul[0], d->a[0])) ? 1 : 0;

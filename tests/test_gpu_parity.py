@@ -395,3 +395,16 @@ def test_one_shot_call_from_several_threads(oracle):
     for t in threads:
         t.join()
     assert not errors, errors[:3]
+
+
+@pytest.mark.parametrize("K", [32, 100, 1000, 4096])
+def test_wide_formats_tree_kernel(oracle, K):
+    """tree class with formats beyond 31 bits (a rounding product behind wide level types, wide operands): the 64-bit
+    2x2-per-lane kernel (default) against the oracle and against the general one-output-per-lane kernel"""
+    wide_lv = [Qu(29, 16, True, RND.CONV, SAT.SMGN), Qu(33, 12, True, RND.ZERO, SAT.TCPL)]
+    for ea, ec, kw in ((E88Z, Qu(30, 8, True, RND.INF, SAT.TCPL), dict(mul_args=Tags(12, 10), add_args=wide_lv)),
+                       (Qu(14, 10), Qu(30, 10), dict(mul_args=Tags(20, 14), add_args=[Qu(34, 14)])),
+                       (E43, W16, dict(add_args=[Qu(40, 3)]))):
+        a = _vs_oracle(oracle, ea, ea, ec, 70, 45, K, expect_kernel="tree_i64", **kw)
+        b = _vs_oracle(oracle, ea, ea, ec, 70, 45, K, flags=capi.OPT_GENERIC_TREE, expect_kernel="tree_i64", **kw)
+        assert np.array_equal(a, b)
