@@ -51,6 +51,7 @@ struct qgemul_plan {
     QEpTable ept;
     QCGeom pc_c;
     void* cwork;
+    int32_t* wide_ws;     // single-limb MFMA with a left-shifting epilogue that leaves 32 bits: raw int32 dot products
 };
 
 static int pow2_bytes(int storage_bits)
@@ -206,8 +207,19 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
 // so the default fuses on the limb kernel only, and only chains the planner has bounded by 32-bit arithmetic (a 64-bit
 // chain inside the kernel was measured slower than the pass on every kernel).  Everything else runs as ONE linear,
 // HBM-bound pass over the stored C (all stages and the final conversion in that pass, 5-6 TB/s).
+// The single-limb MFMA kernels keep the dot product in int32 and run their epilogue in 32 bits.  An exact LEFT shift into a C
+// with finer fracBits can leave 32 bits before the overflow handling sees the value (found by tests/extended_fuzz.py:
+// int<10,-3> operands into Qu<5,7>, shift by 13).  Those descriptors store the raw dot products and convert them in the
+// 64-bit linear pass instead, which keeps the hot kernels' epilogue as it is.
+static bool wide_epilogue(const qgemul_plan* p)
+{
+    const QStep& q = p->an.lin.to_c[0];
+    return p->info.kernel == QG_KERNEL_MFMA_I8 && !q.identity && q.d < 0 && p->an.dot_bits - q.d > 31;
+}
+
 static bool fuses_epilogue(const qgemul_plan* p)
 {
+    if (wide_epilogue(p)) return false;
     if (p->flags & QG_OPT_UNFUSED_EPILOGUE) return false;
     if (!p->ept.bits32) return false;
     if (p->info.kernel == QG_KERNEL_MFMA_I8_LIMB && p->LA == 3 && p->LB == 3) return true;
@@ -358,12 +370,19 @@ int qgemul_plan_create_ep(qgemul_ctx* c, const qgemul_desc* d, const qgemul_epil
             return QG_EHIP;
         }
     }
+    if (wide_epilogue(p) && hipMalloc((void**)&p->wide_ws, (size_t)(p->pc_c.Mp * p->pc_c.Np) * sizeof(int32_t)) != hipSuccess) {
+        hipFree(p->dev_table);
+        hipFree(p->workspace);
+        delete p;
+        return QG_EHIP;
+    }
     if (p->has_ep && !fuses_epilogue(p)) {
         // the tree kernels store C; the chain then runs as a pass over it
         const size_t cb = (size_t)(p->pc_c.Mp * p->pc_c.Np) * (size_t)p->pc_c.cbytes;
         if (hipMalloc(&p->cwork, cb ? cb : 16) != hipSuccess) {
             hipFree(p->dev_table);
             hipFree(p->workspace);
+            hipFree(p->wide_ws);
             delete p;
             return QG_EHIP;
         }
@@ -379,6 +398,7 @@ void qgemul_plan_destroy(qgemul_plan* p)
     hipFree(p->dev_table);
     hipFree(p->workspace);
     hipFree(p->cwork);
+    hipFree(p->wide_ws);
     delete p;
 }
 
@@ -563,6 +583,23 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
         a.to_c = p->an.lin.to_c[0];
         a.maskA = p->pa.trailer ? (const uint32_t*)((const char*)packedA + p->pa.trailer) : nullptr;
         a.maskB = p->pb.trailer ? (const uint32_t*)((const char*)packedB + p->pb.trailer) : nullptr;
+        if (wide_epilogue(p)) {
+            a.C = p->wide_ws;
+            a.cbytes = 4;
+            memset(&a.to_c, 0, sizeof a.to_c);
+            a.to_c.identity = 1;                    // raw int32 dot products ...
+            QG_HIP(qg_launch_mfma(p->LA, p->LB, a, st));
+            QEltwiseArgs f;
+            memset(&f, 0, sizeof f);
+            f.C = (const char*)p->wide_ws;
+            f.D = (char*)packedC;
+            f.n = pcg.Mp * pcg.Np;
+            f.cbytes = 4;
+            f.t.dbytes = pcg.cbytes;
+            f.t.to_d = p->an.lin.to_c[0];           // ... shifted, overflow-handled and stored in 64-bit arithmetic
+            QG_HIP(qg_launch_eltwise(f, st));
+            return QG_OK;
+        }
         QG_HIP(qg_launch_mfma(p->LA, p->LB, a, st));
         return QG_OK;
     }

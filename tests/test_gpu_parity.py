@@ -408,3 +408,15 @@ def test_wide_formats_tree_kernel(oracle, K):
         a = _vs_oracle(oracle, ea, ea, ec, 70, 45, K, expect_kernel="tree_i64", **kw)
         b = _vs_oracle(oracle, ea, ea, ec, 70, 45, K, flags=capi.OPT_GENERIC_TREE, expect_kernel="tree_i64", **kw)
         assert np.array_equal(a, b)
+
+
+def test_single_limb_left_shifting_epilogue(oracle):
+    """found by tests/extended_fuzz.py: int<10,-3> operands (one int8 limb), exact product and sums at fracBits -6, C at
+    fracBits 7 — the epilogue shifts the int32 dot product LEFT by 13 bits, past 32 bits, before C's SAT::SMGN sees it.  Such
+    descriptors convert the raw dot products in the 64-bit pass; every overflow mode, and a C wider than 32 bits."""
+    e = Qu(10, -3)
+    for om in (SAT.TCPL, SAT.ZERO, SAT.SMGN, WRP.TCPL):
+        for c in (Qu(5, 7, True, TRN.SMGN, om), Qu(30, 10, True, TRN.TCPL, om)):
+            for dist in (0, 1):
+                _vs_oracle(oracle, e, e, c, 36, 50, 494, dist=dist, mul_args=Qu(21, -6), add_args=[Qu(33, -6)], expect_kernel="mfma_i8")
+    _vs_oracle(oracle, e, e, Qu(5, 7, True, TRN.SMGN, SAT.SMGN), 300, 260, 4096, mul_args=Qu(21, -6), add_args=[Qu(33, -6)], expect_kernel="mfma_i8")
