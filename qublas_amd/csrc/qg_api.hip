@@ -214,7 +214,9 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
 static bool wide_epilogue(const qgemul_plan* p)
 {
     const QStep& q = p->an.lin.to_c[0];
-    return p->info.kernel == QG_KERNEL_MFMA_I8 && !q.identity && q.d < 0 && p->an.dot_bits - q.d > 31;
+    // ... and a C format beyond 31 value bits does not fit the 32-bit epilogue's clamp bounds at all (second find of the
+    // extended fuzz runs: int<7,-2> x int<7,-1> into Qu<24,9>)
+    return p->info.kernel == QG_KERNEL_MFMA_I8 && !q.identity && (q.W > 30 || (q.d < 0 && p->an.dot_bits - q.d > 31));
 }
 
 static bool fuses_epilogue(const qgemul_plan* p)

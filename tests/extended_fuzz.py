@@ -46,7 +46,7 @@ def main():
             else:
                 lv = [rand_qu(rng, 40 if wide else 14) for _ in range(rng.randint(0, 3))]
                 kw = dict(mul_args=rand_tags(rng, ea), add_args=lv or None)
-            ec = rand_qu(rng, 30 if wide else 16)
+            ec = rand_qu(rng, rng.choice([30, 36, 44]) if wide else rng.choice([16, 16, 34]))
         M = rng.randint(1, 150)
         N = 1 if rng.random() < 0.2 else rng.randint(1, 150)
         K = rng.choice([rng.randint(1, 40), rng.randint(1, 600), rng.randint(1, 5000)]) if not cx else rng.randint(1, 300)

@@ -420,3 +420,13 @@ def test_single_limb_left_shifting_epilogue(oracle):
             for dist in (0, 1):
                 _vs_oracle(oracle, e, e, c, 36, 50, 494, dist=dist, mul_args=Qu(21, -6), add_args=[Qu(33, -6)], expect_kernel="mfma_i8")
     _vs_oracle(oracle, e, e, Qu(5, 7, True, TRN.SMGN, SAT.SMGN), 300, 260, 4096, mul_args=Qu(21, -6), add_args=[Qu(33, -6)], expect_kernel="mfma_i8")
+
+
+def test_single_limb_into_a_c_wider_than_32_bits(oracle):
+    """second find of tests/extended_fuzz_shapes.py: one-limb operands into Qu<24,9> (33 value bits) — the 32-bit epilogue
+    cannot even hold C's clamp bounds; every overflow mode, shifts in both directions"""
+    a, b = Qu(7, -2, False), Qu(7, -1)
+    for om in (SAT.TCPL, SAT.ZERO, SAT.SMGN, WRP.TCPL):
+        for c in (Qu(24, 9, True, TRN.TCPL, om), Qu(34, 0, True, RND.CONV, om), Qu(28, 3, False, RND.ZERO, om)):
+            _vs_oracle(oracle, a, b, c, 129, 1, 100, mul_args=Qu(15, -3), add_args=[Qu(33, -3)], transposed_a=True, expect_kernel="mfma_i8")
+            _vs_oracle(oracle, E43, E43, c, 70, 90, 256, mul_args=Tags(9, 6), add_args=[Qu(21, 6)], expect_kernel="mfma_i8")
