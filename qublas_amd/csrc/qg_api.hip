@@ -644,7 +644,8 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
                                    p->desc.M, p->desc.N, p->pa.K_p, pcg.cbytes, st));
         return QG_OK;
     case QG_KERNEL_GEMV_I32:
-        QG_HIP(qg_launch_gemv(p->dev_table, (int)p->desc.n_levels, p->an.gemv_b_bit, packedA, packedB, packedC, p->desc.M, p->pa.K_p,
+        QG_HIP(qg_launch_gemv(p->dev_table, (int)p->desc.n_levels, p->an.gemv_b_bit, (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : p->an.gemv_fixed,
+                              packedA, packedB, packedC, p->desc.M, p->pa.K_p,
                               pcg.cbytes, st));
         return QG_OK;
     case QG_KERNEL_TREE_CPLX_I32:

@@ -68,21 +68,38 @@ __device__ __forceinline__ void node_all(int (&acc)[N], const int (&x)[N], CTab 
 }
 
 // in-lane levels: v[0..CNT) -> v[0..CNT/2) ... -> v[0]
-template <int CNT>
-__device__ __forceinline__ int lane_tree(int (&v)[CNT], CTab tab, int level)
+// MODE 1 / 2: every level has ONE format with no rounding shift and SAT::ZERO / SAT::TCPL overflow (what default tags
+// produce; QAnalysis::fast_mode) — a node is an add and a range test / a clamp against two constants, with no per-level
+// table read and no scalar branch ladder.  The counters of the run-time-mode kernel showed more scalar than vector
+// instructions per launch (65 M SALU vs 48 M VALU at 65536 x 4096) and 56 % of the wave cycles waiting.
+template <int MODE>
+__device__ __forceinline__ int node_fixed(int a, int b, int lo, int hi)
+{
+    const int t = a + b;
+    if (MODE == 1) return ((unsigned)(t - lo) > (unsigned)(hi - lo)) ? 0 : t;
+    return min(max(t, lo), hi);
+}
+
+template <int CNT, int MODE>
+__device__ __forceinline__ int lane_tree(int (&v)[CNT], CTab tab, int level, int lo, int hi)
 {
     if constexpr (CNT == 1) {
         return v[0];
     } else {
         int h[CNT / 2];   // (arrays of exact size, indexed only by unrolled loops: registers, never scratch)
+        if constexpr (MODE == 0) {
 #pragma unroll
-        for (int o = 0; o < CNT / 2; ++o) h[o] = v[2 * o] + v[2 * o + 1];   // left child + right child, in the tree's order
-        qg_step_all<int, CNT / 2>(h, load_step(&tab->level_add[0][level].q));
-        return lane_tree<CNT / 2>(h, tab, level + 1);
+            for (int o = 0; o < CNT / 2; ++o) h[o] = v[2 * o] + v[2 * o + 1];   // left child + right child, in the tree's order
+            qg_step_all<int, CNT / 2>(h, load_step(&tab->level_add[0][level].q));
+        } else {
+#pragma unroll
+            for (int o = 0; o < CNT / 2; ++o) h[o] = node_fixed<MODE>(v[2 * o], v[2 * o + 1], lo, hi);
+        }
+        return lane_tree<CNT / 2, MODE>(h, tab, level + 1, lo, hi);
     }
 }
 
-template <int CH>   // leaves per lane and segment
+template <int CH, int MODE>   // leaves per lane and segment; MODE: 0 run-time modes, 1 / 2 fixed (see node_fixed)
 __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
 {
     constexpr int Q = CH == 32 ? 5 : CH == 16 ? 4 : CH == 8 ? 3 : 2;
@@ -128,6 +145,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
     pnode.sa = pnode.sb = 0;
     pnode.q = load_step(&tab->mul[0].q);
     const QStep c_cvt = load_step(&tab->c_cvt[0]);
+    const int flo = (int)tab->level_add[0][0].q.lo, fhi = (int)tab->level_add[0][0].q.hi;   // MODE 1 / 2: the one level format
     for (; row < g.M; row += wstride) {
         int root = 0;
         for (int64_t s = 0; s < nseg; ++s) {
@@ -166,11 +184,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
                 }
             }
             // across the lanes: level Q + i pairs lane j (left) with lane j + 2^i
-            int x[1] = {lane_tree<CH>(v, tab, 0)};
+            int x[1] = {lane_tree<CH, MODE>(v, tab, 0, flo, fhi)};
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 int y[1] = {__shfl_down(x[0], 1 << i)};
-                node_all<1>(x, y, tab, Q + i);
+                if constexpr (MODE == 0) node_all<1>(x, y, tab, Q + i);
+                else x[0] = node_fixed<MODE>(x[0], y[0], flo, fhi);
             }
             // x[0] in lane 0 = the segment's node of level Q + 6; carry it into the counter
             const int base = Q + 6;
@@ -178,10 +197,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
             for (int u = 0; u < MAXUP && !parked; ++u) {
                 if (base + u >= g.n_levels) { root = x[0]; parked = true; }
                 else if (((s >> u) & 1) == 0) { if (lane == 0) up[u] = x[0]; parked = true; }
-                else {
+                else if (MODE == 0) {
                     int l[1] = {up[u]};
                     node_all<1>(l, x, tab, base + u);
                     x[0] = l[0];
+                } else {
+                    x[0] = node_fixed<MODE>(up[u], x[0], flo, fhi);
                 }
             }
         }
@@ -287,32 +308,36 @@ hipError_t launch_gemv_short(const QGemvArgs& g, hipStream_t st)
     return hipGetLastError();
 }
 
-template <int CH>
+template <int CH, int MODE = 0>
 hipError_t launch_gemv(const QGemvArgs& g, hipStream_t st)
 {
+    if constexpr (MODE == 0) {
+        if (g.pad_ == 1) return launch_gemv<CH, 1>(g, st);
+        if (g.pad_ == 2) return launch_gemv<CH, 2>(g, st);
+    }
     constexpr int IMG = 64 * (CH * 4 + 16);
     const int64_t nseg = g.K / (64 * CH);
     const int lds = IMG * ((nseg == 1 ? 1 : 0) + WAVES);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemv<CH>, hipFuncAttributeMaxDynamicSharedMemorySize, IMG * (1 + WAVES));
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemv<CH, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, IMG * (1 + WAVES));
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     int64_t blocks = (g.M + WAVES - 1) / WAVES;
     if (blocks > 256 * 8) blocks = 256 * 8;   // rows beyond that are walked by the grid-stride loop
-    hipLaunchKernelGGL(k_gemv<CH>, dim3((unsigned)blocks), dim3(64 * WAVES), lds, st, g);
+    hipLaunchKernelGGL((k_gemv<CH, MODE>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, st, g);
     return hipGetLastError();
 }
 
 } // namespace
 
-hipError_t qg_launch_gemv(const QTreeTable* dev_table, int n_levels, int b_is_bit, const void* A, const void* B, void* C, int64_t M,
-                          int64_t K, int cbytes, hipStream_t st)
+hipError_t qg_launch_gemv(const QTreeTable* dev_table, int n_levels, int b_is_bit, int fixed_mode, const void* A, const void* B, void* C,
+                          int64_t M, int64_t K, int cbytes, hipStream_t st)
 {
     if (M <= 0) return hipSuccess;
     if (K < 16 || (K & (K - 1)) || n_levels < 4 || n_levels > 10 + MAXUP) return hipErrorInvalidValue;
-    QGemvArgs g{dev_table, (const int32_t*)A, (const int32_t*)B, (char*)C, M, K, cbytes, n_levels, b_is_bit, 0};
+    QGemvArgs g{dev_table, (const int32_t*)A, (const int32_t*)B, (char*)C, M, K, cbytes, n_levels, b_is_bit, fixed_mode};
     switch (K) {
     case 16: return launch_gemv_short<16>(g, st);
     case 32: return launch_gemv_short<32>(g, st);

@@ -457,6 +457,15 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     // one-column kernel (qg_gemv.hip): products are formed in 64 bits, everything else in 32
     out->gemv_ok = (!cx && d->N == 1 && d->n_levels >= 4 && d->n_levels <= 30 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     out->gemv_b_bit = (out->gemv_ok && d->b[0].I == 1 && d->b[0].F == 0 && !d->b[0].S && same(d->mul[0], d->a[0])) ? 1 : 0;
+    out->gemv_fixed = 0;
+    if (out->gemv_ok) {
+        // all levels one format (the product's), exact alignment (d == 0), SAT::ZERO or SAT::TCPL
+        const qfmt lf = d->level_add[0][0];
+        bool one = (lf.O == QG_SAT_ZERO || lf.O == QG_SAT_TCPL) && same(lf, d->mul[0]) && (int)lf.I + (int)lf.F <= 29;
+        for (uint32_t l = 0; l < d->n_levels && one; ++l)
+            one = same(d->level_add[0][l], lf) && same(d->level[0][l], lf) && T.level_add[0][l].q.d == 0;
+        if (one) out->gemv_fixed = lf.O == QG_SAT_ZERO ? 1 : 2;
+    }
     out->cplx_fast_ok = (cx && d->n_levels >= 5 && d->n_levels <= 16 && c.max_bits <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     // fixed-mode variant of the complex kernel (BASELINE configuration 5's "RND + SAT"): every sub-operation and every tree
     // step either the identity, or an exact left shift / a rounding shift with RND::POS_INF, followed by SAT::TCPL, so a

@@ -95,3 +95,14 @@ def test_very_short_vectors_use_the_general_kernels(oracle):
         d = lower_reduce(E88, 64, K)
         assert capi.KERNEL_NAMES[capi.classify(d).kernel] != "gemv_i32"
         _check(oracle, d, E88, None, E88, dist=1, ones=True, expect=capi.KERNEL_NAMES[capi.classify(d).kernel])
+
+
+@pytest.mark.parametrize("K", [64, 256, 1000, 8192])
+def test_fixed_mode_nodes_equal_runtime_mode_nodes(oracle, K):
+    """default tags give one level format with SAT::ZERO (int<8,8> TCPL/ZERO) or SAT::TCPL (int<4,3>): the fixed-mode kernel
+    variants (add + range test / clamp) against the run-time-mode variant (QG_OPT_RUNTIME_MODES) and the oracle"""
+    for e, ones in ((E88, True), (E43, True), (E43, False)):
+        d = lower_reduce(e, 257, K) if ones else lower(e, e, e, 257, 1, K)
+        a = _check(oracle, d, e, e, e, ones=ones)
+        b = _check(oracle, d, e, e, e, ones=ones, flags=capi.OPT_RUNTIME_MODES)
+        assert np.array_equal(a, b)
