@@ -599,7 +599,7 @@ static int ablation()
 hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
 {
     if (const int abl = ablation(); abl > 0 && abl < 16) {
-        if (LA == 3 && LB == 3) {
+        if (LA == 3 && LB == 3 && a.variant == 3) {   // (the diagnostic variants exist for the 128x128-tile geometry only)
             switch (abl) {
             case 1: return launch<3, 3, 64, 2, 4, 2, 1, 3, 1>(a, st);
             case 2: return launch<3, 3, 64, 2, 4, 2, 1, 3, 2>(a, st);
