@@ -15,8 +15,8 @@
 //     partial result — a node of level q+6 — in lane 0; segments are combined by a binary counter over the remaining
 //     levels.  Every node is the reference's Qadd of two equal-format children in the reference's order.
 // Rows of 16 .. 128 leaves take k_gemv_short (below), which needs no LDS.
-// Requirements (planner): real descriptor, N = 1, K = 2^p >= 16, every value except the unrounded product within 31
-// bits.  When the whole vector is one segment, B is staged once per workgroup in the same padded image; longer
+// Requirements (planner): real descriptor, N = 1, at least 4 tree levels (the operands are zero-padded to 2^n_levels leaves),
+// every value except the unrounded product within 31 bits.  When the whole vector is one segment, B is staged once per workgroup in the same padded image; longer
 // vectors are re-read per segment from L2.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
@@ -32,7 +32,8 @@ struct QGemvArgs {
     const int32_t* B;   // [K]
     char* C;            // [M] containers of cbytes
     int64_t M, K;
-    int32_t cbytes, n_levels, b_is_bit, pad_;
+    int32_t cbytes, n_levels, b_is_bit;
+    int32_t pad_;       // fixed-mode selector: 0 run-time modes, 1 one format + SAT::ZERO, 2 one format + SAT::TCPL (QAnalysis::gemv_fixed)
 };
 
 typedef int v4i __attribute__((ext_vector_type(4)));
