@@ -220,11 +220,14 @@ def main():
     if rank == 0:
         # dominant kernel, HIP events on the engine's own stream
         kms = plan.time_execute(tC.data_ptr(), tA.data_ptr(), tB.data_ptr(), 3, max(10, min(args.steps, 100)))
+        # SURVEY.md §8-d asks for median and min beside the mean: 30 single launches, each bracketed by its own HIP events
+        singles = sorted(plan.time_execute(tC.data_ptr(), tA.data_ptr(), tB.data_ptr(), 0, 1) for _ in range(30))
         achieved = 2.0 * M * N * K / (kms * 1e-3)
         bound = "mfma" if info.kernel in (1, 2) else "valu"
         roof = {"bound": "mfma", "achieved": achieved / 1e12, "peak": INT8_DENSE_PEAK_OPS / 1e12, "unit": "TOP/s (int8-equivalent 2*M*N*K)",
                 "frac": achieved / INT8_DENSE_PEAK_OPS, "traffic": load_traffic(args.workload),
                 "kernel": capi.KERNEL_NAMES[info.kernel], "kernel_ms": kms,
+                "kernel_ms_median": singles[len(singles) // 2], "kernel_ms_min": singles[0],
                 "limbs": [info.limbs[0], info.limbs[1]],
                 "mfma_issue_frac": achieved * max(1, info.limbs[0] * info.limbs[1]) / INT8_DENSE_PEAK_OPS if bound == "mfma" else None,
                 "algorithmic_bytes": int((M * K + K * N) * max(1, (info.in_bits[0] + 7) // 8) + M * N * (pb[2] // (M * N) if M * N else 0))}
