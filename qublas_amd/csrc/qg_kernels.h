@@ -35,6 +35,11 @@ struct QPackedGeom {
     // MFMA kernel skips the products of planes that are zero everywhere: data that stays inside [-32640, 32639] never
     // touches the third int8 limb of a 17-bit format, and 4 instead of 9 products are exact for it.
     int64_t trailer;        // byte offset of the trailer (0: none)
+    // Karatsuba layout (2 x 2 digits, operands of at most 12 value+sign bits): the two planes hold the UNSIGNED base-64 digits
+    // of x + bias (bias = 2^W for a signed format, so the biased value is non-negative; padding holds 0), and int64
+    // row_sum[rows_p] = sum_k (x + bias) follows the trailer — the kernel's epilogue takes the bias back out with it.
+    int32_t digit6, pad2_;
+    int64_t bias, rowsum_off;
 };
 enum { QG_TRAILER_BYTES = 256 };
 
@@ -108,6 +113,11 @@ struct QMfmaArgs {
     int32_t cbytes;
     int32_t variant;
     QStep to_c;
+    // Karatsuba variant (kara != 0): sum a*b = sum a'b' - biasB * rsA[i] - biasA * rsB[j] + corr, with a' = a + biasA etc.
+    const int64_t* rsA;
+    const int64_t* rsB;
+    int64_t biasA, biasB, corr;
+    int32_t kara, pad3_;
     const uint32_t* maskA;  // plane masks of the packed operands (QPackedGeom::trailer); nullptr: all planes
     const uint32_t* maskB;
     int32_t has_ep, pad_;   // fused element-wise epilogue: C below is then packed D (ep.dbytes containers)

@@ -68,7 +68,14 @@ __device__ __forceinline__ void interleave_hint(std::integer_sequence<int, M...>
 // returns in its first instructions unless it is the one that fits, so the choice is made on the device from data that
 // travels with the packed operand (no host read-back, no stale host state).  (One kernel with a run-time-masked MFMA
 // sequence was measured: it spills and runs 2.4x slower than the full sequence.)
-template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE, int ABL, bool EP, int SA = LA, int SB = LB>   // EP: fused element-wise epilogue
+// KARA (LA = LB = 2, operands of at most 12 value+sign bits): the planes hold UNSIGNED base-64 digits d0, d1 of x + bias, and
+// the kernel issues THREE products per k-step instead of four (Karatsuba): P0 = A0.B0, P1 = A1.B1, P01 = (A0+A1).(B0+B1) —
+// digit sums <= 126 still fit the MFMA's signed int8 operands, and with non-negative digits the sum of two packed-byte
+// registers is one v_add_u32 (no carry crosses a byte).  sum a'b' = P0 + 64 (P01 - P0 - P1) + 4096 P1, and the bias goes
+// out with the operands' row sums: sum ab = sum a'b' - biasB rsA[i] - biasA rsB[j] + K biasA biasB.  Exact: every P is an
+// int32 as long as K * 126^2 < 2^31 (planner).  (The 3 x 3-digit form needs 6 accumulator sets — 384 registers for a
+// 64 x 64 wave tile — which hipcc cannot allocate without spilling)
+template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE, int ABL, bool EP, int SA = LA, int SB = LB, bool KARA = false>   // EP: fused element-wise epilogue
 __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 {
     if constexpr (SA == 3 && SB == 3 && ABL == 0) {
@@ -170,6 +177,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
     };
     // the LA*LB*TI*TJ MFMAs of one k-step, optionally only those with index in [first, last)
     auto mfmas = [&](int set, int first, int last) {
+        if constexpr (KARA) {
+            static_assert(!KARA || (LA == 2 && LB == 2), "Karatsuba variant: 2 x 2 digits");
+            v4i sa[TI], sb[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) sa[i] = fa[set][0][i] + fa[set][1][i];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) sb[j] = fb[set][0][j] + fb[set][1][j];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    acc[0][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[set][0][i], fb[set][0][j], acc[0][i][j], 0, 0, 0);   // P0
+                    acc[2][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[set][1][i], fb[set][1][j], acc[2][i][j], 0, 0, 0);   // P1
+                    acc[1][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(sa[i], sb[j], acc[1][i][j], 0, 0, 0);                   // P01
+                }
+            return;
+        }
         int n = 0;
 #pragma unroll
         for (int la = 0; la < LA; ++la)
@@ -182,7 +206,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
                         if (n >= first && n < last)
                             acc[la + lb][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[set][la][i], fb[set][lb][j], acc[la + lb][i][j], 0, 0, 0);
     };
-    constexpr int NM = LA * LB * TI * TJ;  // MFMAs per k-step per wave
+    constexpr int NM = (KARA ? 3 : LA * LB) * TI * TJ;  // MFMAs per k-step per wave
 
     // prologue: tiles 0 and 1 in flight, tile 0 published, its first fragments loaded
     issue(0, 0);
@@ -249,12 +273,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             S s[16];
+            if constexpr (KARA) {
+                const int64_t cj = g.corr - g.biasA * g.rsB[(int64_t)tile_n * TN + (wn * TJ + j) * 32 + fr];
+                const int64_t* ra = g.rsA + (int64_t)tile_m * TM + (wm * TI + i) * 32 + 4 * fh;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                S x = (S)acc[NW - 1][i][j][e];
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t p0 = acc[0][i][j][e], p01 = acc[1][i][j][e], p1 = acc[2][i][j][e];
+                    s[e] = (S)(p0 + 64 * (p01 - p0 - p1) + 4096 * p1 - g.biasB * ra[(e & 3) + 8 * (e >> 2)] + cj);
+                }
+            } else {
 #pragma unroll
-                for (int w = NW - 2; w >= 0; --w) x = x * 256 + (S)acc[w][i][j][e];
-                s[e] = x;
+                for (int e = 0; e < 16; ++e) {
+                    S x = (S)acc[NW - 1][i][j][e];
+#pragma unroll
+                    for (int w = NW - 2; w >= 0; --w) x = x * 256 + (S)acc[w][i][j][e];
+                    s[e] = x;
+                }
             }
             qg_step_all<S, 16>(s, st);
             if (ABL == 5 && s[0] != (S)0x7ead1234) continue; // diagnostic: keep the arithmetic, drop the stores
@@ -544,6 +578,19 @@ hipError_t launch(const QMfmaArgs& a, hipStream_t st)
     const int64_t blocks = (a.Mp / TM) * (a.Np / TN);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll || a.Kp % BK || a.Mp % TM || a.Np % TN) return hipErrorInvalidValue;
+    if constexpr (LA == 2 && LB == 2 && ABL == 0 && !EP) {
+        if (a.kara) {
+            static bool attr_set_k = false;
+            if (!attr_set_k) {
+                hipError_t e = hipFuncSetAttribute((const void*)k_mfma<2, 2, BK, WGM, WGN, TI, TJ, NSTAGE, 0, false, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e != hipSuccess) return e;
+                attr_set_k = true;
+            }
+            hipLaunchKernelGGL((k_mfma<2, 2, BK, WGM, WGN, TI, TJ, NSTAGE, 0, false, 2, 2, true>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
+            return hipGetLastError();
+        }
+    }
+    if (a.kara) return hipErrorInvalidValue;
     hipLaunchKernelGGL((k_mfma<LA, LB, BK, WGM, WGN, TI, TJ, NSTAGE, ABL, EP>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
     if constexpr (LA == 3 && LB == 3 && ABL == 0) {
         static const bool no_partner = getenv("QG_NO_PLANE_MASK") != nullptr;   // A/B switch (tools/measure_masked.py); full-range data only!

@@ -82,6 +82,13 @@ __device__ __forceinline__ unsigned put_packed(const QPackedGeom& p, char* dst, 
         if (p.bk == 64) sw = (0x78 >> (2 * sw)) & 3;  // the kernels' swz<64>(): {0,2,3,1}
         const int slot = (kl / 16) ^ sw;
         const int64_t blk = ((r / p.tr) * nk + k / p.bk) * p.limbs;
+        if (p.digit6) {   // Karatsuba layout: unsigned base-64 digits of the (already biased, non-negative) value
+            for (int l = 0; l < p.limbs; ++l) {
+                ((int8_t*)dst)[((blk + l) * p.tr + rl) * p.bk + slot * 16 + (kl & 15)] = (int8_t)(v & 63);
+                v >>= 6;
+            }
+            return 0;
+        }
         for (int l = 0; l < p.limbs; ++l) {
             int64_t d = (int64_t)(int8_t)(v & 0xff); // balanced digit in [-128,127]
             ((int8_t*)dst)[((blk + l) * p.tr + rl) * p.bk + slot * 16 + (kl & 15)] = (int8_t)d;
@@ -124,6 +131,7 @@ __global__ __launch_bounds__(256) void k_pack(QOperandGeom g, QPackedGeom p, con
                 v = load_host_part(src, r * g.rs + k * g.ks, g.elem_bytes, g.off[part], g.sb[part]);
                 if (check && (v < lo || v > hi)) bad = true;
             }
+            if (p.digit6) v = (v + p.bias) & ((((int64_t)1) << (6 * p.limbs)) - 1);   // padding stays 0
         }
         if (r_fast) tile[i][tx] = v;  // tile[k_local][r_local]
         else tile[tx][i] = v;         // tile[k_local][r_local] with tx = k_local
@@ -133,6 +141,18 @@ __global__ __launch_bounds__(256) void k_pack(QOperandGeom g, QPackedGeom p, con
     for (int i = ty; i < 64; i += 4) {
         int64_t r = tr * 64 + i, k = tk * 64 + tx;
         if (r < p.rows_p && k < p.K_p) mask |= put_packed(p, dst, part, r, k, tile[tx][i]);
+    }
+    if (p.digit6) {
+        // row sums of the biased values: in the loop above the 64 lanes of a wave held 64 k's of ONE row per step; redo the
+        // walk for the sums (values < 2^12, 64 of them: int32 is plenty)
+        for (int i = ty; i < 64; i += 4) {
+            const int64_t r = tr * 64 + i, k = tk * 64 + tx;
+            int sum = (r < p.rows_p && k < p.K_p) ? (int)tile[tx][i] : 0;
+#pragma unroll
+            for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
+            if (tx == 0 && r < p.rows_p && sum)
+                atomicAdd((unsigned long long*)(dst + p.rowsum_off) + (int64_t)part * p.rows_p + r, (unsigned long long)sum);
+        }
     }
     if (p.trailer) {   // plane mask of the operand: one atomic per wave that saw a non-zero limb
 #pragma unroll
@@ -259,7 +279,9 @@ hipError_t qg_launch_cplx_combine(const QCplxCombine& g, hipStream_t st)
 
 static hipError_t zero_trailer(const QPackedGeom& p, void* dst, hipStream_t st)
 {
-    return p.trailer ? hipMemsetAsync((char*)dst + p.trailer, 0, QG_TRAILER_BYTES, st) : hipSuccess;
+    if (!p.trailer) return hipSuccess;
+    const size_t bytes = QG_TRAILER_BYTES + (p.digit6 ? (size_t)p.rows_p * 8 : 0);   // (row sums sit right behind the trailer)
+    return hipMemsetAsync((char*)dst + p.trailer, 0, bytes, st);
 }
 
 hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const void* src, void* dst, int check_range,

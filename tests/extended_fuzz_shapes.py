@@ -25,7 +25,7 @@ def main():
     oracle.lib()
     ran, kernels = 0, {}
     for it in range(cases):
-        wa, wb = rng.choice([(7, 7), (14, 14), (16, 16), (7, 16), (16, 7), (14, 7), (12, 16), (22, 22), (22, 7)])
+        wa, wb = rng.choice([(7, 7), (14, 14), (16, 16), (7, 16), (16, 7), (14, 7), (12, 16), (22, 22), (22, 7), (11, 11), (10, 11), (9, 9), (11, 8)])
         fa, fb = rng.randint(-2, 6), rng.randint(-2, 6)
         ea = Qu(wa - max(fa, 0) if fa >= 0 else wa, fa, rng.random() < 0.8) if wa - max(fa, 0) >= 0 else Qu(wa, 0)
         eb = Qu(wb - max(fb, 0) if fb >= 0 else wb, fb, rng.random() < 0.8) if wb - max(fb, 0) >= 0 else Qu(wb, 0)

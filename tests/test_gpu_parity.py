@@ -430,3 +430,27 @@ def test_single_limb_into_a_c_wider_than_32_bits(oracle):
         for c in (Qu(24, 9, True, TRN.TCPL, om), Qu(34, 0, True, RND.CONV, om), Qu(28, 3, False, RND.ZERO, om)):
             _vs_oracle(oracle, a, b, c, 129, 1, 100, mul_args=Qu(15, -3), add_args=[Qu(33, -3)], transposed_a=True, expect_kernel="mfma_i8")
             _vs_oracle(oracle, E43, E43, c, 70, 90, 256, mul_args=Tags(9, 6), add_args=[Qu(21, 6)], expect_kernel="mfma_i8")
+
+
+@pytest.mark.parametrize("ea,eb", [(Qu(6, 5), Qu(6, 5)), (Qu(7, 5, False), Qu(3, 8)), (Qu(9, 2), Qu(5, 4, False)), (Qu(11, 0), Qu(4, 5))])
+@pytest.mark.parametrize("shape", [(1536, 1408, 128), (2048, 1200, 100), (1290, 1700, 64), (256, 384, 512), (1, 1, 1)])
+def test_karatsuba_two_digit_kernel(oracle, ea, eb, shape):
+    """operands of 9..12 value+sign bits: two unsigned base-64 digits of the biased value, THREE MFMA products per k-step
+    (Karatsuba), bias removed with the operands' row sums — against the oracle, both A orientations, full and small range,
+    and against the exact tree kernel"""
+    M, N, K = shape
+    pf = Qu(ea.intBits + eb.intBits + 1, ea.fracBits + eb.fracBits, ea.isSigned or eb.isSigned)
+    kw = dict(mul_args=pf, add_args=[Qu(pf.intBits + 14, pf.fracBits, pf.isSigned)])
+    c = Qu(14, 3, True, RND.CONV, SAT.SMGN)
+    # the Karatsuba layout carries int64 row sums behind the planes: visible in the packed size (problems with more than 128
+    # tiles of 128x128 only; smaller ones are latency-bound and keep the four-product kernel)
+    info = capi.classify(lower(ea, eb, c, M, N, K, **kw))
+    rows_p, k_p = -(-M // 128) * 128, -(-K // 64) * 64
+    kara = info.packed_bytes[0] == 2 * rows_p * k_p + 256 + 8 * rows_p
+    mid, small = -(-M // 128) * -(-N // 128), -(-M // 64) * -(-N // 64)
+    assert kara == (not (mid <= 128 and small > mid))      # i.e. whenever the planner chose 128x128 tiles
+    for ta in (False, True):
+        for dist in (0, 1):
+            a = _vs_oracle(oracle, ea, eb, c, M, N, K, dist=dist, transposed_a=ta, expect_kernel="mfma_i8_limb", **kw)
+    b = _vs_oracle(oracle, ea, eb, c, M, N, K, dist=1, transposed_a=True, flags=capi.OPT_FORCE_TREE, **kw)
+    assert np.array_equal(a, b)
