@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
 // Short rows (K = 16 .. 128): a row is K/4 lanes wide, so one 16-byte load per lane covers 256/K whole rows and the lane's
 // four values are already consecutive leaves — no LDS.  Two levels inside the lane, log2(K) - 2 across the lanes of the
 // row's group; U row groups are processed together so that the (wave-uniform) mode switches are paid once per U values.
-template <int KK>
+template <int KK, int MODE>   // MODE: see node_fixed
 __global__ __launch_bounds__(256) void k_gemv_short(QGemvArgs g)
 {
     constexpr int LPR = KK / 4;        // lanes per row
@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256) void k_gemv_short(QGemvArgs g)
     pnode.sa = pnode.sb = 0;
     pnode.q = load_step(&tab->mul[0].q);
     const QStep c_cvt = load_step(&tab->c_cvt[0]);
+    const int flo = (int)tab->level_add[0][0].q.lo, fhi = (int)tab->level_add[0][0].q.hi;   // MODE 1 / 2: the one level format
     const int64_t groups = (g.M + RPL - 1) / RPL;            // groups of RPL rows
     for (int64_t g0 = wave * U; g0 < groups; g0 += nwaves * U) {
         v4i a[U];
@@ -266,19 +267,23 @@ __global__ __launch_bounds__(256) void k_gemv_short(QGemvArgs g)
                 for (int o = 0; o < 4 * U; ++o) p[o] = (int)w[o];
             }
 #pragma unroll
-            for (int o = 0; o < 2 * U; ++o) l0[o] = p[2 * o] + p[2 * o + 1];
+            for (int o = 0; o < 2 * U; ++o) l0[o] = MODE == 0 ? p[2 * o] + p[2 * o + 1] : node_fixed<MODE == 0 ? 1 : MODE>(p[2 * o], p[2 * o + 1], flo, fhi);
         }
-        qg_step_all<int, 2 * U>(l0, load_step(&tab->level_add[0][0].q));
+        if constexpr (MODE == 0) qg_step_all<int, 2 * U>(l0, load_step(&tab->level_add[0][0].q));
         int x[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = l0[2 * u] + l0[2 * u + 1];
-        qg_step_all<int, U>(x, load_step(&tab->level_add[0][1].q));
+        for (int u = 0; u < U; ++u) x[u] = MODE == 0 ? l0[2 * u] + l0[2 * u + 1] : node_fixed<MODE == 0 ? 1 : MODE>(l0[2 * u], l0[2 * u + 1], flo, fhi);
+        if constexpr (MODE == 0) qg_step_all<int, U>(x, load_step(&tab->level_add[0][1].q));
 #pragma unroll
         for (int i = 0; i < XL; ++i) {
             int y[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) y[u] = __shfl_down(x[u], 1 << i);
-            node_all<U>(x, y, tab, 2 + i);
+            if constexpr (MODE == 0) node_all<U>(x, y, tab, 2 + i);
+            else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) x[u] = node_fixed<MODE == 0 ? 1 : MODE>(x[u], y[u], flo, fhi);
+            }
         }
         qg_step_all<int, U>(x, c_cvt);
         if (sub == 0) {
@@ -298,14 +303,18 @@ __global__ __launch_bounds__(256) void k_gemv_short(QGemvArgs g)
     }
 }
 
-template <int KK>
+template <int KK, int MODE = 0>
 hipError_t launch_gemv_short(const QGemvArgs& g, hipStream_t st)
 {
+    if constexpr (MODE == 0) {
+        if (g.pad_ == 1) return launch_gemv_short<KK, 1>(g, st);
+        if (g.pad_ == 2) return launch_gemv_short<KK, 2>(g, st);
+    }
     constexpr int RPL = 64 / (KK / 4);
     const int64_t groups = (g.M + RPL - 1) / RPL;
     int64_t blocks = (groups + 15) / 16;          // 4 waves x U = 4 groups per block pass
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(k_gemv_short<KK>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((k_gemv_short<KK, MODE>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     return hipGetLastError();
 }
 
