@@ -342,12 +342,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 // barrier per k-tile sits at the top of the iteration.  (A/B of the two MFMA shapes: DESIGN.md §9.)
 // Fragment map: lane l holds row (l & 15), bytes [16*(l>>4), +16) of the 64-byte k-step for A and B alike;
 // C/D: col = lane & 15, rows 4*(lane>>4) .. +3 in the 4 result registers.
+
 typedef int v4acc __attribute__((ext_vector_type(4)));
 
 // LA x LB limbs; DBUF: fragments double-buffered across k-tiles (only when the registers allow it)
 template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF, bool EP, bool HINT = true>   // TI x TJ tiles of 16x16 per wave
 __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
 {
+    if constexpr (LA == 3 && LB == 3) {   // plane masks: see k_mfma; the 2 x 2 partner of the launch pair is k_mfma<2,2,...,3,3>
+        const unsigned ma = g.maskA ? (unsigned)__builtin_amdgcn_readfirstlane(*g.maskA) : 7u;
+        const unsigned mb = g.maskB ? (unsigned)__builtin_amdgcn_readfirstlane(*g.maskB) : 7u;
+        if (((ma | mb) & 4u) == 0) return;
+    }
     constexpr int BK = 64, NSTAGE = 3;
     constexpr int TM = WGM * TI * 16, TN = WGN * TJ * 16;
     constexpr int NWAVES = WGM * WGN;
@@ -386,6 +392,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
         const int8_t* b = Bg + (int64_t)kt * B_BYTES;
 #pragma unroll
         for (int pi = 0; pi < PPW; ++pi) {
+            const int p = wave + NWAVES * pi;
+            const int8_t* src = p < A_PIECES ? a + p * 1024 : b + (p - A_PIECES) * 1024;
+            __builtin_amdgcn_global_load_lds(QG_GLOBAL_PTR(src), QG_LDS_PTR(sbase + p * 1024), 16, 0, 0);
+        }
+    };
+
+    auto issue_part = [&](int stage, int kt, int p0, int p1) {   // pieces [p0, p1) of this wave's share
+        char* sbase = smem + stage * STAGE;
+        const int8_t* a = Ag + (int64_t)kt * A_BYTES;
+        const int8_t* b = Bg + (int64_t)kt * B_BYTES;
+#pragma unroll
+        for (int pi = p0; pi < p1; ++pi) {
             const int p = wave + NWAVES * pi;
             const int8_t* src = p < A_PIECES ? a + p * 1024 : b + (p - A_PIECES) * 1024;
             __builtin_amdgcn_global_load_lds(QG_GLOBAL_PTR(src), QG_LDS_PTR(sbase + p * 1024), 16, 0, 0);
@@ -443,9 +461,66 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    static_assert(DBUF, "fragments are double-buffered across k-tiles (a register-lean single-buffered limb variant of this"
-                        " kernel was measured 2 % slower than k_mfma on 32x32x32 and dropped)");
-    {
+    if constexpr (!DBUF) {
+        // Limb variant: the fragment double-buffer of a whole k-tile does not fit beside NW accumulator sets, so the k-tile is
+        // walked in TI row steps: A fragments of row step i+1 (LA reads) are fetched under the MFMAs of row step i into the
+        // other of two small buffers, B fragments of the next k-tile under the second-to-last row step.
+        static_assert(TI % 2 == 0, "the A buffer parity must return to 0 at the end of a k-tile");
+        v4i pa[2][LA], pb[2][LB][TJ];
+        auto load_a = [&](int buf, const char* sA, int i) {
+            const int ra = (wm * TI + i) * 16 + fr;
+#pragma unroll
+            for (int l = 0; l < LA; ++l) pa[buf][l] = *(const v4i*)(sA + (l * TM + ra) * BK + ((fq ^ swz<BK>(ra)) * 16));
+        };
+        auto load_b = [&](int buf, const char* sA) {
+            const char* sB = sA + LA * TM * BK;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int rb = (wn * TJ + j) * 16 + fr;
+#pragma unroll
+                for (int l = 0; l < LB; ++l) pb[buf][l][j] = *(const v4i*)(sB + (l * TN + rb) * BK + ((fq ^ swz<BK>(rb)) * 16));
+            }
+        };
+        load_b(0, smem);
+        load_a(0, smem, 0);
+        int st0 = 0, st1 = 1, st2 = 2;   // stages of tiles k, k+1, k+2
+        for (int kt = 0; kt < nk; kt += 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = kt + h;
+                if (k < nk) {
+                    publish();
+                    const int kn = k + 2 < nk ? k + 2 : nk - 1;
+                    const char* cur = smem + st0 * STAGE;
+                    const char* nxt = smem + st1 * STAGE;
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) {
+                        // reads first, fenced: their first use is a whole row step (LA*LB*TJ MFMAs) away
+                        if (i + 1 < TI) load_a((i + 1) & 1, cur, i + 1);
+                        else load_a(0, nxt, 0);
+                        if (i == TI - 2) load_b(h ^ 1, nxt);
+                        if constexpr (HINT) __builtin_amdgcn_sched_barrier(0);
+                        issue_part(st2, kn, PPW * i / TI, PPW * (i + 1) / TI);
+#pragma unroll
+                        for (int la = 0; la < LA; ++la)
+#pragma unroll
+                            for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+                                for (int j = 0; j < TJ; ++j)
+                                    acc[la + lb][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(pa[i & 1][la], pb[h][lb][j], acc[la + lb][i][j], 0, 0, 0);
+                        if constexpr (HINT) {
+                            interleave_hint<LA * LB * TJ, 0, (PPW + TI - 1) / TI>(std::make_integer_sequence<int, LA * LB * TJ>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    st0 = st1;
+                    st1 = st2;
+                    st2 = (st2 + 1) % 3;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
         // iteration k: publish tile k+1, refill the stage of tile k-1 with tile k+2, prefetch fragments of k+1, MFMA k
         load_frags(0, smem);
         int st1 = 1, st2 = 2;  // stages of tiles k+1, k+2
@@ -533,6 +608,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
     }
 }
 
+// The partner of a 3 x 3 launch for operands whose third limb planes are empty: 2 x 2 limbs read from the 3-plane storage
+// (each kernel of the pair returns at once unless the plane masks select it).
+template <int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE, bool EP>
+void launch_plane_partner(const QMfmaArgs& a, hipStream_t st, int64_t blocks)
+{
+    static const bool no_partner = getenv("QG_NO_PLANE_MASK") != nullptr;   // A/B switch (tools/measure_masked.py); full-range data only!
+    if (!(a.maskA || a.maskB) || no_partner) return;
+    constexpr int TM = WGM * TI * 32, TN = WGN * TJ * 32;
+    constexpr int lds2 = NSTAGE * (2 * TM + 2 * TN) * BK;
+    static bool attr_set2 = false;
+    if (!attr_set2) {
+        if (hipFuncSetAttribute((const void*)k_mfma<2, 2, BK, WGM, WGN, TI, TJ, NSTAGE, 0, EP, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2) != hipSuccess) return;
+        attr_set2 = true;
+    }
+    hipLaunchKernelGGL((k_mfma<2, 2, BK, WGM, WGN, TI, TJ, NSTAGE, 0, EP, 3, 3>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds2, st, a);
+}
+
 template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF, bool EP = false, bool HINT = true>
 hipError_t launch16(const QMfmaArgs& a, hipStream_t st)
 {
@@ -540,7 +632,7 @@ hipError_t launch16(const QMfmaArgs& a, hipStream_t st)
         static const bool no_hint = getenv("QG_NO_HINT16") != nullptr;
         if (no_hint && !a.has_ep) return launch16<LA, LB, WGM, WGN, TI, TJ, DBUF, false, false>(a, st);
     }
-    if constexpr (!EP) {
+    if constexpr (!EP && (LA * LB == 1 || LA * LB == 9)) {
         if (a.has_ep) return launch16<LA, LB, WGM, WGN, TI, TJ, DBUF, true>(a, st);
     }
     if (a.has_ep && (!EP || !a.ep.bits32)) return hipErrorInvalidValue;
@@ -556,6 +648,7 @@ hipError_t launch16(const QMfmaArgs& a, hipStream_t st)
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll || a.Kp % 64 || a.Mp % TM || a.Np % TN) return hipErrorInvalidValue;
     hipLaunchKernelGGL((k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF, EP, HINT>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
+    if constexpr (LA == 3 && LB == 3 && TM == 128 && TN == 128) launch_plane_partner<64, 2, 4, 2, 1, 3, EP>(a, st, blocks);
     return hipGetLastError();
 }
 
@@ -592,20 +685,7 @@ hipError_t launch(const QMfmaArgs& a, hipStream_t st)
     }
     if (a.kara) return hipErrorInvalidValue;
     hipLaunchKernelGGL((k_mfma<LA, LB, BK, WGM, WGN, TI, TJ, NSTAGE, ABL, EP>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
-    if constexpr (LA == 3 && LB == 3 && ABL == 0) {
-        static const bool no_partner = getenv("QG_NO_PLANE_MASK") != nullptr;   // A/B switch (tools/measure_masked.py); full-range data only!
-        if ((a.maskA || a.maskB) && !no_partner) {
-            // the partner for operands whose third limb planes are empty: 2 x 2 limbs read from the 3-plane storage
-            constexpr int lds2 = NSTAGE * (2 * TM + 2 * TN) * BK;
-            static bool attr_set2 = false;
-            if (!attr_set2) {
-                hipError_t e = hipFuncSetAttribute((const void*)k_mfma<2, 2, BK, WGM, WGN, TI, TJ, NSTAGE, ABL, EP, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-                if (e != hipSuccess) return e;
-                attr_set2 = true;
-            }
-            hipLaunchKernelGGL((k_mfma<2, 2, BK, WGM, WGN, TI, TJ, NSTAGE, ABL, EP, 3, 3>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds2, st, a);
-        }
-    }
+    if constexpr (LA == 3 && LB == 3 && ABL == 0) launch_plane_partner<BK, WGM, WGN, TI, TJ, NSTAGE, EP>(a, st, blocks);
     return hipGetLastError();
 }
 
@@ -688,6 +768,21 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
         case 33: return launch<3, 3, 64, 2, 2, 1, 1, 3>(a, st);
         default: return hipErrorInvalidValue;
         }
+    }
+    if (a.variant == 3 && !a.kara) {
+        // 128x128 limb tiles: v_mfma_i32_16x16x64_i8 with the row-step fragment pipeline (k_mfma16, DBUF = false) against
+        // 32x32x32 (k_mfma) at 4096^3, same box, ms: 3x3 0.409 / 0.427, 2x3 0.319 / 0.329, 3x2 0.322 / 0.332, 1x2 0.135 / 0.176,
+        // 2x1 0.138 / 0.178 -> the small shape (the chip holds a higher clock on it); 2x2 0.251 / 0.246, 1x3 0.219 / 0.206,
+        // 3x1 0.219 / 0.215 -> the large one (profiles/r03j_limb_shapes.log).  QG_LIMB32 keeps 32x32x32 everywhere (A/B).
+        static const bool limb32 = getenv("QG_LIMB32") != nullptr;
+        if (!limb32) switch (LA * 10 + LB) {
+            case 33: return launch16<3, 3, 2, 4, 4, 2, false>(a, st);
+            case 23: if (!a.has_ep) return launch16<2, 3, 2, 4, 4, 2, false>(a, st); break;
+            case 32: if (!a.has_ep) return launch16<3, 2, 2, 4, 4, 2, false>(a, st); break;
+            case 12: if (!a.has_ep) return launch16<1, 2, 2, 4, 4, 2, false>(a, st); break;
+            case 21: if (!a.has_ep) return launch16<2, 1, 2, 4, 4, 2, false>(a, st); break;
+            default: break;
+            }
     }
     switch (LA * 10 + LB) {
     case 12: return launch<1, 2, 64, 2, 4, 2, 1, 3>(a, st);
