@@ -346,13 +346,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 typedef int v4acc __attribute__((ext_vector_type(4)));
 
 // LA x LB limbs; DBUF: fragments double-buffered across k-tiles (only when the registers allow it)
-template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF, bool EP, bool HINT = true>   // TI x TJ tiles of 16x16 per wave
+template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF, bool EP, bool HINT = true, int PV = 1, int SA = LA, int SB = LB>   // TI x TJ tiles of 16x16 per wave; SA, SB: planes stored (k_mfma)
 __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
 {
-    if constexpr (LA == 3 && LB == 3) {   // plane masks: see k_mfma; the 2 x 2 partner of the launch pair is k_mfma<2,2,...,3,3>
+    if constexpr (SA == 3 && SB == 3) {   // plane masks: see k_mfma; a 3 x 3 launch is the pair <3,3> + <2,2 on 3-plane storage>
         const unsigned ma = g.maskA ? (unsigned)__builtin_amdgcn_readfirstlane(*g.maskA) : 7u;
         const unsigned mb = g.maskB ? (unsigned)__builtin_amdgcn_readfirstlane(*g.maskB) : 7u;
-        if (((ma | mb) & 4u) == 0) return;
+        const bool two_planes_suffice = ((ma | mb) & 4u) == 0;
+        if (two_planes_suffice != (LA == 2)) return;   // the other kernel of this launch pair does the work
     }
     constexpr int BK = 64, NSTAGE = 3;
     constexpr int TM = WGM * TI * 16, TN = WGN * TJ * 16;
@@ -383,13 +384,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
     const int tile_n = (bid % (GM * tiles_n)) / gsz;
 
     const int nk = (int)(g.Kp / BK);
-    constexpr int A_BYTES = LA * TM * BK, B_BYTES = LB * TN * BK, A_PIECES = A_BYTES / 1024;
-    const int8_t* Ag = g.A + (int64_t)tile_m * nk * A_BYTES + lane * 16;
-    const int8_t* Bg = g.B + (int64_t)tile_n * nk * B_BYTES + lane * 16;
+    constexpr int A_BYTES = LA * TM * BK, B_BYTES = LB * TN * BK, A_PIECES = A_BYTES / 1024;   // copied per stage (the first LA / LB planes)
+    constexpr int A_STRIDE = SA * TM * BK, B_STRIDE = SB * TN * BK;                            // stored per k-tile
+    const int8_t* Ag = g.A + (int64_t)tile_m * nk * A_STRIDE + lane * 16;
+    const int8_t* Bg = g.B + (int64_t)tile_n * nk * B_STRIDE + lane * 16;
     auto issue = [&](int stage, int kt) {
         char* sbase = smem + stage * STAGE;
-        const int8_t* a = Ag + (int64_t)kt * A_BYTES;
-        const int8_t* b = Bg + (int64_t)kt * B_BYTES;
+        const int8_t* a = Ag + (int64_t)kt * A_STRIDE;
+        const int8_t* b = Bg + (int64_t)kt * B_STRIDE;
 #pragma unroll
         for (int pi = 0; pi < PPW; ++pi) {
             const int p = wave + NWAVES * pi;
@@ -400,8 +402,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
 
     auto issue_part = [&](int stage, int kt, int p0, int p1) {   // pieces [p0, p1) of this wave's share
         char* sbase = smem + stage * STAGE;
-        const int8_t* a = Ag + (int64_t)kt * A_BYTES;
-        const int8_t* b = Bg + (int64_t)kt * B_BYTES;
+        const int8_t* a = Ag + (int64_t)kt * A_STRIDE;
+        const int8_t* b = Bg + (int64_t)kt * B_STRIDE;
 #pragma unroll
         for (int pi = p0; pi < p1; ++pi) {
             const int p = wave + NWAVES * pi;
@@ -454,11 +456,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
         asm volatile("" ::: "memory");
     };
 
-    // tiles 0, 1 in flight; tile 0 published
+    constexpr bool DEEP = DBUF && HINT && PV != 0;   // two k-tiles in flight (below)
+    // tiles 0, 1 (and 2) in flight; tile 0 published
     issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (DEEP) {
+        issue(1, nk > 1 ? 1 : nk - 1);
+        issue(2, nk > 2 ? 2 : nk - 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+    } else {
+        if (nk > 1) issue(1, 1);
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if constexpr (!DBUF) {
@@ -500,7 +509,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
                         else load_a(0, nxt, 0);
                         if (i == TI - 2) load_b(h ^ 1, nxt);
                         if constexpr (HINT) __builtin_amdgcn_sched_barrier(0);
-                        issue_part(st2, kn, PPW * i / TI, PPW * (i + 1) / TI);
+                        // LDS-DMA of tile k+2 in the first two row steps: a piece issued late in the iteration has no time to
+                        // land before the next publish (spread over all four row steps, PV = 0: 0.414 vs 0.390 ms at 4096^3)
+                        if constexpr (PV == 0) issue_part(st2, kn, PPW * i / TI, PPW * (i + 1) / TI);
+                        else { if (i < 2) issue_part(st2, kn, PPW * i / 2, PPW * (i + 1) / 2); }
 #pragma unroll
                         for (int la = 0; la < LA; ++la)
 #pragma unroll
@@ -509,7 +521,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
                                 for (int j = 0; j < TJ; ++j)
                                     acc[la + lb][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(pa[i & 1][la], pb[h][lb][j], acc[la + lb][i][j], 0, 0, 0);
                         if constexpr (HINT) {
-                            interleave_hint<LA * LB * TJ, 0, (PPW + TI - 1) / TI>(std::make_integer_sequence<int, LA * LB * TJ>{});
+                            interleave_hint<LA * LB * TJ, 0, PV == 0 ? (PPW + TI - 1) / TI : (PPW + 1) / 2>(std::make_integer_sequence<int, LA * LB * TJ>{});
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -529,6 +541,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
             for (int h = 0; h < 2; ++h) {
                 const int k = kt + h;
                 if (k < nk) {
+                    if constexpr (DEEP) {
+                        // The fragments of tile k were read out of LDS during iteration k-1, so the stage of tile k is free as
+                        // soon as every wave is here: refill it with tile k+3 now.  Two tiles (k+2, k+3) stay in flight, each
+                        // with two iterations to land, on the same three stages; the wait is counted (tile k+1 must be in, the
+                        // PPW pieces of tile k+2 may fly on).  A k-tile of this kernel is 32 MFMAs = 512 issue cycles, less than
+                        // one trip to L2.
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                        issue((st1 + 2) % 3, k + 3 < nk ? k + 3 : nk - 1);
+                        load_frags(h ^ 1, smem + st1 * STAGE);
+                        mfmas(h);
+                        interleave_hint<LA * LB * TI * TJ, LA * TI + LB * TJ, PPW>(std::make_integer_sequence<int, LA * LB * TI * TJ>{});
+                        st1 = st2;
+                        st2 = (st1 + 1) % 3;
+                        continue;
+                    }
                     // branch-free body (past the end: the last tile is fetched once more into a stage nobody reads again, and
                     // fragments are read from it in vain) so that DMA issues, fragment reads and MFMAs share one basic block
                     // and interleave_hint can spread them
@@ -625,7 +654,7 @@ void launch_plane_partner(const QMfmaArgs& a, hipStream_t st, int64_t blocks)
     hipLaunchKernelGGL((k_mfma<2, 2, BK, WGM, WGN, TI, TJ, NSTAGE, 0, EP, 3, 3>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds2, st, a);
 }
 
-template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF, bool EP = false, bool HINT = true>
+template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF, bool EP = false, bool HINT = true, int PV = 1, int SA = LA, int SB = LB>
 hipError_t launch16(const QMfmaArgs& a, hipStream_t st)
 {
     if constexpr (HINT && !EP) {
@@ -640,15 +669,29 @@ hipError_t launch16(const QMfmaArgs& a, hipStream_t st)
     const int lds = 3 * (LA * TM + LB * TN) * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF, EP, HINT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF, EP, HINT, PV, SA, SB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int64_t blocks = (a.Mp / TM) * (a.Np / TN);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll || a.Kp % 64 || a.Mp % TM || a.Np % TN) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF, EP, HINT>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
-    if constexpr (LA == 3 && LB == 3 && TM == 128 && TN == 128) launch_plane_partner<64, 2, 4, 2, 1, 3, EP>(a, st, blocks);
+    hipLaunchKernelGGL((k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF, EP, HINT, PV, SA, SB>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
+    if constexpr (LA == 3 && LB == 3 && SA == 3) {
+        // the partner for operands whose third limb planes are empty: 2 x 2 limbs read from the 3-plane storage (each kernel
+        // of the pair returns at once unless the plane masks select it)
+        static const bool no_partner = getenv("QG_NO_PLANE_MASK") != nullptr;   // A/B switch (tools/measure_masked.py); full-range data only!
+        if ((a.maskA || a.maskB) && !no_partner) {
+            constexpr int lds2 = 3 * (2 * TM + 2 * TN) * 64;
+            static bool attr_set2 = false;
+            if (!attr_set2) {
+                hipError_t e = hipFuncSetAttribute((const void*)k_mfma16<2, 2, WGM, WGN, TI, TJ, DBUF, EP, HINT, PV, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+                if (e != hipSuccess) return e;
+                attr_set2 = true;
+            }
+            hipLaunchKernelGGL((k_mfma16<2, 2, WGM, WGN, TI, TJ, DBUF, EP, HINT, PV, 3, 3>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds2, st, a);
+        }
+    }
     return hipGetLastError();
 }
 
@@ -753,7 +796,11 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
         // (0.283 vs 0.308 ms at 8192x8192x4096, profiles/r01n_ablation_mfma_shape.log); QG_ABLATE=32 keeps the other
         if (a.variant == 5) return launch<1, 1, 64, 2, 2, 1, 1, 3>(a, st);   // 64x64 tiles, one 32x32 MFMA tile per wave
         if (ablation() == 32) return a.variant == 2 ? launch<1, 1, 64, 2, 4, 4, 2, 3>(a, st) : launch<1, 1, 64, 2, 2, 2, 2, 3>(a, st);
-        if (a.variant == 2) return launch16<1, 1, 2, 4, 8, 4, true>(a, st);
+        if (a.variant == 2) {
+            static const bool shallow = getenv("QG_NO_DEEP") != nullptr;   // A/B: one k-tile in flight instead of two
+            if (shallow && !a.has_ep) return launch16<1, 1, 2, 4, 8, 4, true, false, true, 0>(a, st);
+            return launch16<1, 1, 2, 4, 8, 4, true>(a, st);
+        }
         return launch<1, 1, 64, 2, 2, 2, 2, 3>(a, st);  // 128x128 tiles (small problems): the 32x32x32 kernel is the faster one there
     }
     if (a.variant == 6) {   // 64x64 tiles, 4 waves, one 32x32 MFMA tile per wave
@@ -771,16 +818,23 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
     }
     if (a.variant == 3 && !a.kara) {
         // 128x128 limb tiles: v_mfma_i32_16x16x64_i8 with the row-step fragment pipeline (k_mfma16, DBUF = false) against
-        // 32x32x32 (k_mfma) at 4096^3, same box, ms: 3x3 0.409 / 0.427, 2x3 0.319 / 0.329, 3x2 0.322 / 0.332, 1x2 0.135 / 0.176,
-        // 2x1 0.138 / 0.178 -> the small shape (the chip holds a higher clock on it); 2x2 0.251 / 0.246, 1x3 0.219 / 0.206,
-        // 3x1 0.219 / 0.215 -> the large one (profiles/r03j_limb_shapes.log).  QG_LIMB32 keeps 32x32x32 everywhere (A/B).
+        // 32x32x32 (k_mfma) at 4096^3, same box, ms: 3x3 0.388 / 0.427, 2x3 0.290 / 0.329, 3x2 0.295 / 0.332, 2x2 0.221 / 0.232,
+        // 1x3 0.194 / 0.199, 3x1 0.200 / 0.206, 1x2 0.128 / 0.176, 2x1 0.130 / 0.178 (the chip holds a higher clock on the
+        // small shape; profiles/r03j_limb_shapes.log, r03k_pipeline.log).  QG_LIMB32 keeps 32x32x32 everywhere (A/B).
         static const bool limb32 = getenv("QG_LIMB32") != nullptr;
         if (!limb32) switch (LA * 10 + LB) {
-            case 33: return launch16<3, 3, 2, 4, 4, 2, false>(a, st);
+            case 33: {
+                static const bool spread = getenv("QG_DMA_SPREAD") != nullptr;   // A/B: LDS-DMA issues over all four row steps
+                if (spread && !a.has_ep) return launch16<3, 3, 2, 4, 4, 2, false, false, true, 0>(a, st);
+                return launch16<3, 3, 2, 4, 4, 2, false>(a, st);
+            }
             case 23: if (!a.has_ep) return launch16<2, 3, 2, 4, 4, 2, false>(a, st); break;
             case 32: if (!a.has_ep) return launch16<3, 2, 2, 4, 4, 2, false>(a, st); break;
             case 12: if (!a.has_ep) return launch16<1, 2, 2, 4, 4, 2, false>(a, st); break;
             case 21: if (!a.has_ep) return launch16<2, 1, 2, 4, 4, 2, false>(a, st); break;
+            case 13: if (!a.has_ep) return launch16<1, 3, 2, 4, 4, 2, false>(a, st); break;
+            case 31: if (!a.has_ep) return launch16<3, 1, 2, 4, 4, 2, false>(a, st); break;
+            case 22: if (!a.has_ep) return launch16<2, 2, 2, 4, 4, 2, false>(a, st); break;
             default: break;
             }
     }
