@@ -99,6 +99,73 @@ __device__ __forceinline__ unsigned put_packed(const QPackedGeom& p, char* dst, 
     return mask;
 }
 
+// Fast path of k_pack for the common operand: real, 32-bit host elements, balanced int8 limb planes with 64-byte k-tiles.
+// One 64-row x 64-k block of the limb layout per workgroup; a thread owns 16 consecutive k of one row, i.e. one 16-byte
+// chunk per limb plane (one 16-byte store each).  R_FAST: rows are the contiguous host axis (column-major A) -> the 64
+// lanes of a wave take 64 consecutive rows (256-byte coalesced loads per k); otherwise k is contiguous (B, transposed A)
+// -> 4 lanes cover the 64 k-bytes of a row and a wave stores 1 KiB contiguously per plane.  Same bytes as k_pack
+// (tests/test_gpu_resources.py::test_fast_pack_paths_write_the_bytes_of_the_generic_kernels; QG_NO_FAST_PACK=1 disables).
+template <bool R_FAST>
+__global__ __launch_bounds__(256) void k_pack_limb32(QOperandGeom g, QPackedGeom p, const int32_t* __restrict__ src, int8_t* __restrict__ dst,
+                                                     int check, int* flag)
+{
+    const int kt = (int)(p.K_p / 64);
+    const int tk = (int)(blockIdx.x % kt), tr64 = (int)(blockIdx.x / kt);
+    const int t = threadIdx.x;
+    const int row_l = R_FAST ? (t & 63) : (t >> 2), kc = R_FAST ? (t >> 6) : (t & 3);
+    const int64_t r = (int64_t)tr64 * 64 + row_l, k0 = (int64_t)tk * 64 + kc * 16;
+    const int W = g.W[0];
+    const int64_t lo = g.S[0] ? -((int64_t)1 << W) : 0, hi = ((int64_t)1 << W) - 1;
+    int32_t v[16];
+    bool bad = false;
+    const bool row_in = r < g.rows;
+    const int32_t* q = src + r * g.rs + k0 * g.ks;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        v[j] = (row_in && k0 + j < g.K) ? q[(int64_t)j * g.ks] : 0;
+        bad |= (v[j] < lo) | (v[j] > hi);
+    }
+    const int rl = (int)(r % p.tr);
+    const int sw = (0x78 >> (2 * ((rl >> 2) & 3))) & 3;   // swz<64>(): {0,2,3,1}
+    const int64_t blk = ((r / p.tr) * kt + tk) * p.limbs;
+    int8_t* out = dst + (blk * p.tr + rl) * 64 + ((kc ^ sw) * 16);
+    unsigned mask = 0;
+    for (int l = 0; l < p.limbs; ++l) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        uint32_t any = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int32_t d = (int32_t)(int8_t)(v[j] & 0xff);   // balanced digit in [-128,127]
+            w[j >> 2] |= (uint32_t)(d & 0xff) << (8 * (j & 3));
+            any |= (uint32_t)d;
+            v[j] = (int32_t)(((int64_t)v[j] - d) >> 8);
+        }
+        *(uint4*)(out + (int64_t)l * p.tr * 64) = make_uint4(w[0], w[1], w[2], w[3]);
+        mask |= any ? (1u << l) : 0u;
+    }
+    if (p.trailer) {   // plane mask of the operand: one atomic per wave that saw a non-zero limb
+#pragma unroll
+        for (int o = 32; o; o >>= 1) mask |= __shfl_xor(mask, o);
+        if ((t & 63) == 0 && mask) atomicOr((unsigned*)(dst + p.trailer), mask);
+    }
+    if (check && bad) atomicOr(flag, 1);
+}
+
+// Fast path of k_unpack_c: real, 32-bit containers and 32-bit host elements, tiled packed C.  A column of a tile is tm
+// contiguous rows in both layouts, so unpacking is a copy of 16-byte pieces; thread = 4 consecutive rows of one column.
+__global__ __launch_bounds__(256) void k_unpack_c32(QCGeom c, const int32_t* __restrict__ packed, int32_t* __restrict__ dst, int vec)
+{
+    const int64_t m4 = c.M / 4 + (c.M % 4 != 0);
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= m4 * c.N) return;
+    const int64_t n = idx / m4, m = (idx % m4) * 4;
+    const int64_t pi = (((m / c.tm) * (c.Np / c.tn) + n / c.tn) * c.tn + n % c.tn) * c.tm + m % c.tm;   // tm % 4 == 0: the 4 rows share a tile
+    int32_t* q = dst + m + n * c.ldc;
+    if (vec && m + 4 <= c.M) *(int4*)q = *(const int4*)(packed + pi);
+    else
+        for (int e = 0; e < 4 && m + e < c.M; ++e) q[e] = packed[pi + e];
+}
+
 // tile = 64 (k) x 64 (r); 256 threads.  The fast host axis is r when g.rs == 1 (non-transposed A)
 // and k otherwise; global reads follow the fast host axis, packed writes always follow k.
 __global__ __launch_bounds__(256) void k_pack(QOperandGeom g, QPackedGeom p, const char* __restrict__ src, char* __restrict__ dst,
@@ -291,6 +358,14 @@ hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const voi
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
     if (hipError_t e = zero_trailer(p, dst, st); e != hipSuccess) return e;
+    static const bool no_fast = getenv("QG_NO_FAST_PACK") != nullptr;   // A/B and the equivalence test
+    if (!no_fast && g.parts == 1 && g.elem_bytes == 4 && g.sb[0] == 4 && g.off[0] == 0 && p.limbs >= 1 && p.limbs <= 3 && !p.digit6 && p.bk == 64 &&
+        p.tr % 64 == 0 && p.rows_p % p.tr == 0 && p.K_p % 64 == 0 && g.W[0] <= 30 && ((uintptr_t)src & 3) == 0 && ((uintptr_t)dst & 15) == 0) {
+        const unsigned nb = (unsigned)((p.K_p / 64) * (p.rows_p / 64));
+        if (g.rs == 1 && g.ks != 1) hipLaunchKernelGGL(k_pack_limb32<true>, dim3(nb), dim3(256), 0, st, g, p, (const int32_t*)src, (int8_t*)dst, check_range, range_flag);
+        else hipLaunchKernelGGL(k_pack_limb32<false>, dim3(nb), dim3(256), 0, st, g, p, (const int32_t*)src, (int8_t*)dst, check_range, range_flag);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_pack, dim3((unsigned)blocks), dim3(256), 0, st, g, p, (const char*)src, (char*)dst, check_range,
                        range_flag, 0, 0ull, 0);
     return hipGetLastError();
@@ -322,6 +397,15 @@ hipError_t qg_launch_unpack_c(const QCGeom& c, const void* packed, void* dst, hi
     int64_t blocks = ((c.N + 63) / 64) * ((c.M + 63) / 64) * c.parts;
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
+    static const bool no_fast = getenv("QG_NO_FAST_PACK") != nullptr;
+    if (!no_fast && c.parts == 1 && c.cbytes == 4 && c.elem_bytes == 4 && c.sb[0] == 4 && c.off[0] == 0 && c.tm > 0 && c.tm % 4 == 0 &&
+        ((uintptr_t)packed & 15) == 0 && ((uintptr_t)dst & 3) == 0) {
+        const int vec = (c.ldc % 4 == 0) && (((uintptr_t)dst & 15) == 0);
+        const int64_t nthr = (c.M / 4 + (c.M % 4 != 0)) * c.N;
+        if ((nthr + 255) / 256 > 0x7fffffffll) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_unpack_c32, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, c, (const int32_t*)packed, (int32_t*)dst, vec);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_unpack_c, dim3((unsigned)blocks), dim3(256), 0, st, c, (const char*)packed, (char*)dst);
     return hipGetLastError();
 }
