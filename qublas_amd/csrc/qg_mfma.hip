@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 typedef int v4acc __attribute__((ext_vector_type(4)));
 
 // LA x LB limbs; DBUF: fragments double-buffered across k-tiles (only when the registers allow it)
-template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF, bool EP, bool HINT = true, int PV = 1, int SA = LA, int SB = LB>   // TI x TJ tiles of 16x16 per wave; SA, SB: planes stored (k_mfma)
+template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF, bool EP, bool HINT = true, int PV = 1, int SA = LA, int SB = LB, bool KARA = false>   // TI x TJ tiles of 16x16 per wave; SA, SB, KARA: see k_mfma
 __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
 {
     if constexpr (SA == 3 && SB == 3) {   // plane masks: see k_mfma; a 3 x 3 launch is the pair <3,3> + <2,2 on 3-plane storage>
@@ -513,6 +513,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
                         // land before the next publish (spread over all four row steps, PV = 0: 0.414 vs 0.390 ms at 4096^3)
                         if constexpr (PV == 0) issue_part(st2, kn, PPW * i / TI, PPW * (i + 1) / TI);
                         else { if (i < 2) issue_part(st2, kn, PPW * i / 2, PPW * (i + 1) / 2); }
+                        if constexpr (KARA) {   // three products of unsigned base-64 digits (k_mfma): P0, P1, P01 = (a0+a1)(b0+b1)
+                            static_assert(!KARA || (LA == 2 && LB == 2), "Karatsuba variant: 2 x 2 digits");
+                            const v4i sa = pa[i & 1][0] + pa[i & 1][1];
+#pragma unroll
+                            for (int j = 0; j < TJ; ++j) {
+                                const v4i sb = pb[h][0][j] + pb[h][1][j];
+                                acc[0][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(pa[i & 1][0], pb[h][0][j], acc[0][i][j], 0, 0, 0);
+                                acc[2][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(pa[i & 1][1], pb[h][1][j], acc[2][i][j], 0, 0, 0);
+                                acc[1][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(sa, sb, acc[1][i][j], 0, 0, 0);
+                            }
+                        } else
 #pragma unroll
                         for (int la = 0; la < LA; ++la)
 #pragma unroll
@@ -521,7 +532,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
                                 for (int j = 0; j < TJ; ++j)
                                     acc[la + lb][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(pa[i & 1][la], pb[h][lb][j], acc[la + lb][i][j], 0, 0, 0);
                         if constexpr (HINT) {
-                            interleave_hint<LA * LB * TJ, 0, PV == 0 ? (PPW + TI - 1) / TI : (PPW + 1) / 2>(std::make_integer_sequence<int, LA * LB * TJ>{});
+                            interleave_hint<(KARA ? 3 : LA * LB) * TJ, 0, PV == 0 ? (PPW + TI - 1) / TI : (PPW + 1) / 2>(std::make_integer_sequence<int, (KARA ? 3 : LA * LB) * TJ>{});
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -595,6 +606,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                if constexpr (KARA) {   // sum a'b' = P0 + 64 (P01 - P0 - P1) + 4096 P1; the biases go out with the row sums (k_mfma)
+                    const int64_t cj = g.corr - g.biasA * g.rsB[(int64_t)tile_n * TN + (wn * TJ + j) * 16 + fr];
+                    const int64_t ra = g.rsA[(int64_t)tile_m * TM + (wm * TI + i) * 16 + 4 * fq + e];
+                    const int64_t p0 = acc[0][i][j][e], p01 = acc[1][i][j][e], p1 = acc[2][i][j][e];
+                    s[j * 4 + e] = (S)(p0 + 64 * (p01 - p0 - p1) + 4096 * p1 - g.biasB * ra + cj);
+                    continue;
+                }
                 S x = (S)acc[NW - 1][i][j][e];
 #pragma unroll
                 for (int w = NW - 2; w >= 0; --w) x = x * 256 + (S)acc[w][i][j][e];
@@ -654,7 +672,7 @@ void launch_plane_partner(const QMfmaArgs& a, hipStream_t st, int64_t blocks)
     hipLaunchKernelGGL((k_mfma<2, 2, BK, WGM, WGN, TI, TJ, NSTAGE, 0, EP, 3, 3>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds2, st, a);
 }
 
-template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF, bool EP = false, bool HINT = true, int PV = 1, int SA = LA, int SB = LB>
+template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF, bool EP = false, bool HINT = true, int PV = 1, int SA = LA, int SB = LB, bool KARA = false>
 hipError_t launch16(const QMfmaArgs& a, hipStream_t st)
 {
     if constexpr (HINT && !EP) {
@@ -671,14 +689,14 @@ hipError_t launch16(const QMfmaArgs& a, hipStream_t st)
     const int lds = 3 * (LA * TM + LB * TN) * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF, EP, HINT, PV, SA, SB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF, EP, HINT, PV, SA, SB, KARA>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int64_t blocks = (a.Mp / TM) * (a.Np / TN);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll || a.Kp % 64 || a.Mp % TM || a.Np % TN) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF, EP, HINT, PV, SA, SB>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
+    hipLaunchKernelGGL((k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF, EP, HINT, PV, SA, SB, KARA>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
     if constexpr (LA == 3 && LB == 3 && SA == 3) {
         // the partner for operands whose third limb planes are empty: 2 x 2 limbs read from the 3-plane storage (each kernel
         // of the pair returns at once unless the plane masks select it)
@@ -817,6 +835,10 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
         case 33: return launch<3, 3, 64, 2, 2, 1, 1, 3>(a, st);
         default: return hipErrorInvalidValue;
         }
+    }
+    if (a.variant == 3 && a.kara && LA == 2 && LB == 2 && !a.has_ep) {
+        static const bool kara32 = getenv("QG_KARA32") != nullptr;   // A/B: the Karatsuba kernel on 32x32x32
+        if (!kara32) return launch16<2, 2, 2, 4, 4, 2, false, false, true, 1, 2, 2, true>(a, st);
     }
     if (a.variant == 3 && !a.kara) {
         // 128x128 limb tiles: v_mfma_i32_16x16x64_i8 with the row-step fragment pipeline (k_mfma16, DBUF = false) against
