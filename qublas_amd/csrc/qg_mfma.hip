@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
     //     (every wave has waited for its own LDS-DMA pieces of that tile), after which the first
     //     fragments of tile kt+1 are prefetched and the stage last read in iteration kt-1 is
     //     refilled with tile kt+2 (raw s_barrier: __syncthreads() would also drain the DMA queue).
-    static_assert(NSTAGE == 3 && KSTEPS % 2 == 0, "pipeline shape");
+    static_assert((NSTAGE == 3 || (NSTAGE > 3 && ABL == 0)) && KSTEPS % 2 == 0, "pipeline shape");
     v4i fa[2][LA][TI], fb[2][LB][TJ];
     auto load_frags = [&](int set, const char* stage_base, int ks) {
         const char* sA = stage_base;
@@ -210,9 +210,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 
     // prologue: tiles 0 and 1 in flight, tile 0 published, its first fragments loaded
     issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (NSTAGE == 3) {
+        if (nk > 1) issue(1, 1);
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        // NSTAGE - 1 tiles in flight (small problems: a k-tile of a 64x64-tile kernel is ~100 issue cycles, a fraction of one
+        // trip to L2, so with two tiles in flight every k-tile waits for its data); past the end the last tile is fetched again
+#pragma unroll
+        for (int t = 1; t < NSTAGE - 1; ++t) issue(t, t < nk ? t : nk - 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * PPW) : "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     load_frags(0, smem, 0);
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
     for (int kt = 0; kt < nk; ++kt) {
         const char* sc = smem + cur * STAGE;
         const int nx = cur + 1 == NSTAGE ? 0 : cur + 1;   // stage of tile kt+1
-        const int rf = nx + 1 == NSTAGE ? 0 : nx + 1;     // stage to refill with tile kt+2
+        const int rf = cur == 0 ? NSTAGE - 1 : cur - 1;   // stage of tile kt-1: refilled with tile kt+NSTAGE-1
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             if (ks + 1 < KSTEPS) {
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
             } else {
                 // tile kt+1 was issued one iteration ago: wait for this wave's pieces, then publish
                 if (ABL != 4) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 3) * PPW) : "memory");   // tile kt+1 is in; kt+2 ... may fly on
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                 }
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
                 if constexpr (ABL == 0) {
                     // branch-free refill (past the end: the last tile once more, into a stage nobody reads again) so that the
                     // LDS-DMA issues, the fragment reads of the next tile and this k-step's MFMAs share one basic block
-                    issue(rf, kt + 2 < nk ? kt + 2 : nk - 1);
+                    issue(rf, kt + NSTAGE - 1 < nk ? kt + NSTAGE - 1 : nk - 1);
                     load_frags(0, smem + nx * STAGE, 0);
                     mfmas(ks & 1, 0, NM);
                     interleave_hint<NM, LA * TI + LB * TJ, PPW>(std::make_integer_sequence<int, NM>{});
@@ -822,6 +830,20 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
             return launch16<1, 1, 2, 4, 8, 4, true>(a, st);
         }
         return launch<1, 1, 64, 2, 2, 2, 2, 3>(a, st);  // 128x128 tiles (small problems): the 32x32x32 kernel is the faster one there
+    }
+    if (a.variant == 6 && !a.has_ep && !a.kara && (a.Mp / 64) * (a.Np / 64) <= 256) {
+        // At most one workgroup per CU anyway: a 5-stage LDS ring (4 k-tiles in flight; a k-tile of these kernels is a few hundred
+        // cycles, less than one trip to L2).  512^2 x 4096 int<8,8>: 39.8 -> 27.9 us; with more workgroups than CUs the ring's LDS
+        // would cost co-residency (1536 x 1024 x 1024: 21.2 -> 24.4 us), and the single-limb 64x64 kernel gained nothing from it
+        // (its k-tile is bound by the dependent MFMA pair and the barrier).  QG_STAGES3 keeps three stages (A/B).
+        static const bool three = getenv("QG_STAGES3") != nullptr;
+        if (!three) switch (LA * 10 + LB) {
+            case 22: return launch<2, 2, 64, 2, 2, 1, 1, 5>(a, st);
+            case 23: return launch<2, 3, 64, 2, 2, 1, 1, 5>(a, st);
+            case 32: return launch<3, 2, 64, 2, 2, 1, 1, 5>(a, st);
+            case 33: return launch<3, 3, 64, 2, 2, 1, 1, 5>(a, st);
+            default: break;
+            }
     }
     if (a.variant == 6) {   // 64x64 tiles, 4 waves, one 32x32 MFMA tile per wave
         switch (LA * 10 + LB) {
