@@ -774,7 +774,13 @@ QMfmaCfg qg_mfma_pick(int LA, int LB, int64_t M, int64_t N)
         // (1024^2: 64 -> 256 workgroups)
         const int64_t mid = ((M + 127) / 128) * ((N + 127) / 128);
         static const bool no_small = getenv("QG_NO_SMALL_TILES") != nullptr;   // A/B switch for tools/measure_small.py
-        if (!no_small && mid <= 128 && ((M + 63) / 64) * ((N + 63) / 64) > mid) return QMfmaCfg{5, 64, 64, 64};
+        if (!no_small && mid <= 128 && ((M + 63) / 64) * ((N + 63) / 64) > mid) {
+            // 128-byte k-tiles: these launches are bound by the per-k-tile barrier, DMA issue and exposed fragment reads of a
+            // one-wave-per-SIMD workgroup (~0.2 us per 64-byte k-tile whatever the ring depth), so half as many k-tiles:
+            // 1024^3 5.97 -> 5.35 us, 512^2 x 4096 13.3 -> 10.2 us (profiles/r03n_small_ring.jsonl).  QG_BK64 for A/B.
+            static const bool bk64 = getenv("QG_BK64") != nullptr;
+            return bk64 ? QMfmaCfg{5, 64, 64, 64} : QMfmaCfg{7, 64, 64, 128};
+        }
         return QMfmaCfg{1, 128, 128, 64};
     }
     {   // limb kernels: the same small-problem rule (1024^2 outputs: 64 -> 256 workgroups)
@@ -823,6 +829,7 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
         // single limb: v_mfma_i32_16x16x64_i8 measured 8 % faster than 32x32x32 at the same tiles
         // (0.283 vs 0.308 ms at 8192x8192x4096, profiles/r01n_ablation_mfma_shape.log); QG_ABLATE=32 keeps the other
         if (a.variant == 5) return launch<1, 1, 64, 2, 2, 1, 1, 3>(a, st);   // 64x64 tiles, one 32x32 MFMA tile per wave
+        if (a.variant == 7) return launch<1, 1, 128, 2, 2, 1, 1, 3>(a, st);   // the same on 128-byte k-tiles
         if (ablation() == 32) return a.variant == 2 ? launch<1, 1, 64, 2, 4, 4, 2, 3>(a, st) : launch<1, 1, 64, 2, 2, 2, 2, 3>(a, st);
         if (a.variant == 2) {
             static const bool shallow = getenv("QG_NO_DEEP") != nullptr;   // A/B: one k-tile in flight instead of two
