@@ -781,6 +781,11 @@ QMfmaCfg qg_mfma_pick(int LA, int LB, int64_t M, int64_t N)
             static const bool bk64 = getenv("QG_BK64") != nullptr;
             return bk64 ? QMfmaCfg{5, 64, 64, 64} : QMfmaCfg{7, 64, 64, 128};
         }
+        {   // at most one workgroup per CU: 128-byte k-tiles here as well (2048^2 x 8192 55.3 -> 44.8 us, 1792^2 x 4096 30.8 -> 24.4 us,
+            // 2048^3 15.3 -> 15.2 us); with more workgroups the 96 KB LDS image would cost co-residency.  QG_BK64 for A/B.
+            static const bool bk64 = getenv("QG_BK64") != nullptr;
+            if (!bk64 && mid <= 256) return QMfmaCfg{8, 128, 128, 128};
+        }
         return QMfmaCfg{1, 128, 128, 64};
     }
     {   // limb kernels: the same small-problem rule (1024^2 outputs: 64 -> 256 workgroups)
@@ -830,6 +835,7 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
         // (0.283 vs 0.308 ms at 8192x8192x4096, profiles/r01n_ablation_mfma_shape.log); QG_ABLATE=32 keeps the other
         if (a.variant == 5) return launch<1, 1, 64, 2, 2, 1, 1, 3>(a, st);   // 64x64 tiles, one 32x32 MFMA tile per wave
         if (a.variant == 7) return launch<1, 1, 128, 2, 2, 1, 1, 3>(a, st);   // the same on 128-byte k-tiles
+        if (a.variant == 8) return launch<1, 1, 128, 2, 2, 2, 2, 3>(a, st);   // 128x128 tiles on 128-byte k-tiles
         if (ablation() == 32) return a.variant == 2 ? launch<1, 1, 64, 2, 4, 4, 2, 3>(a, st) : launch<1, 1, 64, 2, 2, 2, 2, 3>(a, st);
         if (a.variant == 2) {
             static const bool shallow = getenv("QG_NO_DEEP") != nullptr;   // A/B: one k-tile in flight instead of two
