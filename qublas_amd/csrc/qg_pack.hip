@@ -99,7 +99,7 @@ __device__ __forceinline__ unsigned put_packed(const QPackedGeom& p, char* dst, 
     return mask;
 }
 
-// Fast path of k_pack for the common operand: real, 32-bit host elements, balanced int8 limb planes with 64-byte k-tiles.
+// Fast path of k_pack for the common operand: real, 32-bit host elements, balanced int8 limb planes with 64- or 128-byte k-tiles.
 // One 64-row x 64-k block of the limb layout per workgroup; a thread owns 16 consecutive k of one row, i.e. one 16-byte
 // chunk per limb plane (one 16-byte store each).  R_FAST: rows are the contiguous host axis (column-major A) -> the 64
 // lanes of a wave take 64 consecutive rows (256-byte coalesced loads per k); otherwise k is contiguous (B, transposed A)
@@ -126,9 +126,11 @@ __global__ __launch_bounds__(256) void k_pack_limb32(QOperandGeom g, QPackedGeom
         bad |= (v[j] < lo) | (v[j] > hi);
     }
     const int rl = (int)(r % p.tr);
-    const int sw = (0x78 >> (2 * ((rl >> 2) & 3))) & 3;   // swz<64>(): {0,2,3,1}
-    const int64_t blk = ((r / p.tr) * kt + tk) * p.limbs;
-    int8_t* out = dst + (blk * p.tr + rl) * 64 + ((kc ^ sw) * 16);
+    // the kernels' swz<BK>(): 64-byte rows {0,2,3,1}[(row / 4) % 4], 128-byte rows (row / 2) % 8
+    const int sw = p.bk == 64 ? (0x78 >> (2 * ((rl >> 2) & 3))) & 3 : (rl >> 1) & 7;
+    const int c = p.bk == 64 ? kc : (tk & 1) * 4 + kc;   // 16-byte chunk of this thread inside its k-tile
+    const int64_t blk = ((r / p.tr) * (p.K_p / p.bk) + (p.bk == 64 ? tk : tk >> 1)) * p.limbs;
+    int8_t* out = dst + (blk * p.tr + rl) * p.bk + ((c ^ sw) * 16);
     unsigned mask = 0;
     for (int l = 0; l < p.limbs; ++l) {
         uint32_t w[4] = {0, 0, 0, 0};
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void k_pack_limb32(QOperandGeom g, QPackedGeom
             any |= (uint32_t)d;
             v[j] = (int32_t)(((int64_t)v[j] - d) >> 8);
         }
-        *(uint4*)(out + (int64_t)l * p.tr * 64) = make_uint4(w[0], w[1], w[2], w[3]);
+        *(uint4*)(out + (int64_t)l * p.tr * p.bk) = make_uint4(w[0], w[1], w[2], w[3]);
         mask |= any ? (1u << l) : 0u;
     }
     if (p.trailer) {   // plane mask of the operand: one atomic per wave that saw a non-zero limb
@@ -359,8 +361,8 @@ hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const voi
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
     if (hipError_t e = zero_trailer(p, dst, st); e != hipSuccess) return e;
     static const bool no_fast = getenv("QG_NO_FAST_PACK") != nullptr;   // A/B and the equivalence test
-    if (!no_fast && g.parts == 1 && g.elem_bytes == 4 && g.sb[0] == 4 && g.off[0] == 0 && p.limbs >= 1 && p.limbs <= 3 && !p.digit6 && p.bk == 64 &&
-        p.tr % 64 == 0 && p.rows_p % p.tr == 0 && p.K_p % 64 == 0 && g.W[0] <= 30 && ((uintptr_t)src & 3) == 0 && ((uintptr_t)dst & 15) == 0) {
+    if (!no_fast && g.parts == 1 && g.elem_bytes == 4 && g.sb[0] == 4 && g.off[0] == 0 && p.limbs >= 1 && p.limbs <= 3 && !p.digit6 && (p.bk == 64 || p.bk == 128) &&
+        p.tr % 64 == 0 && p.rows_p % p.tr == 0 && p.K_p % p.bk == 0 && g.W[0] <= 30 && ((uintptr_t)src & 3) == 0 && ((uintptr_t)dst & 15) == 0) {
         const unsigned nb = (unsigned)((p.K_p / 64) * (p.rows_p / 64));
         if (g.rs == 1 && g.ks != 1) hipLaunchKernelGGL(k_pack_limb32<true>, dim3(nb), dim3(256), 0, st, g, p, (const int32_t*)src, (int8_t*)dst, check_range, range_flag);
         else hipLaunchKernelGGL(k_pack_limb32<false>, dim3(nb), dim3(256), 0, st, g, p, (const int32_t*)src, (int8_t*)dst, check_range, range_flag);
