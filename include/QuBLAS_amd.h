@@ -183,7 +183,17 @@ public:
     raw_t data = 0;
 
     constexpr Qu_s() = default;
-    Qu_s(double v) : data(raw_t(detail::from_double(v, fmt))) {}
+    // QuMode<RND::CONV>: the reference's construction from a double goes through a 2400-bit buffer whose CONV branch
+    // returns an artefact (the format maximum for every negative input; tests/test_from_double.py).  This header does not
+    // imitate it and does not silently differ either: it throws, unless QUBLAS_AMD_ARITHMETIC_CONV is defined, in which
+    // case the value is rounded half-to-even (the definition the reference's own <= 64-bit conversions implement).
+    Qu_s(double v) : data(raw_t(detail::from_double(v, fmt)))
+    {
+#ifndef QUBLAS_AMD_ARITHMETIC_CONV
+        if constexpr (QM::value == QG_RND_CONV)
+            throw std::runtime_error("Qu(double) with QuMode<RND::CONV>: reference result is a multi-word artefact; define QUBLAS_AMD_ARITHMETIC_CONV for round-half-even");
+#endif
+    }
     double toDouble() const { return std::ldexp(double(data), -F); }
     Qu_s& fill(int64_t raw) { data = raw_t(raw); return *this; }  // raw store, no range check (QuBLAS.h:2447-2452)
 };

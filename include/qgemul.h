@@ -8,7 +8,7 @@
  * Qreduce include/QuBLAS.h:4960-4990 / :5014-5018 and the converting constructor :2398-2411).
  *
  * The reference resolves every quantisation decision at compile time from template tags.
- * The host header (include/QuBLAS_amd.h, or the binding in include/qgemul_lower.hpp used with
+ * The host header (include/QuBLAS_amd.h, or the binding in include/qgemul_reference_binding.hpp used with
  * the reference's own header) evaluates the same merger rules at compile time and lowers the
  * result to the plain-data descriptor below; nothing in this file is a template, nothing
  * depends on PyTorch, and every pointer is a plain pointer.
@@ -137,7 +137,16 @@ enum {
      * (HBM-bound, 5-6 TB/s).  The single-limb kernels also have a fused variant but it is slower than the pass (one
      * workgroup per CU: the matrix cores idle during the longer epilogue), so it is opt-in. */
     QG_OPT_FUSED_EPILOGUE = 16u,  /* fuse wherever a fused variant exists (32-bit chains on the single-limb kernels too) */
-    QG_OPT_UNFUSED_EPILOGUE = 32u /* never fuse: always the pass after the kernel */
+    QG_OPT_UNFUSED_EPILOGUE = 32u, /* never fuse: always the pass after the kernel */
+    /* result-identical kernel choices, for equivalence tests and same-process A/B timing */
+    QG_OPT_GENERIC_LAYOUT = 64u,   /* pack / unpack with the any-format kernels even where a fast path exists */
+    /* qgemul_pack_f64 on an element whose QuMode is RND::CONV: the reference's Qu_s(double) takes a 2400-bit path whose CONV
+     * branch returns a multi-word artefact (the format maximum for every negative input; tests/test_from_double.py), so by
+     * default such a pack is REJECTED (QG_EUNSUPPORTED).  With this flag the engine converts with the arithmetic definition
+     * of RND::CONV (round half to even) — what the <= 62-bit conversions on the Qgemul path do and the reference pins. */
+    QG_OPT_ARITHMETIC_CONV = 256u,
+    QG_OPT_LOCKSTEP_TILES = 128u   /* large single-limb problems: the 64-byte-k-tile kernel whose waves run in lock step
+                                    * (k_mfma16) instead of the two-group kernel on 128-byte k-tiles (k_mfma_pp) */
 };
 
 /* status codes */
@@ -224,7 +233,8 @@ enum { QG_OPERAND_A = 0, QG_OPERAND_B = 1, QG_OPERAND_C = 2 };
 int qgemul_pack(qgemul_plan* p, int operand, const void* src_dev, int64_t ld, void* packed_dev);
 /* quantise-on-load: `src_dev` is a device pointer to a column-major tensor of doubles with the
  * operand's declared shape (complex: {re, im} pairs); every value is converted exactly as Qu_s(double) does
- * (QuBLAS.h:2387-2393: the element type's own QuMode, then its OfMode) and packed in one pass. */
+ * (QuBLAS.h:2387-2393: the element type's own QuMode, then its OfMode) and packed in one pass.  An element type with
+ * QuMode<RND::CONV> is refused (QG_EUNSUPPORTED) unless the plan was created with QG_OPT_ARITHMETIC_CONV. */
 int qgemul_pack_f64(qgemul_plan* p, int operand, const double* src_dev, int64_t ld, void* packed_dev);
 /* packed C -> reference layout (device-resident), ready for one D2H copy */
 int qgemul_unpack_c(qgemul_plan* p, const void* packed_dev, void* dst_dev, int64_t ld);

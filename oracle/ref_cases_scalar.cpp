@@ -246,6 +246,26 @@ int main(int argc, char** argv)
         from_double_modes<SAT::SMGN>(out);
         from_double_modes<WRP::TCPL>(out);
         break;
+    case 6: {
+        // 32-bit edges of WRP::TCPL: the unsigned mask of exactly 32 value bits is ArbiInt<32>::allOnes() = -1
+        // in the reference, so nothing is masked; the signed 32-storage-bit target wraps through its int32 storage.
+        using s400 = Qu<intBits<40>, fracBits<0>>;
+        using u32w = Qu<intBits<32>, fracBits<0>, isSigned<false>, OfMode<WRP::TCPL>>;
+        using u1616w = Qu<intBits<16>, fracBits<16>, isSigned<false>, OfMode<WRP::TCPL>>;
+        using u31w = Qu<intBits<31>, fracBits<0>, isSigned<false>, OfMode<WRP::TCPL>>;
+        using u33w = Qu<intBits<33>, fracBits<0>, isSigned<false>, OfMode<WRP::TCPL>>;
+        using s31w = Qu<intBits<31>, fracBits<0>, isSigned<true>, OfMode<WRP::TCPL>>;
+        using s30w = Qu<intBits<30>, fracBits<0>, isSigned<true>, OfMode<WRP::TCPL>>;
+        const int64_t lo = -(1ll << 36), hi = (1ll << 36), step = (1ll << 27) + 12345;
+        cvt_table<s400, u32w>(out, lo, hi, step);
+        cvt_table<s400, u32w>(out, -16, 16);
+        cvt_table<s400, u1616w>(out, lo, hi, step);
+        cvt_table<s400, u31w>(out, lo, hi, step);
+        cvt_table<s400, u33w>(out, lo, hi, step);
+        cvt_table<s400, s31w>(out, lo, hi, step);
+        cvt_table<s400, s30w>(out, lo, hi, step);
+        break;
+    }
     default:
         return 2;
     }

@@ -15,7 +15,7 @@
 //
 // Besides the results, each case prints the fully RESOLVED formats of every node as the
 // reference's own types report them (T::intB, T::fracB, T::isS, T::QuM, T::OfM) — that pins the
-// descriptor lowering of include/qgemul_lower.hpp and qublas_amd/desc.py.
+// descriptor lowering of include/QuBLAS_amd.h / include/qgemul_reference_binding.hpp and qublas_amd/desc.py.
 #pragma once
 #include "QuBLAS.h"
 

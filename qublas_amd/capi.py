@@ -16,10 +16,13 @@ import numpy as np
 from .desc import (Qcomplex, Qu, host_layout, qgemul_desc, qgemul_ep_args, qgemul_epilogue, qgemul_info, qgemul_opts)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqugemm.so")
+# QUBLAS_AMD_DIAG=1 (tools/ only) loads the diagnostic build: environment A/B switches and ablation variants exist there and
+# nowhere else (qublas_amd/build.py).  Tests, smoke and bench load the product library.
+LIB_PATH = os.path.join(_HERE, "libqugemm_diag.so" if os.environ.get("QUBLAS_AMD_DIAG") == "1" else "libqugemm.so")
 
 QG_OK, QG_EINVAL, QG_EUNSUPPORTED, QG_EHIP, QG_ERCCL, QG_ERANGE, QG_ENOGPU = 0, -1, -2, -3, -4, -5, -6
 OPT_FORCE_TREE, OPT_CHECK_RANGE, OPT_GENERIC_TREE, OPT_RUNTIME_MODES, OPT_FUSED_EPILOGUE, OPT_UNFUSED_EPILOGUE = 1, 2, 4, 8, 16, 32
+OPT_GENERIC_LAYOUT, OPT_LOCKSTEP_TILES, OPT_ARITHMETIC_CONV = 64, 128, 256
 OPERAND_A, OPERAND_B, OPERAND_C = 0, 1, 2
 BITS_ASCII, BITS_PACKED = 0, 1
 KERNEL_NAMES = {0: "none", 1: "mfma_i8", 2: "mfma_i8_limb", 3: "tree_i32", 4: "tree_i64", 5: "tree_cplx", 6: "tree_cplx_i32", 7: "mfma_cplx", 8: "gemv_i32"}

@@ -31,6 +31,28 @@ struct qgemul_ctx {
     int* flag_dev;
 };
 
+// Every entry point that launches, allocates or frees runs on ITS context's device, whatever device the calling thread has
+// current, and leaves the caller's current device as it found it (one process may drive several GPUs: qgemul_run_sharded).
+struct DeviceScope {
+    int prev = -1;
+    bool changed = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int dev)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            changed = err == hipSuccess;
+        }
+    }
+    ~DeviceScope() { if (changed) hipSetDevice(prev); }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+#define QG_ON_DEVICE(ctxp)                 \
+    DeviceScope dev_scope_((ctxp)->device); \
+    QG_HIP(dev_scope_.err)
+
 struct qgemul_plan {
     qgemul_ctx* ctx;
     qgemul_desc desc;
@@ -113,7 +135,7 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
             if (lb2 > LB) LB = lb2;
         }
         const int mn = LA < LB ? LA : LB;
-        cfg = qg_mfma_pick(LA, LB, d->M * parts, d->N * parts);
+        cfg = qg_mfma_pick(LA, LB, d->M * parts, d->N * parts, (ep ? QG_OPT_LOCKSTEP_TILES : 0u) | flags);   // (the fused / unfused element-wise chain keeps the kernel it was measured on)
         if (cfg.variant && (int64_t)mn * d->K <= (1ll << 17) - 1)
             kernel = d->is_complex ? QG_KERNEL_MFMA_CPLX : ((LA == 1 && LB == 1) ? QG_KERNEL_MFMA_I8 : QG_KERNEL_MFMA_I8_LIMB);
         else {
@@ -168,7 +190,7 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     // Karatsuba (qg_mfma.hip, KARA): two-limb operands whose biased values fit 12 bits are stored as two unsigned base-64
     // digits each, and the product takes 3 MFMAs per k-step instead of 4
     {
-        static const bool no_kara = getenv("QG_NO_KARA") != nullptr;   // A/B switch
+        static const bool no_kara = QG_DIAG_ENV("QG_NO_KARA");   // A/B switch
         auto ubits = [](qfmt f) { return (int)f.I + (int)f.F + (f.S ? 1 : 0); };
         // (problems small enough for the 64x64 tiles are latency-bound: measured 9.5 vs 8.9 us at 1024^3, schoolbook kept there)
         if (!no_kara && !d->is_complex && LA == 2 && LB == 2 && (kernel == QG_KERNEL_MFMA_I8_LIMB) && cfg.variant == 3 && ubits(d->a[0]) <= 12 &&
@@ -237,6 +259,11 @@ static bool wide_epilogue(const qgemul_plan* p)
     return p->info.kernel == QG_KERNEL_MFMA_I8 && !q.identity && (q.W > 30 || (q.d < 0 && p->an.dot_bits - q.d > 31));
 }
 
+#ifdef QG_DIAG
+static uint32_t* g_diag_stamps = nullptr;   // device buffer for in-kernel clock stamps (diagnostic build only)
+extern "C" void qgemul_diag_set_stamps(void* dev) { g_diag_stamps = (uint32_t*)dev; }
+#endif
+
 static bool fuses_epilogue(const qgemul_plan* p)
 {
     if (wide_epilogue(p)) return false;
@@ -289,7 +316,8 @@ int qgemul_ctx_create(int device, qgemul_ctx** out)
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return QG_ENOGPU;
     if (device < 0) QG_HIP(hipGetDevice(&device));
     if (device >= n) return QG_EINVAL;
-    QG_HIP(hipSetDevice(device));
+    DeviceScope scope(device);   // the caller's current device is restored on return
+    QG_HIP(scope.err);
     hipDeviceProp_t prop;
     QG_HIP(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return QG_ENOGPU; // kernels exist for gfx950 only
@@ -306,7 +334,7 @@ int qgemul_ctx_create(int device, qgemul_ctx** out)
 void qgemul_ctx_destroy(qgemul_ctx* c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
+    DeviceScope scope(c->device);
     hipStreamSynchronize(c->stream);
     hipFree(c->flag_dev);
     hipStreamDestroy(c->stream);
@@ -316,6 +344,7 @@ void qgemul_ctx_destroy(qgemul_ctx* c)
 int qgemul_ctx_sync(qgemul_ctx* c)
 {
     if (!c) return QG_EINVAL;
+    QG_ON_DEVICE(c);
     QG_HIP(hipStreamSynchronize(c->stream));
     return QG_OK;
 }
@@ -325,13 +354,14 @@ void* qgemul_ctx_stream(qgemul_ctx* c) { return c ? (void*)c->stream : nullptr; 
 int qgemul_dev_alloc(qgemul_ctx* c, size_t bytes, void** out)
 {
     if (!c || !out) return QG_EINVAL;
-    QG_HIP(hipSetDevice(c->device));
+    QG_ON_DEVICE(c);
     QG_HIP(hipMalloc(out, bytes ? bytes : 16));
     return QG_OK;
 }
 int qgemul_dev_free(qgemul_ctx* c, void* p)
 {
     if (!c) return QG_EINVAL;
+    QG_ON_DEVICE(c);
     QG_HIP(hipStreamSynchronize(c->stream));
     QG_HIP(hipFree(p));
     return QG_OK;
@@ -340,6 +370,7 @@ int qgemul_memcpy_h2d(qgemul_ctx* c, void* dst, const void* src, size_t bytes)
 {
     if (!c) return QG_EINVAL;
     if (!bytes) return QG_OK;
+    QG_ON_DEVICE(c);
     QG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     QG_HIP(hipStreamSynchronize(c->stream));
     return QG_OK;
@@ -348,6 +379,7 @@ int qgemul_memcpy_d2h(qgemul_ctx* c, void* dst, const void* src, size_t bytes)
 {
     if (!c) return QG_EINVAL;
     if (!bytes) return QG_OK;
+    QG_ON_DEVICE(c);
     QG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     QG_HIP(hipStreamSynchronize(c->stream));
     return QG_OK;
@@ -372,7 +404,8 @@ int qgemul_plan_create_ep(qgemul_ctx* c, const qgemul_desc* d, const qgemul_epil
                            ep, &p->ept, &p->pc_c);
     if (st != QG_OK) { delete p; return st; }
     p->variant = p->cfg.variant;
-    if (hipSetDevice(c->device) != hipSuccess || hipMalloc((void**)&p->dev_table, sizeof(QTreeTable)) != hipSuccess) {
+    DeviceScope scope(c->device);
+    if (scope.err != hipSuccess || hipMalloc((void**)&p->dev_table, sizeof(QTreeTable)) != hipSuccess) {
         delete p;
         return QG_EHIP;
     }
@@ -414,6 +447,7 @@ int qgemul_plan_create_ep(qgemul_ctx* c, const qgemul_desc* d, const qgemul_epil
 void qgemul_plan_destroy(qgemul_plan* p)
 {
     if (!p) return;
+    DeviceScope scope(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
     hipFree(p->dev_table);
     hipFree(p->workspace);
@@ -463,11 +497,12 @@ static QOperandGeom operand_geom(const qgemul_plan* p, int operand, int64_t ld)
 int qgemul_pack(qgemul_plan* p, int operand, const void* src_dev, int64_t ld, void* packed_dev)
 {
     if (!p || !src_dev || !packed_dev || (operand != QG_OPERAND_A && operand != QG_OPERAND_B)) return QG_EINVAL;
+    QG_ON_DEVICE(p->ctx);
     QOperandGeom g = operand_geom(p, operand, ld);
     const QPackedGeom& pg = operand == QG_OPERAND_A ? p->pa : p->pb;
     const int check = (p->flags & QG_OPT_CHECK_RANGE) ? 1 : 0;
     if (check) QG_HIP(hipMemsetAsync(p->ctx->flag_dev, 0, 4, p->ctx->stream));
-    QG_HIP(qg_launch_pack(g, pg, src_dev, packed_dev, check, p->ctx->flag_dev, p->ctx->stream));
+    QG_HIP(qg_launch_pack(g, pg, src_dev, packed_dev, check, p->ctx->flag_dev, p->ctx->stream, (p->flags & QG_OPT_GENERIC_LAYOUT) ? 1 : 0));
     if (check) {
         int flag = 0;
         QG_HIP(hipMemcpyAsync(&flag, p->ctx->flag_dev, 4, hipMemcpyDeviceToHost, p->ctx->stream));
@@ -480,6 +515,14 @@ int qgemul_pack(qgemul_plan* p, int operand, const void* src_dev, int64_t ld, vo
 int qgemul_pack_f64(qgemul_plan* p, int operand, const double* src_dev, int64_t ld, void* packed_dev)
 {
     if (!p || !src_dev || !packed_dev || (operand != QG_OPERAND_A && operand != QG_OPERAND_B)) return QG_EINVAL;
+    if (!(p->flags & QG_OPT_ARITHMETIC_CONV)) {
+        // Qu_s(double) with QuMode<RND::CONV>: the reference's result is an artefact of its multi-word CONV branch
+        // (QuBLAS.h:2137-2156 on ArbiInt<2400>); silently returning the arithmetic answer would break bit-exactness
+        const qfmt* f = operand == QG_OPERAND_A ? p->desc.a : p->desc.b;
+        for (int q = 0; q < (p->desc.is_complex ? 2 : 1); ++q)
+            if (f[q].Q == QG_RND_CONV) return QG_EUNSUPPORTED;
+    }
+    QG_ON_DEVICE(p->ctx);
     QOperandGeom g = operand_geom(p, operand, ld);
     const QPackedGeom& pg = operand == QG_OPERAND_A ? p->pa : p->pb;
     QG_HIP(qg_launch_pack_f64(g, pg, src_dev, packed_dev, p->ctx->stream));
@@ -489,6 +532,7 @@ int qgemul_pack_f64(qgemul_plan* p, int operand, const double* src_dev, int64_t 
 int qgemul_fill_packed(qgemul_plan* p, int operand, uint64_t seed, int dist, void* packed_dev)
 {
     if (!p || !packed_dev || (operand != QG_OPERAND_A && operand != QG_OPERAND_B)) return QG_EINVAL;
+    QG_ON_DEVICE(p->ctx);
     QOperandGeom g = operand_geom(p, operand, 0);
     const QPackedGeom& pg = operand == QG_OPERAND_A ? p->pa : p->pb;
     QG_HIP(qg_launch_fill(g, pg, seed, dist, packed_dev, p->ctx->stream));
@@ -498,9 +542,10 @@ int qgemul_fill_packed(qgemul_plan* p, int operand, uint64_t seed, int dist, voi
 int qgemul_unpack_c(qgemul_plan* p, const void* packed_dev, void* dst_dev, int64_t ld)
 {
     if (!p || !packed_dev || !dst_dev) return QG_EINVAL;
+    QG_ON_DEVICE(p->ctx);
     QCGeom c = p->pc;
     c.ldc = ld ? ld : p->desc.M;
-    QG_HIP(qg_launch_unpack_c(c, packed_dev, dst_dev, p->ctx->stream));
+    QG_HIP(qg_launch_unpack_c(c, packed_dev, dst_dev, p->ctx->stream, (p->flags & QG_OPT_GENERIC_LAYOUT) ? 1 : 0));
     return QG_OK;
 }
 
@@ -511,6 +556,7 @@ int qgemul_execute(qgemul_plan* p, void* packedC, const void* packedA, const voi
     if (!p || !packedC || !packedA || !packedB) return QG_EINVAL;
     if (p->has_ep) return QG_EINVAL;  // a plan with an epilogue runs through qgemul_execute_ep
     if (p->desc.M == 0 || p->desc.N == 0) return QG_OK;
+    QG_ON_DEVICE(p->ctx);
     return execute_kernel(p, packedC, packedA, packedB, nullptr);
 }
 
@@ -522,6 +568,7 @@ int qgemul_execute_ep(qgemul_plan* p, void* packedD, const void* packedA, const 
     for (int k = 0; k < p->ept.n; ++k)
         if (!p->ept.st[k].scalar && !args->e_packed[k]) return QG_EINVAL;
     if (p->desc.M == 0 || p->desc.N == 0) return QG_OK;
+    QG_ON_DEVICE(p->ctx);
     QEpArgs a;
     memset(&a, 0, sizeof a);
     for (int k = 0; k < p->ept.n; ++k) {
@@ -577,6 +624,7 @@ int qgemul_pack_e(qgemul_plan* p, int stage, const void* src_dev, int64_t ld, vo
 {
     if (!p || !src_dev || !packed_dev || !p->has_ep || stage < 0 || stage >= p->ept.n || p->ept.st[stage].scalar) return QG_EINVAL;
     if (ld && ld < p->desc.M) return QG_EINVAL;
+    QG_ON_DEVICE(p->ctx);
     const qfmt f = p->ep.stage[stage].e;
     const int src_bytes = (1 + (int)f.I + (int)f.F) <= 32 ? 4 : 8;
     QG_HIP(qg_launch_pack_e(p->pc, src_dev, ld ? ld : p->desc.M, src_bytes, packed_dev, p->ept.st[stage].ebytes, p->ctx->stream));
@@ -603,6 +651,9 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
         a.to_c = p->an.lin.to_c[0];
         a.maskA = p->pa.trailer ? (const uint32_t*)((const char*)packedA + p->pa.trailer) : nullptr;
         a.maskB = p->pb.trailer ? (const uint32_t*)((const char*)packedB + p->pb.trailer) : nullptr;
+#ifdef QG_DIAG
+        a.dbg = g_diag_stamps;
+#endif
         if (p->pa.digit6) {
             a.kara = 1;
             a.rsA = (const int64_t*)((const char*)packedA + p->pa.rowsum_off);
@@ -718,6 +769,7 @@ int qgemul_export_bitstream(qgemul_plan* p, const void* packedC, int tensor_chun
     if (w <= 0 || tensor_chunk < 0 || elem_chunk < 0) return QG_EINVAL;
     if (elem_chunk > 0 && w % elem_chunk) return QG_EINVAL;      // the reference throws (QuBLAS.h:4599-4602)
     if (tensor_chunk > 0 && n % tensor_chunk) return QG_EINVAL;  // the reference's loop does not terminate (:4745)
+    QG_ON_DEVICE(p->ctx);
     QBitsArgs a;
     memset(&a, 0, sizeof a);
     a.c = p->pc;
@@ -735,6 +787,7 @@ static int time_execute(qgemul_plan* p, void* packedC, const void* packedA, cons
                         int warmup, int iters, float* avg_ms)
 {
     if (!p || !avg_ms || iters < 1) return QG_EINVAL;
+    QG_ON_DEVICE(p->ctx);
     hipStream_t st = p->ctx->stream;
     auto once = [&]() { return p->has_ep ? qgemul_execute_ep(p, packedC, packedA, packedB, args) : qgemul_execute(p, packedC, packedA, packedB); };
     for (int i = 0; i < warmup; ++i) {

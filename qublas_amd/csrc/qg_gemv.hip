@@ -328,12 +328,8 @@ hipError_t launch_gemv(const QGemvArgs& g, hipStream_t st)
     constexpr int IMG = 64 * (CH * 4 + 16);
     const int64_t nseg = g.K / (64 * CH);
     const int lds = IMG * ((nseg == 1 ? 1 : 0) + WAVES);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemv<CH, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, IMG * (1 + WAVES));
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};   // one bit per device
+    if (hipError_t e = qg_lds_attr((const void*)k_gemv<CH, MODE>, IMG * (1 + WAVES), attr_done); e != hipSuccess) return e;
     int64_t blocks = (g.M + WAVES - 1) / WAVES;
     if (blocks > 256 * 8) blocks = 256 * 8;   // rows beyond that are walked by the grid-stride loop
     hipLaunchKernelGGL((k_gemv<CH, MODE>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, st, g);
@@ -358,7 +354,11 @@ hipError_t qg_launch_gemv(const QTreeTable* dev_table, int n_levels, int b_is_bi
     // (64 leaves per lane were measured first: v[64] plus the 64 prefetch registers spill, 0.68 ms for 65536 x 4096)
     // leaves per lane: 16 measured best at 65536 x 4096 (0.277 ms, 3.9 TB/s; 32 leaves 0.48 ms: the prefetch registers
     // spill under the 128-register cap of 16 waves); QG_GEMV_CH overrides for A/B runs (tools/measure_reduce.py)
+#ifdef QG_DIAG
     static const int force_ch = getenv("QG_GEMV_CH") ? atoi(getenv("QG_GEMV_CH")) : 0;
+#else
+    constexpr int force_ch = 0;
+#endif
     const int ch = force_ch ? force_ch : 16;
     if (ch >= 32 && K >= 2048) return launch_gemv<32>(g, st);
     if (ch >= 16 && K >= 1024) return launch_gemv<16>(g, st);

@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <atomic>
 
 #include "qg_eltwise_args.h"
 #include "qg_plan.h"
@@ -60,12 +63,12 @@ __host__ __device__ inline int64_t qg_c_index(const QCGeom& c, int part, int64_t
 }
 
 hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const void* src, void* dst, int check_range,
-                          int* range_flag, hipStream_t st);
+                          int* range_flag, hipStream_t st, int generic = 0);   // generic: the any-format kernel even where a fast path exists
 // the same with a column-major tensor of DOUBLES as source (complex: {re, im} pairs), quantised on load with each
 // part's own QuMode / OfMode exactly as Qu_s(double) does (QuBLAS.h:2387-2393)
 hipError_t qg_launch_pack_f64(const QOperandGeom& g, const QPackedGeom& p, const void* src, void* dst, hipStream_t st);
 hipError_t qg_launch_fill(const QOperandGeom& g, const QPackedGeom& p, uint64_t seed, int dist, void* dst, hipStream_t st);
-hipError_t qg_launch_unpack_c(const QCGeom& c, const void* packed, void* dst, hipStream_t st);
+hipError_t qg_launch_unpack_c(const QCGeom& c, const void* packed, void* dst, hipStream_t st, int generic = 0);
 
 // complex linear class: combine the four raw dot-product blocks of D (tiled int64) into packed complex C [2][M][N]
 struct QCplxCombine {
@@ -104,7 +107,7 @@ struct QMfmaCfg {
     int variant;    // 0 = no kernel for this limb combination
     int TM, TN, BK; // output tile and k-tile (bytes) the packed operands are padded to
 };
-QMfmaCfg qg_mfma_pick(int LA, int LB, int64_t M, int64_t N);
+QMfmaCfg qg_mfma_pick(int LA, int LB, int64_t M, int64_t N, uint32_t opt_flags = 0);
 struct QMfmaArgs {
     const int8_t* A;  // [LA][Mp][Kp]
     const int8_t* B;  // [LB][Np][Kp]
@@ -121,10 +124,34 @@ struct QMfmaArgs {
     const uint32_t* maskA;  // plane masks of the packed operands (QPackedGeom::trailer); nullptr: all planes
     const uint32_t* maskB;
     int32_t has_ep, pad_;   // fused element-wise epilogue: C below is then packed D (ep.dbytes containers)
+    uint32_t* dbg;          // diagnostic build: in-kernel clock stamps (qg_mfma_pp.hip); nullptr otherwise
     QEpTable ep;
     QEpArgs epa;
 };
 hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st);
+// single limb, 256x256 tiles, 128-byte k-tiles, two wave groups alternating on the matrix cores (qg_mfma_pp.hip; variant 9)
+hipError_t qg_launch_mfma_pp(const QMfmaArgs& a, hipStream_t st);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is set once per DEVICE (one process may drive several: qgemul_run_sharded);
+// `done` holds one bit per device ordinal of the calling thread's current device
+inline hipError_t qg_lds_attr(const void* fn, int bytes, std::atomic<uint64_t>& done)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && ((done.load(std::memory_order_acquire) >> dev) & 1)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
+    return e;
+}
+
+// A/B and ablation switches read from the environment exist only in the diagnostic build (libqugemm_diag.so, -DQG_DIAG,
+// used by tools/); the product library ignores the environment altogether.
+#ifdef QG_DIAG
+#define QG_DIAG_ENV(name) (getenv(name) != nullptr)
+#else
+#define QG_DIAG_ENV(name) false
+#endif
 
 // element-wise epilogue as its own pass (kernels that do not fuse it) and the operand packer; see qg_eltwise.h
 hipError_t qg_launch_eltwise(const QEltwiseArgs& g, hipStream_t st);

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <utility>
 
 #include "qg_eltwise.h"
@@ -668,15 +669,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
 template <int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE, bool EP>
 void launch_plane_partner(const QMfmaArgs& a, hipStream_t st, int64_t blocks)
 {
-    static const bool no_partner = getenv("QG_NO_PLANE_MASK") != nullptr;   // A/B switch (tools/measure_masked.py); full-range data only!
+    static const bool no_partner = QG_DIAG_ENV("QG_NO_PLANE_MASK");   // A/B switch (tools/measure_masked.py); full-range data only!
     if (!(a.maskA || a.maskB) || no_partner) return;
     constexpr int TM = WGM * TI * 32, TN = WGN * TJ * 32;
     constexpr int lds2 = NSTAGE * (2 * TM + 2 * TN) * BK;
-    static bool attr_set2 = false;
-    if (!attr_set2) {
-        if (hipFuncSetAttribute((const void*)k_mfma<2, 2, BK, WGM, WGN, TI, TJ, NSTAGE, 0, EP, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2) != hipSuccess) return;
-        attr_set2 = true;
-    }
+    static std::atomic<uint64_t> attr_done2{0};
+    if (qg_lds_attr((const void*)k_mfma<2, 2, BK, WGM, WGN, TI, TJ, NSTAGE, 0, EP, 3, 3>, lds2, attr_done2) != hipSuccess) return;
     hipLaunchKernelGGL((k_mfma<2, 2, BK, WGM, WGN, TI, TJ, NSTAGE, 0, EP, 3, 3>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds2, st, a);
 }
 
@@ -684,7 +682,7 @@ template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF, bool EP =
 hipError_t launch16(const QMfmaArgs& a, hipStream_t st)
 {
     if constexpr (HINT && !EP) {
-        static const bool no_hint = getenv("QG_NO_HINT16") != nullptr;
+        static const bool no_hint = QG_DIAG_ENV("QG_NO_HINT16");
         if (no_hint && !a.has_ep) return launch16<LA, LB, WGM, WGN, TI, TJ, DBUF, false, false>(a, st);
     }
     if constexpr (!EP && (LA * LB == 1 || LA * LB == 9)) {
@@ -695,12 +693,8 @@ hipError_t launch16(const QMfmaArgs& a, hipStream_t st)
     if (a.has_ep && (!EP || !a.ep.bits32)) return hipErrorInvalidValue;
     constexpr int TM = WGM * TI * 16, TN = WGN * TJ * 16;
     const int lds = 3 * (LA * TM + LB * TN) * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF, EP, HINT, PV, SA, SB, KARA>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};   // one bit per device (qg_lds_attr)
+    if (hipError_t e = qg_lds_attr((const void*)k_mfma16<LA, LB, WGM, WGN, TI, TJ, DBUF, EP, HINT, PV, SA, SB, KARA>, lds, attr_done); e != hipSuccess) return e;
     const int64_t blocks = (a.Mp / TM) * (a.Np / TN);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll || a.Kp % 64 || a.Mp % TM || a.Np % TN) return hipErrorInvalidValue;
@@ -708,15 +702,11 @@ hipError_t launch16(const QMfmaArgs& a, hipStream_t st)
     if constexpr (LA == 3 && LB == 3 && SA == 3) {
         // the partner for operands whose third limb planes are empty: 2 x 2 limbs read from the 3-plane storage (each kernel
         // of the pair returns at once unless the plane masks select it)
-        static const bool no_partner = getenv("QG_NO_PLANE_MASK") != nullptr;   // A/B switch (tools/measure_masked.py); full-range data only!
+        static const bool no_partner = QG_DIAG_ENV("QG_NO_PLANE_MASK");   // A/B switch (tools/measure_masked.py); full-range data only!
         if ((a.maskA || a.maskB) && !no_partner) {
             constexpr int lds2 = 3 * (2 * TM + 2 * TN) * 64;
-            static bool attr_set2 = false;
-            if (!attr_set2) {
-                hipError_t e = hipFuncSetAttribute((const void*)k_mfma16<2, 2, WGM, WGN, TI, TJ, DBUF, EP, HINT, PV, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-                if (e != hipSuccess) return e;
-                attr_set2 = true;
-            }
+            static std::atomic<uint64_t> attr_done2{0};
+            if (hipError_t e = qg_lds_attr((const void*)k_mfma16<2, 2, WGM, WGN, TI, TJ, DBUF, EP, HINT, PV, 3, 3>, lds2, attr_done2); e != hipSuccess) return e;
             hipLaunchKernelGGL((k_mfma16<2, 2, WGM, WGN, TI, TJ, DBUF, EP, HINT, PV, 3, 3>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds2, st, a);
         }
     }
@@ -733,23 +723,15 @@ hipError_t launch(const QMfmaArgs& a, hipStream_t st)
     constexpr int TM = WGM * TI * 32, TN = WGN * TJ * 32;
     constexpr int STAGE = (LA * TM + LB * TN) * BK;
     const int lds = NSTAGE * STAGE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mfma<LA, LB, BK, WGM, WGN, TI, TJ, NSTAGE, ABL, EP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};   // one bit per device (qg_lds_attr)
+    if (hipError_t e = qg_lds_attr((const void*)k_mfma<LA, LB, BK, WGM, WGN, TI, TJ, NSTAGE, ABL, EP>, lds, attr_done); e != hipSuccess) return e;
     const int64_t blocks = (a.Mp / TM) * (a.Np / TN);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll || a.Kp % BK || a.Mp % TM || a.Np % TN) return hipErrorInvalidValue;
     if constexpr (LA == 2 && LB == 2 && ABL == 0 && !EP) {
         if (a.kara) {
-            static bool attr_set_k = false;
-            if (!attr_set_k) {
-                hipError_t e = hipFuncSetAttribute((const void*)k_mfma<2, 2, BK, WGM, WGN, TI, TJ, NSTAGE, 0, false, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                if (e != hipSuccess) return e;
-                attr_set_k = true;
-            }
+            static std::atomic<uint64_t> attr_done_k{0};
+            if (hipError_t e = qg_lds_attr((const void*)k_mfma<2, 2, BK, WGM, WGN, TI, TJ, NSTAGE, 0, false, 2, 2, true>, lds, attr_done_k); e != hipSuccess) return e;
             hipLaunchKernelGGL((k_mfma<2, 2, BK, WGM, WGN, TI, TJ, NSTAGE, 0, false, 2, 2, true>), dim3((unsigned)blocks), dim3(64 * WGM * WGN), lds, st, a);
             return hipGetLastError();
         }
@@ -762,51 +744,58 @@ hipError_t launch(const QMfmaArgs& a, hipStream_t st)
 
 } // namespace
 
-QMfmaCfg qg_mfma_pick(int LA, int LB, int64_t M, int64_t N)
+QMfmaCfg qg_mfma_pick(int LA, int LB, int64_t M, int64_t N, uint32_t opt_flags)
 {
     QMfmaCfg c = {0, 0, 0, 0};
     if (LA < 1 || LB < 1 || LA > 3 || LB > 3) return c;
     if (LA == 1 && LB == 1) {
         // 256x256 tiles halve the L2->LDS traffic per MAC; use them once they fill the 256 CUs
         const int64_t big = ((M + 255) / 256) * ((N + 255) / 256);
-        if (big >= 256) return QMfmaCfg{2, 256, 256, 64};
+        // two wave groups alternating on the matrix cores, 128-byte k-tiles (qg_mfma_pp.hip); QG_OPT_LOCKSTEP_TILES keeps k_mfma16
+        if (big >= 256) return (opt_flags & QG_OPT_LOCKSTEP_TILES) ? QMfmaCfg{2, 256, 256, 64} : QMfmaCfg{9, 256, 256, 128};
         // small problems: 64x64 tiles once 128x128 ones would leave more than half of the 256 CUs without a workgroup
         // (1024^2: 64 -> 256 workgroups)
         const int64_t mid = ((M + 127) / 128) * ((N + 127) / 128);
-        static const bool no_small = getenv("QG_NO_SMALL_TILES") != nullptr;   // A/B switch for tools/measure_small.py
+        static const bool no_small = QG_DIAG_ENV("QG_NO_SMALL_TILES");   // A/B switch for tools/measure_small.py
         if (!no_small && mid <= 128 && ((M + 63) / 64) * ((N + 63) / 64) > mid) {
             // 128-byte k-tiles: these launches are bound by the per-k-tile barrier, DMA issue and exposed fragment reads of a
             // one-wave-per-SIMD workgroup (~0.2 us per 64-byte k-tile whatever the ring depth), so half as many k-tiles:
             // 1024^3 5.97 -> 5.35 us, 512^2 x 4096 13.3 -> 10.2 us (profiles/r03n_small_ring.jsonl).  QG_BK64 for A/B.
-            static const bool bk64 = getenv("QG_BK64") != nullptr;
+            static const bool bk64 = QG_DIAG_ENV("QG_BK64");
             return bk64 ? QMfmaCfg{5, 64, 64, 64} : QMfmaCfg{7, 64, 64, 128};
         }
         {   // at most one workgroup per CU: 128-byte k-tiles here as well (2048^2 x 8192 55.3 -> 44.8 us, 1792^2 x 4096 30.8 -> 24.4 us,
             // 2048^3 15.3 -> 15.2 us); with more workgroups the 96 KB LDS image would cost co-residency.  QG_BK64 for A/B.
-            static const bool bk64 = getenv("QG_BK64") != nullptr;
+            static const bool bk64 = QG_DIAG_ENV("QG_BK64");
             if (!bk64 && mid <= 256) return QMfmaCfg{8, 128, 128, 128};
         }
         return QMfmaCfg{1, 128, 128, 64};
     }
     {   // limb kernels: the same small-problem rule (1024^2 outputs: 64 -> 256 workgroups)
-        static const bool no_small = getenv("QG_NO_SMALL_TILES") != nullptr;
+        static const bool no_small = QG_DIAG_ENV("QG_NO_SMALL_TILES");
         const int64_t mid = ((M + 127) / 128) * ((N + 127) / 128);
         if (!no_small && mid <= 128 && ((M + 63) / 64) * ((N + 63) / 64) > mid) return QMfmaCfg{6, 64, 64, 64};
     }
     return QMfmaCfg{3, 128, 128, 64};
 }
 
-// QG_ABLATE=1..5 selects diagnostic variants of the two benchmarked kernels (results are WRONG by
-// construction; used only by tools/ablate.py to price the phases of the loop)
+// QG_ABLATE=1..5 selects diagnostic variants of the two benchmarked kernels (results are WRONG by construction; used only
+// by tools/ablate.py to price the phases of the loop).  They exist in the diagnostic build only (libqugemm_diag.so, -DQG_DIAG):
+// the product library neither reads the variable nor contains the variants.
+#ifdef QG_DIAG
 static int ablation()
 {
     static int v = -1;
     if (v < 0) { const char* e = getenv("QG_ABLATE"); v = e ? atoi(e) : 0; }
     return v;
 }
+#else
+static constexpr int ablation() { return 0; }
+#endif
 
 hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
 {
+#ifdef QG_DIAG
     if (const int abl = ablation(); abl > 0 && abl < 16) {
         if (LA == 3 && LB == 3 && a.variant == 3) {   // (the diagnostic variants exist for the 128x128-tile geometry only)
             switch (abl) {
@@ -830,15 +819,19 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
             }
         }
     }
+#endif
     if (LA == 1 && LB == 1) {
         // single limb: v_mfma_i32_16x16x64_i8 measured 8 % faster than 32x32x32 at the same tiles
         // (0.283 vs 0.308 ms at 8192x8192x4096, profiles/r01n_ablation_mfma_shape.log); QG_ABLATE=32 keeps the other
+        if (a.variant == 9) return a.has_ep ? hipErrorInvalidValue : qg_launch_mfma_pp(a, st);
         if (a.variant == 5) return launch<1, 1, 64, 2, 2, 1, 1, 3>(a, st);   // 64x64 tiles, one 32x32 MFMA tile per wave
         if (a.variant == 7) return launch<1, 1, 128, 2, 2, 1, 1, 3>(a, st);   // the same on 128-byte k-tiles
         if (a.variant == 8) return launch<1, 1, 128, 2, 2, 2, 2, 3>(a, st);   // 128x128 tiles on 128-byte k-tiles
+#ifdef QG_DIAG
         if (ablation() == 32) return a.variant == 2 ? launch<1, 1, 64, 2, 4, 4, 2, 3>(a, st) : launch<1, 1, 64, 2, 2, 2, 2, 3>(a, st);
+#endif
         if (a.variant == 2) {
-            static const bool shallow = getenv("QG_NO_DEEP") != nullptr;   // A/B: one k-tile in flight instead of two
+            static const bool shallow = QG_DIAG_ENV("QG_NO_DEEP");   // A/B: one k-tile in flight instead of two
             if (shallow && !a.has_ep) return launch16<1, 1, 2, 4, 8, 4, true, false, true, 0>(a, st);
             return launch16<1, 1, 2, 4, 8, 4, true>(a, st);
         }
@@ -849,7 +842,7 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
         // cycles, less than one trip to L2).  512^2 x 4096 int<8,8>: 39.8 -> 27.9 us; with more workgroups than CUs the ring's LDS
         // would cost co-residency (1536 x 1024 x 1024: 21.2 -> 24.4 us), and the single-limb 64x64 kernel gained nothing from it
         // (its k-tile is bound by the dependent MFMA pair and the barrier).  QG_STAGES3 keeps three stages (A/B).
-        static const bool three = getenv("QG_STAGES3") != nullptr;
+        static const bool three = QG_DIAG_ENV("QG_STAGES3");
         if (!three) switch (LA * 10 + LB) {
             case 22: return launch<2, 2, 64, 2, 2, 1, 1, 5>(a, st);
             case 23: return launch<2, 3, 64, 2, 2, 1, 1, 5>(a, st);
@@ -872,7 +865,7 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
         }
     }
     if (a.variant == 3 && a.kara && LA == 2 && LB == 2 && !a.has_ep) {
-        static const bool kara32 = getenv("QG_KARA32") != nullptr;   // A/B: the Karatsuba kernel on 32x32x32
+        static const bool kara32 = QG_DIAG_ENV("QG_KARA32");   // A/B: the Karatsuba kernel on 32x32x32
         if (!kara32) return launch16<2, 2, 2, 4, 4, 2, false, false, true, 1, 2, 2, true>(a, st);
     }
     if (a.variant == 3 && !a.kara) {
@@ -880,10 +873,10 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st)
         // 32x32x32 (k_mfma) at 4096^3, same box, ms: 3x3 0.388 / 0.427, 2x3 0.290 / 0.329, 3x2 0.295 / 0.332, 2x2 0.221 / 0.232,
         // 1x3 0.194 / 0.199, 3x1 0.200 / 0.206, 1x2 0.128 / 0.176, 2x1 0.130 / 0.178 (the chip holds a higher clock on the
         // small shape; profiles/r03j_limb_shapes.log, r03k_pipeline.log).  QG_LIMB32 keeps 32x32x32 everywhere (A/B).
-        static const bool limb32 = getenv("QG_LIMB32") != nullptr;
+        static const bool limb32 = QG_DIAG_ENV("QG_LIMB32");
         if (!limb32) switch (LA * 10 + LB) {
             case 33: {
-                static const bool spread = getenv("QG_DMA_SPREAD") != nullptr;   // A/B: LDS-DMA issues over all four row steps
+                static const bool spread = QG_DIAG_ENV("QG_DMA_SPREAD");   // A/B: LDS-DMA issues over all four row steps
                 if (spread && !a.has_ep) return launch16<3, 3, 2, 4, 4, 2, false, false, true, 0>(a, st);
                 return launch16<3, 3, 2, 4, 4, 2, false>(a, st);
             }

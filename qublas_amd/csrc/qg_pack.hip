@@ -354,13 +354,13 @@ static hipError_t zero_trailer(const QPackedGeom& p, void* dst, hipStream_t st)
 }
 
 hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const void* src, void* dst, int check_range,
-                          int* range_flag, hipStream_t st)
+                          int* range_flag, hipStream_t st, int generic)
 {
     int64_t blocks = ((p.K_p + 63) / 64) * ((p.rows_p + 63) / 64) * g.parts;
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
     if (hipError_t e = zero_trailer(p, dst, st); e != hipSuccess) return e;
-    static const bool no_fast = getenv("QG_NO_FAST_PACK") != nullptr;   // A/B and the equivalence test
+    const bool no_fast = generic != 0;   // QG_OPT_GENERIC_LAYOUT: the any-format kernel (byte-identical; the equivalence test)
     if (!no_fast && g.parts == 1 && g.elem_bytes == 4 && g.sb[0] == 4 && g.off[0] == 0 && p.limbs >= 1 && p.limbs <= 3 && !p.digit6 && (p.bk == 64 || p.bk == 128) &&
         p.tr % 64 == 0 && p.rows_p % p.tr == 0 && p.K_p % p.bk == 0 && g.W[0] <= 30 && ((uintptr_t)src & 3) == 0 && ((uintptr_t)dst & 15) == 0) {
         const unsigned nb = (unsigned)((p.K_p / 64) * (p.rows_p / 64));
@@ -394,12 +394,12 @@ hipError_t qg_launch_fill(const QOperandGeom& g, const QPackedGeom& p, uint64_t 
     return hipGetLastError();
 }
 
-hipError_t qg_launch_unpack_c(const QCGeom& c, const void* packed, void* dst, hipStream_t st)
+hipError_t qg_launch_unpack_c(const QCGeom& c, const void* packed, void* dst, hipStream_t st, int generic)
 {
     int64_t blocks = ((c.N + 63) / 64) * ((c.M + 63) / 64) * c.parts;
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
-    static const bool no_fast = getenv("QG_NO_FAST_PACK") != nullptr;
+    const bool no_fast = generic != 0;
     if (!no_fast && c.parts == 1 && c.cbytes == 4 && c.elem_bytes == 4 && c.sb[0] == 4 && c.off[0] == 0 && c.tm > 0 && c.tm % 4 == 0 &&
         ((uintptr_t)packed & 15) == 0 && ((uintptr_t)dst & 3) == 0) {
         const int vec = (c.ldc % 4 == 0) && (((uintptr_t)dst & 15) == 0);

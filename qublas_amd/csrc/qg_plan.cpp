@@ -90,6 +90,13 @@ Rng through(Ctx& c, Rng in, int fromF, qfmt to, bool identity)
     c.note(in);
     c.raw_product = false;
     if (identity) return in;
+    // Converting INTO an unsigned WRP::TCPL format of exactly 32 value bits: the reference's mask is ArbiInt<32>::allOnes(),
+    // whose data is -1 (QuBLAS.h:361-377), so `val & mask` (:2328-2331) masks nothing and the value is stored unwrapped in
+    // the 33-bit storage (-7 -> -7, 2^33 + 5 -> 2^33 + 5; pinned by tests/golden ref_scalar cvt tables).  An artefact of
+    // the same family as the d = 32 RND case below: rejected, not imitated.  (Signed, 32 storage bits: the reference's
+    // int32 storage wraps by itself and agrees with the arithmetic definition.)
+    if (to.O == QG_WRP_TCPL && !to.S && (int)to.I + (int)to.F == 32)
+        c.fail(QG_EUNSUPPORTED, "unsigned WRP::TCPL into exactly 32 bits: reference result is an ArbiInt<32>::allOnes artefact");
     int d = fromF - (int)to.F;
     Rng r = in;
     if (d <= 0) {

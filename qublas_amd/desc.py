@@ -1,4 +1,4 @@
-"""Descriptor lowering in Python — a mirror of include/qgemul_lower.hpp used by the tests and the
+"""Descriptor lowering in Python — a mirror of the lowering in include/QuBLAS_amd.h and include/qgemul_reference_binding.hpp, used by the tests and the
 benchmark harness to build `qgemul_desc` structures (include/qgemul.h) without a C++ compile.
 
 It restates the reference's compile-time result-type rules:

@@ -44,7 +44,7 @@ def main():
             x = awkward_doubles(nrng, max(M * K, 64), 2.0 ** rng.randint(-4, 12))[:M * K].copy()
             d = lower(e, ONE, e, M, K, K, mul_args=e, add_args=[e])
             if capi.classify_status(d)[0] == capi.QG_OK:
-                plan = capi.Plan(ctx, d)
+                plan = capi.Plan(ctx, d, capi.OPT_ARITHMETIC_CONV)   # (RND::CONV elements: the arithmetic definition, include/qgemul.h)
                 pb = plan.info.packed_bytes
                 pA, pB, pC = ctx.alloc(pb[0]), ctx.alloc(pb[1]), ctx.alloc(pb[2])
                 dX = ctx.alloc(x.nbytes)

@@ -77,6 +77,15 @@ def test_rejections():
     d = lower(Qu(30, 30), Qu(1, 0), Qu(6, -2, QuMode=4), 4, 4, 4, mul_args=Qu(31, 30))
     st, info = capi.classify_status(d)
     assert st == capi.QG_EUNSUPPORTED, info.reason
+    # converting into an unsigned WRP::TCPL format of exactly 32 value bits: another ArbiInt<32>::allOnes artefact
+    # (tests/test_oracle_golden.py::test_wrap_into_32_bits_is_a_reference_artefact_only_for_unsigned) ...
+    for c in (Qu(32, 0, False, OfMode=3), Qu(16, 16, False, OfMode=3)):
+        st, info = capi.classify_status(lower(e, e, c, 4, 4, 4))
+        assert st == capi.QG_EUNSUPPORTED, info.reason
+    # ... and only that: 31 / 33 unsigned bits and the signed 32-storage-bit format wrap arithmetically in the reference too
+    for c in (Qu(31, 0, False, OfMode=3), Qu(33, 0, False, OfMode=3), Qu(31, 0, True, OfMode=3), Qu(32, 0, False, OfMode=0)):
+        st, info = capi.classify_status(lower(e, e, c, 4, 4, 4))
+        assert st == capi.QG_OK, info.reason
     # wider than 62 bits
     d = lower(Qu(30, 30), Qu(30, 30), Qu(8, 8), 4, 4, 4, mul_args=Qu(60, 60))
     st, _ = capi.classify_status(d)

@@ -39,13 +39,22 @@ def test_pack_f64_then_gemm(oracle, ea, eb, ta):
     Ai = quantize(oracle, ea, Ad).astype(oracle.host_dtype(ea))
     Bi = quantize(oracle, eb, Bd).astype(oracle.host_dtype(eb))
     exp = oracle.gemm(d, Ai, Bi, ec)
+    conv = RND.CONV in (ea.QuMode, eb.QuMode)
     with capi.Context() as ctx:
-        plan = capi.Plan(ctx, d)
+        # an RND::CONV element type: the arithmetic conversion only on request (QG_OPT_ARITHMETIC_CONV); by default the
+        # pack is refused, because the reference's double construction under CONV is an artefact the engine does not imitate
+        plan = capi.Plan(ctx, d, capi.OPT_ARITHMETIC_CONV if conv else 0)
         pb = plan.info.packed_bytes
         pA, pB, pC = ctx.alloc(pb[0]), ctx.alloc(pb[1]), ctx.alloc(pb[2])
         dA, dB, dC = ctx.alloc(Ad.nbytes), ctx.alloc(Bd.nbytes), ctx.alloc(M * N * 4)
         ctx.h2d(dA, Ad)
         ctx.h2d(dB, Bd)
+        if conv:
+            gated = capi.Plan(ctx, d)
+            with pytest.raises(capi.QgemulError) as ei:
+                gated.pack_f64(capi.OPERAND_A if ea.QuMode == RND.CONV else capi.OPERAND_B, dA if ea.QuMode == RND.CONV else dB, pA)
+            assert ei.value.status == capi.QG_EUNSUPPORTED
+            gated.close()
         plan.pack_f64(capi.OPERAND_A, dA, pA)
         plan.pack_f64(capi.OPERAND_B, dB, pB)
         plan.execute(pC, pA, pB)

@@ -50,6 +50,30 @@ def test_convert_truth_tables(oracle, part):
     assert n > 10000
 
 
+def test_wrap_into_32_bits_is_a_reference_artefact_only_for_unsigned(oracle):
+    """tests/golden/ref_scalar_6: WRP::TCPL targets around 32 bits, produced by the reference.  Unsigned targets of EXACTLY 32
+    value bits come back unwrapped (the mask is ArbiInt<32>::allOnes() = -1, QuBLAS.h:361-377, :2328-2331): the engine rejects
+    such conversions (qg_plan.cpp, tests/test_cabi_cpu.py::test_rejections) and the oracle keeps the arithmetic definition.
+    Every other width, and the signed 32-storage-bit target, agree with the oracle value for value."""
+    L = oracle.lib()
+    seen_artefact = seen_plain = 0
+    for t in G.scalar_tables(6):
+        src, dst = Qu.from_tuple(t["from"]), Qu.from_tuple(t["to"])
+        xs = range(t["lo"], t["hi"] + 1, t["step"])
+        assert len(xs) == len(t["y"])
+        artefact = (not dst.isSigned) and dst.intBits + dst.fracBits == 32
+        for x, y in zip(xs, t["y"]):
+            got = L.qoracle_convert(x, src.c(), dst.c())
+            if artefact:
+                assert y == x << (dst.fracBits - src.fracBits)            # the reference stores the value unwrapped
+                assert got == y % (1 << 32)                               # the oracle wraps
+                seen_artefact += got != y
+            else:
+                assert got == y, (t["from"], t["to"], x)
+                seen_plain += 1
+    assert seen_artefact > 100 and seen_plain > 1000
+
+
 def test_mul_add_truth_tables(oracle):
     L = oracle.lib()
     kinds = set()

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Single-limb linear class, large problems: k_mfma_pp (two wave groups alternating on the matrix cores, 128-byte k-tiles)
+against k_mfma16 (lock-step waves, 64-byte k-tiles; QG_OPT_LOCKSTEP_TILES) in ONE process, interleaved rounds, HIP events on
+the engine's stream.  One JSON line per (shape, kernel) with mean / median / min over the rounds.  Needs an MI355X."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from qublas_amd import capi  # noqa: E402
+from qublas_amd.desc import Qu, Tags, lower  # noqa: E402
+
+E43 = Qu(4, 3)
+PEAK = 5.0e15
+SHAPES = [(16384, 16384, 4096), (2048, 16384, 4096), (8192, 8192, 4096), (4096, 4096, 4096), (16384, 16384, 2048), (16384, 16384, 1024), (16384, 16384, 512)]
+
+
+def main():
+    rounds = int(os.environ.get("ROUNDS", "7"))
+    iters = int(os.environ.get("ITERS", "20"))
+    only = os.environ.get("ONLY")
+    with capi.Context(0) as ctx:
+        for M, N, K in SHAPES:
+            if only and only != f"{M}x{N}x{K}":
+                continue
+            d = lower(E43, E43, E43, M, N, K, mul_args=Tags(9, 6), add_args=[Qu(21, 6)])
+            arms = []
+            arm_list = [("pp", 0, None), ("lockstep", capi.OPT_LOCKSTEP_TILES, None)]
+            if os.environ.get("QUBLAS_AMD_DIAG") == "1":   # diagnostic library: the launch-per-tile form of the same kernel, start staggers
+                arm_list.insert(1, ("pp_launch_per_tile", 0, ("QG_PP_LAUNCH_PER_TILE", "1")))
+                for sv in os.environ.get("TAILS", "").split():
+                    arm_list.append((f"pp_tail_{sv}", 0, ("QG_PP_TAIL", sv)))
+            for name, flags, envname in arm_list:
+                plan = capi.Plan(ctx, d, flags)
+                pb = plan.info.packed_bytes
+                pA, pB, pC = ctx.alloc(pb[0]), ctx.alloc(pb[1]), ctx.alloc(pb[2])
+                plan.fill(capi.OPERAND_A, 1, 0, pA)
+                plan.fill(capi.OPERAND_B, 2, 0, pB)
+                arms.append((name, plan, pA, pB, pC, [], envname))
+            def timed(arm, warm, it):
+                if arm[6]:
+                    os.environ[arm[6][0]] = arm[6][1]
+                try:
+                    return arm[1].time_execute(arm[4], arm[2], arm[3], warm, it)
+                finally:
+                    if arm[6]:
+                        del os.environ[arm[6][0]]
+            for arm in arms:
+                timed(arm, 5, 5)
+            for _ in range(rounds):
+                for arm in arms:
+                    arm[5].append(timed(arm, 1, iters))
+            for name, plan, pA, pB, pC, ts, _e in arms:
+                s = sorted(ts)
+                ops = 2.0 * M * N * K
+                med = s[len(s) // 2]
+                print(json.dumps({"shape": [M, N, K], "kernel": name, "ms_mean": sum(s) / len(s), "ms_median": med, "ms_min": s[0],
+                                  "pct_int8_peak_median": 100.0 * ops / (med * 1e-3) / PEAK, "rounds": rounds, "iters": iters}), flush=True)
+                for p in (pA, pB, pC):
+                    ctx.free(p)
+                plan.close()
+
+
+if __name__ == "__main__":
+    main()
