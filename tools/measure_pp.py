@@ -13,7 +13,9 @@ from qublas_amd import capi  # noqa: E402
 from qublas_amd.desc import Qu, Tags, lower  # noqa: E402
 
 E43 = Qu(4, 3)
+E88 = Qu(8, 8, True, 5, 1)   # TRN::TCPL, SAT::ZERO
 PEAK = 5.0e15
+LIMB_SHAPES = [(4096, 4096, 4096), (8192, 8192, 4096), (4096, 4096, 2048), (4096, 4096, 1024), (4096, 4096, 8192), (2048, 2048, 4096)]
 SHAPES = [(16384, 16384, 4096), (2048, 16384, 4096), (8192, 8192, 4096), (4096, 4096, 4096), (16384, 16384, 2048), (16384, 16384, 1024), (16384, 16384, 512)]
 
 
@@ -22,10 +24,14 @@ def main():
     iters = int(os.environ.get("ITERS", "20"))
     only = os.environ.get("ONLY")
     with capi.Context(0) as ctx:
-        for M, N, K in SHAPES:
+        limb = os.environ.get("WL") == "limb"   # the 3 x 3-limb kernels (configuration 3's operands) instead of the single-limb ones
+        for M, N, K in (LIMB_SHAPES if limb else SHAPES):
             if only and only != f"{M}x{N}x{K}":
                 continue
-            d = lower(E43, E43, E43, M, N, K, mul_args=Tags(9, 6), add_args=[Qu(21, 6)])
+            if limb:
+                d = lower(E88, E88, Qu(23, 8), M, N, K, mul_args=Tags(17, 16), add_args=[Qu(30, 16)])
+            else:
+                d = lower(E43, E43, E43, M, N, K, mul_args=Tags(9, 6), add_args=[Qu(21, 6)])
             arms = []
             arm_list = [("pp", 0, None), ("lockstep", capi.OPT_LOCKSTEP_TILES, None)]
             if os.environ.get("QUBLAS_AMD_DIAG") == "1":   # diagnostic library: the launch-per-tile form of the same kernel, start staggers
