@@ -145,6 +145,8 @@ enum {
      * default such a pack is REJECTED (QG_EUNSUPPORTED).  With this flag the engine converts with the arithmetic definition
      * of RND::CONV (round half to even) — what the <= 62-bit conversions on the Qgemul path do and the reference pins. */
     QG_OPT_ARITHMETIC_CONV = 256u,
+    /* qgemul_run: shard the rows of C over every gfx950 device this process can see (qgemul_run_sharded with all of them) */
+    QG_OPT_ALL_DEVICES = 512u,
     QG_OPT_LOCKSTEP_TILES = 128u   /* large single-limb problems: the 64-byte-k-tile kernel whose waves run in lock step
                                     * (k_mfma16) instead of the two-group kernel on 128-byte k-tiles (k_mfma_pp) */
 };
@@ -307,6 +309,17 @@ int qgemul_time_execute_ep(qgemul_plan* p, void* packedD, const void* packedA, c
  * one scalar element; D (ldc from opts) is fully overwritten */
 int qgemul_run_ep(const qgemul_desc* d, const qgemul_epilogue* ep, void* D, const void* A, const void* B,
                   const void* const* E, const qgemul_opts* o);
+
+/* ---- several GPUs in one process ----
+ * The M x N outputs are independent: device i computes a band of whole 256-row blocks of C from the matching rows of A' and
+ * all of B (replicated); the packed C bands travel to devices[0] with peer copies (over xGMI where the devices are linked),
+ * are unpacked there into ONE host-layout C and copied back — no other exchange step.  Same arguments, layouts, status
+ * codes and per-thread caching as qgemul_run (one context, plan and set of grow-only buffers per device of the list;
+ * qgemul_run_release() frees them); opts->device is ignored.  A device may appear more than once in the list (two contexts
+ * on one card: how the partition / reassembly logic is tested on a one-GPU box).  n <= 16.  Real and complex, any class.
+ * (Multi-PROCESS sharding — one rank per GPU, RCCL gather — is qublas_amd/dist.py and bench.py; QG_ERCCL is reserved for a
+ * library-owned RCCL transport and is not returned by this version.) */
+int qgemul_run_sharded(const qgemul_desc* d, void* C, const void* A, const void* B, const qgemul_opts* o, const int* devices, int n);
 
 /* ---- BitStream export of the result tensor ----
  * What  BitStream<tensorProcessT, elemProcessT>(C)  returns in the reference (QuBLAS.h:4811-4827; demo main.cpp:9-18):

@@ -177,12 +177,26 @@ qgemul_desc Qgemul_lower(const TC&, const TA&, const TB&)
     return Qgemul_lower_types<Tags...>(std::type_identity<TC>{}, std::type_identity<TA>{}, std::type_identity<TB>{});
 }
 
+// Options of the one-shot calls below, per translation unit (QG_OPT_* of qgemul.h).  Several GPUs in one process:
+//     QgemulRunFlags() |= QG_OPT_ALL_DEVICES;     // every Qgemul<...>(C, A, B) is row-sharded over all visible gfx950 devices
+// QgemulRelease() frees what the library caches for the calling thread (context, plan, device buffers); the library also does
+// it when the thread exits.
+inline uint32_t& QgemulRunFlags()
+{
+    static uint32_t flags = 0;
+    return flags;
+}
+inline void QgemulRelease() { qgemul_run_release(); }
+
 // the README entry point: C = A' * B with per-product and per-tree-node quantisation
 template <typename... Tags, class TC, class TA, class TB>
 void Qgemul(TC& C, const TA& A, const TB& B)
 {
     const qgemul_desc d = Qgemul_lower<Tags...>(C, A, B);
-    const int st = qgemul_run(&d, C.data.data(), A.data.data(), B.data.data(), nullptr);
+    qgemul_opts opts{};
+    opts.device = -1;
+    opts.flags = QgemulRunFlags();
+    const int st = qgemul_run(&d, C.data.data(), A.data.data(), B.data.data(), &opts);
     if (st != QG_OK) throw std::runtime_error(std::string("Qgemul: ") + qgemul_strerror(st));
 }
 

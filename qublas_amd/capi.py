@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libqugemm_diag.so" if os.environ.get("QUBLAS_AMD
 
 QG_OK, QG_EINVAL, QG_EUNSUPPORTED, QG_EHIP, QG_ERCCL, QG_ERANGE, QG_ENOGPU = 0, -1, -2, -3, -4, -5, -6
 OPT_FORCE_TREE, OPT_CHECK_RANGE, OPT_GENERIC_TREE, OPT_RUNTIME_MODES, OPT_FUSED_EPILOGUE, OPT_UNFUSED_EPILOGUE = 1, 2, 4, 8, 16, 32
-OPT_GENERIC_LAYOUT, OPT_LOCKSTEP_TILES, OPT_ARITHMETIC_CONV = 64, 128, 256
+OPT_GENERIC_LAYOUT, OPT_LOCKSTEP_TILES, OPT_ARITHMETIC_CONV, OPT_ALL_DEVICES = 64, 128, 256, 512
 OPERAND_A, OPERAND_B, OPERAND_C = 0, 1, 2
 BITS_ASCII, BITS_PACKED = 0, 1
 KERNEL_NAMES = {0: "none", 1: "mfma_i8", 2: "mfma_i8_limb", 3: "tree_i32", 4: "tree_i64", 5: "tree_cplx", 6: "tree_cplx_i32", 7: "mfma_cplx", 8: "gemv_i32"}
@@ -35,7 +35,7 @@ EXPORTS = [
     "qgemul_pack", "qgemul_pack_f64", "qgemul_unpack_c", "qgemul_execute", "qgemul_fill_packed", "qgemul_time_execute",
     "qgemul_classify_ep", "qgemul_plan_create_ep", "qgemul_packed_e_bytes", "qgemul_pack_e", "qgemul_execute_ep",
     "qgemul_time_execute_ep", "qgemul_run_ep", "qgemul_plan_fuses_epilogue",
-    "qgemul_bitstream_bytes", "qgemul_export_bitstream", "qgemul_run_release",
+    "qgemul_bitstream_bytes", "qgemul_export_bitstream", "qgemul_run_release", "qgemul_run_sharded",
 ]
 
 _lib = None
@@ -155,6 +155,21 @@ def run(desc: qgemul_desc, C_out: np.ndarray, A: np.ndarray, B: np.ndarray, *, l
     o = qgemul_opts(lda, ldb, ldc, device, flags)
     _chk(lib().qgemul_run(C.byref(desc), C_out.ctypes.data_as(C.c_void_p), A.ctypes.data_as(C.c_void_p),
                           B.ctypes.data_as(C.c_void_p), C.byref(o)), "qgemul_run")
+    return C_out
+
+
+def run_sharded(desc: qgemul_desc, C_out: np.ndarray, A: np.ndarray, B: np.ndarray, devices, *, lda: int = 0, ldb: int = 0,
+                ldc: int = 0, flags: int = 0) -> np.ndarray:
+    """qgemul_run_sharded: one process, the rows of C in bands over `devices` (an ordinal may repeat)."""
+    A = np.ascontiguousarray(A)
+    B = np.ascontiguousarray(B)
+    assert C_out.flags["C_CONTIGUOUS"]
+    o = qgemul_opts(lda, ldb, ldc, -1, flags)
+    devs = (C.c_int * len(devices))(*devices)
+    L = lib()
+    L.qgemul_run_sharded.argtypes = [C.POINTER(qgemul_desc), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(qgemul_opts), C.POINTER(C.c_int), C.c_int]
+    _chk(L.qgemul_run_sharded(C.byref(desc), C_out.ctypes.data_as(C.c_void_p), A.ctypes.data_as(C.c_void_p),
+                              B.ctypes.data_as(C.c_void_p), C.byref(o), devs, len(devices)), "qgemul_run_sharded")
     return C_out
 
 

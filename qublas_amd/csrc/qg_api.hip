@@ -843,13 +843,53 @@ struct RunCache {
     qgemul_epilogue pe;
     bool has_pe = false;
     uint32_t pflags = 0;
-    enum { NBUF = 6 + 2 * QG_MAX_EW };
+    enum { NBUF = 6 + 16 };   // 0-5: host-layout A, B, C and packed A, B, C; behind them: the epilogue operands (2 per stage) or, on the
+                              // root of a sharded call, the landing buffers of the other bands
     void* buf[NBUF] = {};
     size_t cap[NBUF] = {};
 };
 thread_local RunCache g_run;
+// qgemul_run_sharded: one such cache per entry of the device list (slot i serves devices[i] of the calling thread's last list)
+enum { QG_MAX_SHARDS = 16 };
+thread_local RunCache g_shard[QG_MAX_SHARDS];
+thread_local hipEvent_t g_shard_ev[QG_MAX_SHARDS] = {};
+// What a thread has cached is released when the thread ends (worker threads that call Qgemul<>() and exit must not leak a stream
+// and device buffers each).  For the main thread this runs inside exit() BEFORE any static object — HIP's included — is torn down.
+struct RunCacheReaper {
+    bool armed = false;
+    ~RunCacheReaper() { if (armed) qgemul_run_release(); }
+};
+thread_local RunCacheReaper g_reaper;
 
-int cache_buffer(RunCache& c, int i, size_t bytes, void** out)
+// descriptors are compared field by field: padding and reserved bytes of a caller's struct are not part of its meaning, and a
+// descriptor that was not built with `{}` must still hit the cache
+bool same_fmt(const qfmt& x, const qfmt& y) { return x.I == y.I && x.F == y.F && x.S == y.S && x.Q == y.Q && x.O == y.O; }
+bool same_desc(const qgemul_desc& x, const qgemul_desc& y)
+{
+    if (x.abi != y.abi || x.transA != y.transA || x.is_complex != y.is_complex || x.cmul != y.cmul || x.M != y.M || x.N != y.N ||
+        x.K != y.K || x.n_levels != y.n_levels || x.n_levels > QG_MAX_LEVELS)
+        return false;
+    for (int p = 0; p < 2; ++p) {
+        if (!same_fmt(x.a[p], y.a[p]) || !same_fmt(x.b[p], y.b[p]) || !same_fmt(x.c[p], y.c[p])) return false;
+        for (uint32_t l = 0; l < x.n_levels; ++l)
+            if (!same_fmt(x.level_add[p][l], y.level_add[p][l]) || !same_fmt(x.level[p][l], y.level[p][l])) return false;
+    }
+    for (int i = 0; i < 8; ++i)
+        if (!same_fmt(x.mul[i], y.mul[i])) return false;
+    return true;
+}
+bool same_epilogue(const qgemul_epilogue& x, const qgemul_epilogue& y)
+{
+    if (x.n_stages != y.n_stages || x.n_stages > QG_MAX_EW || !same_fmt(x.d, y.d)) return false;
+    for (uint32_t k = 0; k < x.n_stages; ++k) {
+        const qgemul_ew_stage &a = x.stage[k], &b = y.stage[k];
+        if (a.op != b.op || a.x_first != b.x_first || a.e_scalar != b.e_scalar || !same_fmt(a.e, b.e) || !same_fmt(a.r, b.r) || !same_fmt(a.t, b.t))
+            return false;
+    }
+    return true;
+}
+
+int cache_buffer(RunCache& c, int i, size_t bytes, void** out)   // (the caller has made the cache's device current)
 {
     if (bytes > c.cap[i]) {
         if (c.buf[i]) {
@@ -868,16 +908,27 @@ int cache_buffer(RunCache& c, int i, size_t bytes, void** out)
 }
 } // namespace
 
-void qgemul_run_release(void)
+static void release_cache(RunCache& c)
 {
-    RunCache& c = g_run;
-    if (c.ctx) hipStreamSynchronize(c.ctx->stream);
-    if (c.plan) qgemul_plan_destroy(c.plan);
-    for (int i = 0; i < RunCache::NBUF; ++i) { if (c.buf[i]) hipFree(c.buf[i]); c.buf[i] = nullptr; c.cap[i] = 0; }
-    if (c.ctx) qgemul_ctx_destroy(c.ctx);
+    if (c.ctx) {
+        DeviceScope scope(c.ctx->device);
+        hipStreamSynchronize(c.ctx->stream);
+        if (c.plan) qgemul_plan_destroy(c.plan);
+        for (int i = 0; i < RunCache::NBUF; ++i) { if (c.buf[i]) hipFree(c.buf[i]); c.buf[i] = nullptr; c.cap[i] = 0; }
+        qgemul_ctx_destroy(c.ctx);
+    }
     c.plan = nullptr;
     c.ctx = nullptr;
     c.device = -2;
+}
+
+void qgemul_run_release(void)
+{
+    release_cache(g_run);
+    for (int i = 0; i < QG_MAX_SHARDS; ++i) {
+        if (g_shard_ev[i]) { hipEventDestroy(g_shard_ev[i]); g_shard_ev[i] = nullptr; }
+        release_cache(g_shard[i]);
+    }
 }
 
 int qgemul_run_ep(const qgemul_desc* d, const qgemul_epilogue* ep, void* C, const void* A, const void* B, const void* const* E,
@@ -888,13 +939,24 @@ int qgemul_run_ep(const qgemul_desc* d, const qgemul_epilogue* ep, void* C, cons
     memset(&opts, 0, sizeof opts);
     opts.device = -1;
     if (o) opts = *o;
+    g_reaper.armed = true;
     RunCache& c = g_run;
     if (opts.device < 0 && c.ctx) {   // "current device": follow hipSetDevice calls the caller made between two calls
         int cur = c.device;
         if (hipGetDevice(&cur) == hipSuccess) opts.device = cur;
     }
-    const bool same_plan = c.plan && c.pflags == opts.flags && memcmp(&c.pd, d, sizeof *d) == 0 && c.has_pe == (ep != nullptr) &&
-                           (!ep || memcmp(&c.pe, ep, sizeof *ep) == 0) && (opts.device < 0 || opts.device == c.device);
+    if (opts.flags & QG_OPT_ALL_DEVICES) {
+        if (ep) return QG_EUNSUPPORTED;   // the element-wise chain runs on one device
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return QG_ENOGPU;
+        int list[QG_MAX_SHARDS];
+        int n = 0;
+        for (int i = 0; i < ndev && n < QG_MAX_SHARDS; ++i) list[n++] = i;
+        opts.flags &= ~(uint32_t)QG_OPT_ALL_DEVICES;
+        return qgemul_run_sharded(d, C, A, B, &opts, list, n);
+    }
+    const bool same_plan = c.plan && c.pflags == opts.flags && same_desc(c.pd, *d) && c.has_pe == (ep != nullptr) &&
+                           (!ep || same_epilogue(c.pe, *ep)) && (opts.device < 0 || opts.device == c.device);
     if (!same_plan) {
         // validate before touching the device so that descriptor errors are reported without a GPU
         qgemul_info info;
@@ -973,6 +1035,152 @@ int qgemul_run_ep(const qgemul_desc* d, const qgemul_epilogue* ep, void* C, cons
     } while (0);
     const hipError_t e = hipStreamSynchronize(ctx->stream);
     if (st == QG_OK && e != hipSuccess) { g_last_hip = (int)e; st = QG_EHIP; }
+    return st;
+}
+
+// ---- several GPUs in one process: row bands of C, one per entry of the device list (include/qgemul.h) ----
+// One host thread drives every device: all work is queued asynchronously on each device's own stream (H2D of the band of A
+// and of B, pack, GEMM, peer copy of the packed C band to the root), the root's stream waits for each band's event, unpacks it
+// into the one host-layout C and copies that back.  Bands are whole blocks of 256 rows (every packed row tile divides 256).
+int qgemul_run_sharded(const qgemul_desc* d, void* C, const void* A, const void* B, const qgemul_opts* o, const int* devices, int n)
+{
+    if (!d || !C || !A || !B || !devices || n < 1 || n > QG_MAX_SHARDS) return QG_EINVAL;
+    g_reaper.armed = true;
+    qgemul_opts opts;
+    memset(&opts, 0, sizeof opts);
+    if (o) opts = *o;
+    opts.flags &= ~(uint32_t)QG_OPT_ALL_DEVICES;
+    {   // validate the whole problem before touching a device (a band of an unsupported descriptor is unsupported too)
+        qgemul_info info;
+        int st = qgemul_classify(d, opts.flags, &info);
+        if (st != QG_OK) return st;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return QG_ENOGPU;
+    for (int i = 0; i < n; ++i)
+        if (devices[i] < 0 || devices[i] >= ndev) return QG_EINVAL;
+    if (d->M == 0 || d->N == 0) return QG_OK;
+    const int64_t lda = opts.lda ? opts.lda : (d->transA ? d->K : d->M);
+    const int64_t ldb = opts.ldb ? opts.ldb : d->K;
+    const int64_t ldc = opts.ldc ? opts.ldc : d->M;
+    if (lda < (d->transA ? d->K : d->M) || ldb < d->K || ldc < d->M) return QG_EINVAL;
+
+    // contiguous bands of whole 256-row blocks, sizes differing by at most one block (qublas_amd/dist.py: row_partition)
+    const int64_t ALIGN = 256, units = (d->M + ALIGN - 1) / ALIGN;
+    int64_t row0[QG_MAX_SHARDS], rows[QG_MAX_SHARDS];
+    {
+        int64_t u0 = 0;
+        for (int i = 0; i < n; ++i) {
+            const int64_t u = units / n + (i < units % n ? 1 : 0);
+            const int64_t r0 = u0 * ALIGN < d->M ? u0 * ALIGN : d->M, r1 = (u0 + u) * ALIGN < d->M ? (u0 + u) * ALIGN : d->M;
+            row0[i] = r0;
+            rows[i] = r1 - r0;
+            u0 += u;
+        }
+    }
+    int st = QG_OK;
+    const int root = 0;   // devices[0] assembles C
+    // contexts first: the root's is needed by every band
+    for (int i = 0; i < n && st == QG_OK; ++i) {
+        RunCache& c = g_shard[i];
+        if (c.ctx && c.device != devices[i]) release_cache(c);
+        if (!c.ctx) {
+            st = qgemul_ctx_create(devices[i], &c.ctx);
+            if (st != QG_OK) { c.ctx = nullptr; break; }
+            c.device = c.ctx->device;
+        }
+        if (!g_shard_ev[i]) {
+            DeviceScope scope(c.device);
+            if (hipEventCreateWithFlags(&g_shard_ev[i], hipEventDisableTiming) != hipSuccess) { g_shard_ev[i] = nullptr; st = QG_EHIP; }
+        }
+    }
+    if (st != QG_OK) return st;
+    RunCache& rc = g_shard[root];
+    const qfmt* cf = d->c;
+    const QHostElem hcel = qg_host_elem(cf, d->is_complex);
+    const size_t bytesC = (size_t)((d->N - 1) * ldc + d->M) * hcel.size;
+    void* dC = nullptr;   // host-layout C on the root
+    {
+        DeviceScope scope(rc.device);
+        if ((st = cache_buffer(rc, 2, bytesC, &dC)) != QG_OK) return st;
+        // the caller's C may have padding between columns (ldc > M): keep those bytes as they are
+        if (ldc != d->M && hipMemcpyAsync(dC, C, bytesC, hipMemcpyHostToDevice, rc.ctx->stream) != hipSuccess) return QG_EHIP;
+    }
+    for (int i = 0; i < n && st == QG_OK; ++i) {
+        if (rows[i] == 0) continue;
+        RunCache& c = g_shard[i];
+        DeviceScope scope(c.device);
+        if (scope.err != hipSuccess) { st = QG_EHIP; break; }
+        qgemul_desc bd = *d;
+        bd.M = rows[i];
+        if (!(c.plan && c.pflags == opts.flags && !c.has_pe && same_desc(c.pd, bd))) {
+            if (c.plan) { qgemul_plan_destroy(c.plan); c.plan = nullptr; }
+            st = qgemul_plan_create(c.ctx, &bd, opts.flags, &c.plan);
+            if (st != QG_OK) { c.plan = nullptr; break; }
+            c.pd = bd;
+            c.has_pe = false;
+            c.pflags = opts.flags;
+        }
+        qgemul_plan* p = c.plan;
+        hipStream_t s = c.ctx->stream;
+        const size_t ea = (size_t)p->ha.size, eb = (size_t)p->hb.size;
+        // the band of A in host layout, tight on the device: A declared dim<M,K> (column-major) is strided in the band's rows,
+        // A declared dim<K,M> (QgemulTransposedA) is one contiguous run of columns
+        const size_t bytesA = d->transA ? (size_t)((rows[i] - 1) * lda + d->K) * ea : (size_t)rows[i] * (size_t)d->K * ea;
+        const size_t bytesB = (size_t)((d->N - 1) * ldb + d->K) * eb;
+        void *dA, *dB, *pA, *pB, *pC, *pCroot = nullptr;
+        if ((st = cache_buffer(c, 0, bytesA, &dA)) || (st = cache_buffer(c, 1, bytesB, &dB)) ||
+            (st = cache_buffer(c, 3, (size_t)p->info.packed_bytes[0], &pA)) || (st = cache_buffer(c, 4, (size_t)p->info.packed_bytes[1], &pB)) ||
+            (st = cache_buffer(c, 5, (size_t)p->info.packed_bytes[2], &pC)))
+            break;
+        hipError_t he;
+        int64_t band_lda;
+        if (d->transA) {
+            he = hipMemcpyAsync(dA, (const char*)A + (size_t)row0[i] * (size_t)lda * ea, bytesA, hipMemcpyHostToDevice, s);
+            band_lda = lda;
+        } else {
+            he = hipMemcpy2DAsync(dA, (size_t)rows[i] * ea, (const char*)A + (size_t)row0[i] * ea, (size_t)lda * ea, (size_t)rows[i] * ea,
+                                  (size_t)d->K, hipMemcpyHostToDevice, s);
+            band_lda = rows[i];
+        }
+        if (he != hipSuccess || hipMemcpyAsync(dB, B, bytesB, hipMemcpyHostToDevice, s) != hipSuccess) { st = QG_EHIP; break; }
+        if ((st = qgemul_pack(p, QG_OPERAND_A, dA, band_lda, pA)) || (st = qgemul_pack(p, QG_OPERAND_B, dB, ldb, pB)) ||
+            (st = qgemul_execute(p, pC, pA, pB)))
+            break;
+        // the packed band goes to the root (a peer copy; the same device twice: a device-to-device copy), the root unpacks it
+        if (i == root) {
+            pCroot = pC;
+        } else {
+            // one landing buffer per band on the root: the slots behind the six fixed ones, grown on demand
+            const int slot = 6 + (i - 1);
+            if (slot >= RunCache::NBUF) { st = QG_EUNSUPPORTED; break; }
+            {
+                DeviceScope rscope(rc.device);
+                if ((st = cache_buffer(rc, slot, (size_t)p->info.packed_bytes[2], &pCroot)) != QG_OK) break;
+            }
+            if (hipMemcpyPeerAsync(pCroot, rc.device, pC, c.device, (size_t)p->info.packed_bytes[2], s) != hipSuccess) { st = QG_EHIP; break; }
+        }
+        if (hipEventRecord(g_shard_ev[i], s) != hipSuccess) { st = QG_EHIP; break; }
+        {
+            DeviceScope rscope(rc.device);
+            if (i != root && hipStreamWaitEvent(rc.ctx->stream, g_shard_ev[i], 0) != hipSuccess) { st = QG_EHIP; break; }
+            QCGeom g = p->pc;          // the band's packed geometry, written at row offset row0 of the full C
+            g.ldc = ldc;
+            char* dst = (char*)dC + (size_t)row0[i] * hcel.size;
+            if (qg_launch_unpack_c(g, pCroot, dst, rc.ctx->stream, (opts.flags & QG_OPT_GENERIC_LAYOUT) ? 1 : 0) != hipSuccess) { st = QG_EHIP; break; }
+        }
+    }
+    if (st == QG_OK) {
+        DeviceScope scope(rc.device);
+        if (hipMemcpyAsync(C, dC, bytesC, hipMemcpyDeviceToHost, rc.ctx->stream) != hipSuccess) st = QG_EHIP;
+    }
+    // the call is synchronous: every stream drains before the caller's buffers may change (root last: it waits for the others)
+    for (int i = n - 1; i >= 0; --i) {
+        if (!g_shard[i].ctx) continue;
+        DeviceScope scope(g_shard[i].device);
+        const hipError_t e = hipStreamSynchronize(g_shard[i].ctx->stream);
+        if (st == QG_OK && e != hipSuccess) { g_last_hip = (int)e; st = QG_EHIP; }
+    }
     return st;
 }
 

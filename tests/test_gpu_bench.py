@@ -1,0 +1,72 @@
+"""bench.py as the driver runs it (run with -m gpu).  `python bench.py --gpus 2` must work as invoked: the parent touches no GPU
+and starts the two ranks itself; on the one-GPU test box both ranks share the card and rendezvous over gloo (the RCCL transport
+needs one GPU per rank: that run is the driver's).  The nccl branch — process group, gather, device-side stream ordering — runs
+here with a world of ONE rank.  Both legs of the JSON line are checked: the metric workload and extra.c4 (configuration 4,
+strong scaling, with and without the gather)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*argv, env=None, timeout=600):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=timeout,
+                       env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def check_common(j, world):
+    assert j["n_gpus"] == world and j["unit"].startswith("int-op/s") and j["higher_is_better"] is True
+    assert j["config"]["M_per_gpu"] == 4096 and j["config"]["K"] == 4096 and j["scaling"] == "weak"
+    assert j["value"] > 1e12 and j["roofline"]["bound"] == "mfma" and 0.01 < j["roofline"]["frac"] < 0.12
+    c4 = j["extra"]["c4"]
+    assert "error" not in c4, c4
+    assert c4["M"] == 16384 and c4["N"] == 16384 and c4["K"] == 4096 and c4["scaling"] == "strong"
+    assert sum(c4["rows_per_rank"]) == 16384 and all(r % 256 == 0 for r in c4["rows_per_rank"])
+    assert c4["world_size"] == world and c4["value_compute_only"] > 1e14
+    return c4
+
+
+def test_self_launcher_two_ranks_gloo():
+    j = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "5", "--warmup", "2", "--prewarm", "20", "--no-cpu", "--c4-steps", "3")
+    c4 = check_common(j, 2)
+    assert j["rccl_world_size"] == 2 and j["backend"] == "gloo" and j["gather_bytes_per_step_per_rank"] == 4096 * 4096 * 4
+    assert c4["rows_per_rank"] == [8192, 8192] and c4["rccl_world_size"] == 2
+    assert c4["gather_bytes_per_rank"] == 8192 * 16384          # packed 1-byte C
+    assert c4["value_one_gather"] > 0 and c4["chunks"] >= 2 and c4["value_chunked_gather"] > 0
+
+
+def test_nccl_branch_with_one_rank():
+    j = run_bench("--gpus", "1", "--force-dist", "--steps", "5", "--warmup", "2", "--prewarm", "20", "--no-cpu", "--c4-steps", "3")
+    c4 = check_common(j, 1)
+    assert j["rccl_world_size"] == 1 and j["backend"] == "nccl"
+    assert c4["rccl_world_size"] == 1 and c4["backend"] == "nccl" and c4["value_one_gather"] > 1e14
+
+
+def test_a_failing_rank_fails_the_launcher():
+    """Exit code: a rank that dies (here: an impossible backend) must make `python bench.py --gpus 2` exit non-zero."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "no_such_backend", "--steps", "1",
+                        "--warmup", "0", "--prewarm", "0", "--no-cpu", "--no-extra"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
+def test_single_gpu_line_carries_every_baseline_configuration():
+    j = run_bench("--steps", "10", "--warmup", "3", "--prewarm", "50", "--c4-steps", "5", timeout=900)
+    check_common(j, 1)
+    assert j["cpu_baseline"]["value"] and j["cpu_baseline"]["kind"] in ("reference", "port")
+    ex = j["extra"]
+    for name, bound in (("c2L", "mfma"), ("c2T", "valu"), ("c3T", "valu"), ("c5TF", "valu"), ("c5B", "valu")):
+        assert "error" not in ex[name], ex[name]
+        assert ex[name]["roofline"]["bound"] == bound and ex[name]["roofline"]["kernel_ms"] > 0
+    assert ex["c4"]["roofline"]["bound"] == "mfma" and ex["c4"]["roofline"]["frac"] > 0.3
+    assert ex["c3T"]["launches_timed"] >= 10
+    assert j["roofline"]["traffic"] is None or "traffic_source" in j["roofline"]
