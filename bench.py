@@ -490,8 +490,12 @@ def main(argv=None):
         # the layout steps either side of the hot path, timed separately (never part of `value`)
         try:
             hb = info.host_elem_bytes
-            hA = torch.zeros(M * K * hb[0], dtype=torch.uint8, device=dev)
-            hB = torch.zeros(K * N * hb[1], dtype=torch.uint8, device=dev)
+            # host-layout operands with full-range values (zeros would select the 2 x 2-limb path through the plane masks and
+            # flatter the timings)
+            ea, eb_ = wl["a"], wl["b"]
+            assert hb[0] == 4 and hb[1] == 4
+            hA = torch.randint(ea.raw_min, ea.raw_max + 1, (M * K,), dtype=torch.int32, device=dev).view(torch.uint8)
+            hB = torch.randint(eb_.raw_min, eb_.raw_max + 1, (K * N,), dtype=torch.int32, device=dev).view(torch.uint8)
             hC = torch.empty(M * N * hb[2], dtype=torch.uint8, device=dev)
             torch.cuda.synchronize()
             lay = {}
@@ -505,6 +509,16 @@ def main(argv=None):
                     fn()
                 ctx.sync()
                 lay[nm] = (time.perf_counter() - t1) / 5 * 1e3
+            # the same C written by the kernel's own epilogue in the reference layout (no packed C, no unpack pass)
+            plan.execute_host_c(hC.data_ptr(), tA.data_ptr(), tB.data_ptr())
+            ctx.sync()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                plan.execute_host_c(hC.data_ptr(), tA.data_ptr(), tB.data_ptr())
+            ctx.sync()
+            lay["gemm_into_host_layout_c_ms"] = (time.perf_counter() - t1) / 10 * 1e3
+            lay["epilogue_stores_host_layout"] = bool(plan.stores_host_c)
+            lay["host_layout_call_ms"] = lay["pack_a_ms"] + lay["pack_b_ms"] + lay["gemm_into_host_layout_c_ms"]
             lay["host_layout_bytes"] = [int(hA.numel()), int(hB.numel()), int(hC.numel())]
             out["layout_steps"] = lay
             del hA, hB, hC

@@ -242,6 +242,13 @@ int qgemul_pack_f64(qgemul_plan* p, int operand, const double* src_dev, int64_t 
 int qgemul_unpack_c(qgemul_plan* p, const void* packed_dev, void* dst_dev, int64_t ld);
 /* the hot path: packed A, packed B -> packed C, asynchronous on the ctx stream */
 int qgemul_execute(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB);
+/* The hot path with C in the REFERENCE layout on the device (column-major, element (i, j) at i + j * ldc; ldc in elements,
+ * 0 = M): packed A, packed B -> host-layout C.  Where the kernel's epilogue can store its runs of rows straight into that
+ * layout (linear class on the two-group MFMA kernels with a 4- or 8-byte C element: qgemul_plan_stores_host_c() = 1) no
+ * packed C and no unpack pass exist; every other plan runs qgemul_execute into a buffer of the plan plus qgemul_unpack_c —
+ * the call always works.  Asynchronous on the ctx stream; not for plans with an epilogue. */
+int qgemul_execute_host_c(qgemul_plan* p, void* C_dev, int64_t ldc, const void* packedA, const void* packedB);
+int qgemul_plan_stores_host_c(const qgemul_plan* p);
 /* synthetic operand straight into packed form: raw values uniform over the format's full range
  * (dist 0, what Qu::fill() does, QuBLAS.h:526-536) or |raw| < 2^(W/2) (dist 1), from
  * splitmix64(seed ^ linear_index) — the same generator oracle/qoracle.c implements on the host. */

@@ -35,7 +35,7 @@ EXPORTS = [
     "qgemul_pack", "qgemul_pack_f64", "qgemul_unpack_c", "qgemul_execute", "qgemul_fill_packed", "qgemul_time_execute",
     "qgemul_classify_ep", "qgemul_plan_create_ep", "qgemul_packed_e_bytes", "qgemul_pack_e", "qgemul_execute_ep",
     "qgemul_time_execute_ep", "qgemul_run_ep", "qgemul_plan_fuses_epilogue",
-    "qgemul_bitstream_bytes", "qgemul_export_bitstream", "qgemul_run_release", "qgemul_run_sharded",
+    "qgemul_bitstream_bytes", "qgemul_export_bitstream", "qgemul_run_release", "qgemul_run_sharded", "qgemul_execute_host_c", "qgemul_plan_stores_host_c",
 ]
 
 _lib = None
@@ -241,6 +241,18 @@ class Plan:
 
     def execute(self, pC: int, pA: int, pB: int):
         _chk(lib().qgemul_execute(self.h, C.c_void_p(pC), C.c_void_p(pA), C.c_void_p(pB)), "qgemul_execute")
+
+    def execute_host_c(self, C_dev: int, pA: int, pB: int, ldc: int = 0):
+        """packed A, packed B -> C in the reference layout on the device (no packed C where the kernel can store it directly)"""
+        L = lib()
+        L.qgemul_execute_host_c.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        _chk(L.qgemul_execute_host_c(self.h, C.c_void_p(C_dev), ldc, C.c_void_p(pA), C.c_void_p(pB)), "qgemul_execute_host_c")
+
+    @property
+    def stores_host_c(self) -> bool:
+        L = lib()
+        L.qgemul_plan_stores_host_c.argtypes = [C.c_void_p]
+        return bool(L.qgemul_plan_stores_host_c(self.h))
 
     def bitstream_bytes(self, fmt: int = 0) -> int:
         return int(lib().qgemul_bitstream_bytes(self.h, fmt))

@@ -74,7 +74,10 @@ struct qgemul_plan {
     QCGeom pc_c;
     void* cwork;
     int32_t* wide_ws;     // single-limb MFMA with a left-shifting epilogue that leaves 32 bits: raw int32 dot products
+    void* hostc_pc;       // qgemul_execute_host_c on a kernel that cannot store the reference layout: its packed C
 };
+
+struct HostC { void* C; int64_t ld; };   // execute_kernel: store the reference layout directly (kernels that can)
 
 static int pow2_bytes(int storage_bits)
 {
@@ -453,6 +456,7 @@ void qgemul_plan_destroy(qgemul_plan* p)
     hipFree(p->workspace);
     hipFree(p->cwork);
     hipFree(p->wide_ws);
+    hipFree(p->hostc_pc);
     delete p;
 }
 
@@ -549,7 +553,7 @@ int qgemul_unpack_c(qgemul_plan* p, const void* packed_dev, void* dst_dev, int64
     return QG_OK;
 }
 
-static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB, const qgemul_ep_args* epa);
+static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB, const qgemul_ep_args* epa, const HostC* hostc = nullptr);
 
 int qgemul_execute(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB)
 {
@@ -558,6 +562,38 @@ int qgemul_execute(qgemul_plan* p, void* packedC, const void* packedA, const voi
     if (p->desc.M == 0 || p->desc.N == 0) return QG_OK;
     QG_ON_DEVICE(p->ctx);
     return execute_kernel(p, packedC, packedA, packedB, nullptr);
+}
+
+// the kernels whose epilogue can store the reference layout: k_mfma_pp (variant 9) / k_mfma_ppl (variant 10), real, 4- or 8-byte
+// container equal to the host element, no raw-dot-product detour
+static bool stores_host_c(const qgemul_plan* p)
+{
+    if (p->has_ep || p->desc.is_complex || wide_epilogue(p)) return false;
+    if (p->info.kernel != QG_KERNEL_MFMA_I8 && p->info.kernel != QG_KERNEL_MFMA_I8_LIMB) return false;
+    if (p->variant != 9 && p->variant != 10) return false;
+    if (p->variant == 10 && (p->pa.rows_p / p->cfg.TM) * (p->pb.rows_p / p->cfg.TN) < 256) return false;   // (falls back to the lock-step kernel)
+    return (p->pc.cbytes == 4 || p->pc.cbytes == 8) && p->pc.cbytes == p->hc.size;
+}
+
+int qgemul_plan_stores_host_c(const qgemul_plan* p) { return p && stores_host_c(p) ? 1 : 0; }
+
+int qgemul_execute_host_c(qgemul_plan* p, void* C_dev, int64_t ldc, const void* packedA, const void* packedB)
+{
+    if (!p || !C_dev || !packedA || !packedB || p->has_ep) return QG_EINVAL;
+    if (ldc && ldc < p->desc.M) return QG_EINVAL;
+    if (p->desc.M == 0 || p->desc.N == 0) return QG_OK;
+    QG_ON_DEVICE(p->ctx);
+    if (stores_host_c(p)) {
+        const HostC h{C_dev, ldc ? ldc : p->desc.M};
+        return execute_kernel(p, C_dev, packedA, packedB, nullptr, &h);
+    }
+    if (!p->hostc_pc) QG_HIP(hipMalloc(&p->hostc_pc, (size_t)p->info.packed_bytes[2] ? (size_t)p->info.packed_bytes[2] : 16));
+    const int st = execute_kernel(p, p->hostc_pc, packedA, packedB, nullptr);
+    if (st != QG_OK) return st;
+    QCGeom c = p->pc;
+    c.ldc = ldc ? ldc : p->desc.M;
+    QG_HIP(qg_launch_unpack_c(c, p->hostc_pc, C_dev, p->ctx->stream, (p->flags & QG_OPT_GENERIC_LAYOUT) ? 1 : 0));
+    return QG_OK;
 }
 
 int qgemul_execute_ep(qgemul_plan* p, void* packedD, const void* packedA, const void* packedB, const qgemul_ep_args* args)
@@ -631,7 +667,7 @@ int qgemul_pack_e(qgemul_plan* p, int stage, const void* src_dev, int64_t ld, vo
     return QG_OK;
 }
 
-static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB, const qgemul_ep_args*)
+static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB, const qgemul_ep_args*, const HostC* hostc)
 {
     hipStream_t st = p->ctx->stream;
     const QCGeom& pcg = p->has_ep ? p->pc_c : p->pc;
@@ -678,6 +714,14 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
             f.t.to_d = p->an.lin.to_c[0];           // ... shifted, overflow-handled and stored in 64-bit arithmetic
             QG_HIP(qg_launch_eltwise(f, st));
             return QG_OK;
+        }
+        if (hostc) {   // (only reached when stores_host_c(p): see qgemul_execute_host_c)
+            a.C = hostc->C;
+            a.c_host = 1;
+            a.c_ld = hostc->ld;
+            a.c_M = p->desc.M;
+            a.c_N = p->desc.N;
+            a.c_vec = (((uintptr_t)hostc->C & 15) == 0 && (hostc->ld * pcg.cbytes) % 16 == 0) ? 1 : 0;
         }
         QG_HIP(qg_launch_mfma(p->LA, p->LB, a, st));
         return QG_OK;
@@ -1007,6 +1051,12 @@ int qgemul_run_ep(const qgemul_desc* d, const qgemul_epilogue* ep, void* C, cons
         // the caller's C may have padding between columns (ldc > M): keep those bytes as they are
         if (ldc != d->M && hipMemcpyAsync(dC, C, bytesC, hipMemcpyHostToDevice, s) != hipSuccess) { st = QG_EHIP; break; }
         if ((st = qgemul_pack(p, QG_OPERAND_A, dA, lda, pA)) || (st = qgemul_pack(p, QG_OPERAND_B, dB, ldb, pB))) break;
+        if (!ep && stores_host_c(p)) {
+            // the kernel's epilogue writes the reference layout: no packed C, no unpack pass
+            if ((st = qgemul_execute_host_c(p, dC, ldc, pA, pB))) break;
+            if (hipMemcpyAsync(C, dC, bytesC, hipMemcpyDeviceToHost, s) != hipSuccess) { st = QG_EHIP; break; }
+            break;
+        }
         if (!ep) {
             if ((st = qgemul_execute(p, pC, pA, pB))) break;
         } else {

@@ -125,6 +125,11 @@ struct QMfmaArgs {
     const uint32_t* maskB;
     int32_t has_ep, pad_;   // fused element-wise epilogue: C below is then packed D (ep.dbytes containers)
     uint32_t* dbg;          // diagnostic build: in-kernel clock stamps (qg_mfma_pp.hip); nullptr otherwise
+    // c_host != 0 (k_mfma_pp / k_mfma_ppl, 4- and 8-byte containers): C is the REFERENCE layout on the device — element (i, j)
+    // at i + j * c_ld, c_M x c_N logical — and the epilogue's runs of 4 rows land there directly: no packed C, no unpack pass.
+    // c_vec: every run of 4 rows is 16-byte aligned (base and c_ld permitting): one vector store per run.
+    int32_t c_host, c_vec;
+    int64_t c_ld, c_M, c_N;
     QEpTable ep;
     QEpArgs epa;
 };

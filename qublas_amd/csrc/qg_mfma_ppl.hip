@@ -254,8 +254,24 @@ __device__ __forceinline__ void ppl_body(const QMfmaArgs& g)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int col = wn * 32 + j * 16 + fr;
-                const int64_t base = tile_base + (int64_t)col * TM + row0;
                 const int64_t* q = s + j * 4;
+                if (g.c_host) {   // the reference layout itself (wave-uniform choice): element (r, c) at r + c * ld
+                    const int64_t gr = (int64_t)tile_m * TM + row0, gc = (int64_t)tile_n * TN + col;
+                    if (gc < g.c_N) {
+                        using E = std::conditional_t<CB == 4, int32_t, int64_t>;
+                        E* dst = (E*)C + gc * g.c_ld + gr;
+                        if (gr + 3 < g.c_M && g.c_vec) {
+                            if constexpr (CB == 4) *(int4*)dst = make_int4((int)q[0], (int)q[1], (int)q[2], (int)q[3]);
+                            else { *(longlong2*)dst = make_longlong2(q[0], q[1]); *(longlong2*)(dst + 2) = make_longlong2(q[2], q[3]); }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (gr + e < g.c_M) dst[e] = (E)q[e];
+                        }
+                    }
+                    continue;
+                }
+                const int64_t base = tile_base + (int64_t)col * TM + row0;
                 if constexpr (CB == 4) {
                     *(int4*)(C + base * 4) = make_int4((int)q[0], (int)q[1], (int)q[2], (int)q[3]);
                 } else {

@@ -105,7 +105,9 @@ __device__ __forceinline__ unsigned put_packed(const QPackedGeom& p, char* dst, 
 // lanes of a wave take 64 consecutive rows (256-byte coalesced loads per k); otherwise k is contiguous (B, transposed A)
 // -> 4 lanes cover the 64 k-bytes of a row and a wave stores 1 KiB contiguously per plane.  Same bytes as k_pack
 // (tests/test_gpu_resources.py::test_fast_pack_paths_write_the_bytes_of_the_generic_kernels; QG_NO_FAST_PACK=1 disables).
-template <bool R_FAST>
+// VEC (k contiguous, source and leading dimension 16-byte aligned): a thread's 16 consecutive k are four 16-byte loads instead
+// of sixteen 4-byte ones (the B operand of 4096^2 int<8,8>: 0.042 -> see profiles/).
+template <bool R_FAST, bool VEC = false>
 __global__ __launch_bounds__(256) void k_pack_limb32(QOperandGeom g, QPackedGeom p, const int32_t* __restrict__ src, int8_t* __restrict__ dst,
                                                      int check, int* flag)
 {
@@ -120,10 +122,21 @@ __global__ __launch_bounds__(256) void k_pack_limb32(QOperandGeom g, QPackedGeom
     bool bad = false;
     const bool row_in = r < g.rows;
     const int32_t* q = src + r * g.rs + k0 * g.ks;
+    if (VEC && row_in && k0 + 16 <= g.K) {
+        const int4* q4 = (const int4*)q;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        v[j] = (row_in && k0 + j < g.K) ? q[(int64_t)j * g.ks] : 0;
-        bad |= (v[j] < lo) | (v[j] > hi);
+        for (int j = 0; j < 4; ++j) {
+            const int4 x = q4[j];
+            v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) bad |= (v[j] < lo) | (v[j] > hi);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            v[j] = (row_in && k0 + j < g.K) ? q[(int64_t)j * g.ks] : 0;
+            bad |= (v[j] < lo) | (v[j] > hi);
+        }
     }
     const int rl = (int)(r % p.tr);
     // the kernels' swz<BK>(): 64-byte rows {0,2,3,1}[(row / 4) % 4], 128-byte rows (row / 2) % 8
@@ -365,6 +378,8 @@ hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const voi
         p.tr % 64 == 0 && p.rows_p % p.tr == 0 && p.K_p % p.bk == 0 && g.W[0] <= 30 && ((uintptr_t)src & 3) == 0 && ((uintptr_t)dst & 15) == 0) {
         const unsigned nb = (unsigned)((p.K_p / 64) * (p.rows_p / 64));
         if (g.rs == 1 && g.ks != 1) hipLaunchKernelGGL(k_pack_limb32<true>, dim3(nb), dim3(256), 0, st, g, p, (const int32_t*)src, (int8_t*)dst, check_range, range_flag);
+        else if (g.ks == 1 && g.rs % 4 == 0 && ((uintptr_t)src & 15) == 0)
+            hipLaunchKernelGGL((k_pack_limb32<false, true>), dim3(nb), dim3(256), 0, st, g, p, (const int32_t*)src, (int8_t*)dst, check_range, range_flag);
         else hipLaunchKernelGGL(k_pack_limb32<false>, dim3(nb), dim3(256), 0, st, g, p, (const int32_t*)src, (int8_t*)dst, check_range, range_flag);
         return hipGetLastError();
     }

@@ -1,5 +1,5 @@
 """Helper of tests/test_gpu_resources.py: pack seeded operands and unpack a seeded packed C through the C-ABI, print a
-SHA-256 per buffer.  Run once as is (fast pack paths) and once under QG_NO_FAST_PACK=1 (generic kernels)."""
+SHA-256 per buffer.  dump(0): fast pack paths; dump(capi.OPT_GENERIC_LAYOUT): the any-format kernels."""
 import hashlib
 import json
 import os
@@ -18,16 +18,18 @@ CASES = [  # (elem A, elem B, C, M, N, K, transposed_a, lda pad)
     (Qu(7, 7), Qu(7, 7), Qu(20, 8), 128, 128, 256, False, 4),
     (Qu(4, 3), Qu(4, 3), Qu(12, 3), 515, 70, 1000, False, 1),
     (Qu(8, 8), Qu(8, 8), Qu(23, 8), 1024, 1024, 512, False, 0),
+    (Qu(8, 8), Qu(8, 8), Qu(23, 8), 260, 200, 1000, True, 4),     # k contiguous, 16-byte aligned rows, ragged K: vector + scalar loads
+    (Qu(4, 3), Qu(4, 3), Qu(16, 3), 4096, 4096, 256, False, 0),   # the 256-row / 128-byte k-tile layout of the two-group kernel
 ]
 
 
-def main():
+def dump(flags):
     out = []
     with capi.Context(0) as ctx:
         for ea, eb, ec, M, N, K, ta, pad in CASES:
             I, F = ea.intBits + eb.intBits + 1, ea.fracBits + eb.fracBits
             d = lower(ea, eb, ec, M, N, K, mul_args=Tags(I, F), add_args=[Qu(I + 12, F)], transposed_a=ta)
-            plan = capi.Plan(ctx, d)
+            plan = capi.Plan(ctx, d, flags)
             pb = [int(x) for x in plan.info.packed_bytes]
             rng = np.random.default_rng(M + N + K)
             rec = {"case": [M, N, K, ta, pad], "kernel": capi.KERNEL_NAMES[plan.info.kernel]}
@@ -62,8 +64,8 @@ def main():
             for q in (pcd, hc):
                 ctx.free(q)
             plan.close()
-    print(json.dumps(out))
+    return out
 
 
 if __name__ == "__main__":
-    main()
+    print(json.dumps(dump(capi.OPT_GENERIC_LAYOUT if "--generic" in sys.argv else 0)))

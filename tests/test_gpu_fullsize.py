@@ -88,8 +88,8 @@ def test_config2_1024_tree_and_linear(oracle):
 
 
 def test_config4_16384_rowshards(oracle):
-    """Configuration 4 (16384 x 16384 x 4096, int<4,3>, AddArgs<Qu<21,6>>): sampled blocks vs the oracle,
-    and a 2048-row shard computed on its own equals the same rows of the full product."""
+    """Configuration 4 (16384 x 16384 x 4096, int<4,3>, AddArgs<Qu<21,6>>): sampled blocks vs the oracle, and EVERY one of the
+    eight 2048-row shards computed on its own (what each of 8 GPUs does) equals the same rows of the full product."""
     ec = Qu(16, 3)
     M = N = 16384
     K = 4096
@@ -100,25 +100,55 @@ def test_config4_16384_rowshards(oracle):
     check_block(oracle, d, E43, E43, ec, got, rows=(5000, 5016), cols=(0, 2048))
     check_block(oracle, d, E43, E43, ec, got, rows=(16380, 16384), cols=(14336, 16384))
     full = got.view(np.int32).reshape(N, M)
-    # shard 3 of 8: rows [6144, 8192) — packed directly from the host view of those rows
     A = oracle.fill(E43, M * K, 1)
     B = oracle.fill(E43, K * N, 2)
     ds = lower(E43, E43, ec, 2048, N, K, **kw)
     out = np.zeros(2048 * N, np.int32)
-    capi.run(ds, out, A[6144:], B, lda=M)
-    assert np.array_equal(out.reshape(N, 2048), full[:, 6144:8192])
+    for shard in range(8):          # rows [2048 shard, 2048 (shard + 1)) — packed directly from the host view of those rows
+        capi.run(ds, out, A[2048 * shard:], B, lda=M)
+        assert np.array_equal(out.reshape(N, 2048), full[:, 2048 * shard:2048 * (shard + 1)]), shard
 
 
-def test_config5_2048_complex_tf(oracle):
-    """Configuration 5 formats, K = N = 2048, a 256-row band (the full 2048 rows are the same kernel 8 times)."""
-    r = Qu(6, 3, True, RND.POS_INF, SAT.TCPL)
-    i = Qu(6, -3, True, RND.POS_INF, SAT.TCPL)
-    c5 = Qcomplex(r, i)
-    wide = Qcomplex(Qu(18, 6, True, RND.POS_INF), Qu(18, 6, True, RND.POS_INF))
-    d = lower(c5, c5, wide, 256, 2048, 2048, mul_args=TFComplexMul())
+def test_config4_narrow_c_as_configured(oracle):
+    """Configuration 4 with ITS OWN C type (int<4,3>: the 1-byte packed container that travels in the gather): the whole
+    16384 x 16384 product on the two-group kernel and on the lock-step kernel agree, blocks agree with the oracle, and the
+    result is not all saturation (half-range operands)."""
+    M = N = 16384
+    K = 4096
+    d = lower(E43, E43, E43, M, N, K, mul_args=Tags(9, 6), add_args=[Qu(21, 6)])
+    got, kernel = run_resident(d, dist=1)
+    assert kernel == "mfma_i8"
+    check_block(oracle, d, E43, E43, E43, got, rows=(0, 8), cols=(0, 1024), dist=1)
+    check_block(oracle, d, E43, E43, E43, got, rows=(8191, 8195), cols=(8000, 9024), dist=1)
+    check_block(oracle, d, E43, E43, E43, got, rows=(16376, 16384), cols=(15360, 16384), dist=1)
+    got_l, _ = run_resident(d, flags=capi.OPT_LOCKSTEP_TILES, dist=1)
+    assert np.array_equal(got, got_l)
+    c = got.view(np.int32)
+    assert float(np.mean((c == E43.raw_max) | (c == E43.raw_min))) < 0.9
+
+
+R63 = Qu(6, 3, True, RND.POS_INF, SAT.TCPL)
+I63N = Qu(6, -3, True, RND.POS_INF, SAT.TCPL)
+C5 = Qcomplex(R63, I63N)
+
+
+@pytest.mark.parametrize("cname", ["narrow", "wide"])
+def test_config5_2048_complex_tf_full_size(oracle, cname):
+    """Configuration 5 at FULL size, M = N = K = 2048 (the 2048-row grid, not a band): the configuration's own narrow C
+    (Qcomplex<int<6,3>,int<6,-3>>) and a wide C that does not saturate; bands at the first rows, in the middle and at the last
+    rows against the oracle; and the whole matrix from the fixed-mode kernel variant equals the run-time-mode variant."""
+    ec = C5 if cname == "narrow" else Qcomplex(Qu(18, 6, True, RND.POS_INF), Qu(18, 6, True, RND.POS_INF))
+    d = lower(C5, C5, ec, 2048, 2048, 2048, mul_args=TFComplexMul())
     got, kernel = run_resident(d, dist=1)
     assert kernel == "tree_cplx_i32"
-    check_block(oracle, d, c5, c5, wide, got, rows=(100, 116), cols=(0, 2048), dist=1)
+    for rows in ((0, 8), (1000, 1008), (2040, 2048)):
+        check_block(oracle, d, C5, C5, ec, got, rows=rows, cols=(0, 2048), dist=1)
+    got_rt, kernel_rt = run_resident(d, flags=capi.OPT_RUNTIME_MODES, dist=1)
+    assert kernel_rt == "tree_cplx_i32"
+    assert np.array_equal(got, got_rt)
+    if cname == "wide":
+        v = got.view(oracle.host_dtype(ec))
+        assert 0.5 < float(np.mean(v["re"] != 0))      # a real comparison, not zeros
 
 
 def test_linear_class_additivity(oracle):

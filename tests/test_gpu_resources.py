@@ -79,21 +79,10 @@ def test_run_cache_is_bounded_and_released(oracle):
 
 
 def test_fast_pack_paths_write_the_bytes_of_the_generic_kernels():
-    """k_pack_limb32 / k_unpack_c32 (32-bit real operands) against k_pack / k_unpack_c: same packed bytes, same host C,
-    padded leading dimensions and ragged shapes included.  The switch is read once per process, hence two child processes."""
-    import json
-    import os
-    import subprocess
-    import sys
-    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pack_dump.py")
-    outs = []
-    for generic in (False, True):
-        env = dict(os.environ)
-        env.pop("QG_NO_FAST_PACK", None)
-        if generic:
-            env["QG_NO_FAST_PACK"] = "1"
-        r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
-    assert outs[0] == outs[1]
-    assert any(rec["kernel"] == "mfma_i8_limb" for rec in outs[0]) and any(rec["kernel"] == "mfma_i8" for rec in outs[0])
+    """k_pack_limb32 (both axis orders, scalar and 16-byte loads) / k_unpack_c32 against k_pack / k_unpack_c
+    (QG_OPT_GENERIC_LAYOUT): same packed bytes, same host C, padded leading dimensions and ragged shapes included."""
+    import pack_dump
+    fast = pack_dump.dump(0)
+    generic = pack_dump.dump(capi.OPT_GENERIC_LAYOUT)
+    assert fast == generic
+    assert any(rec["kernel"] == "mfma_i8_limb" for rec in fast) and any(rec["kernel"] == "mfma_i8" for rec in fast)
