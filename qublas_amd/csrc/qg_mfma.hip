@@ -80,8 +80,8 @@ template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE, 
 __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 {
     if constexpr (SA == 3 && SB == 3 && ABL == 0) {
-        const unsigned ma = g.maskA ? (unsigned)__builtin_amdgcn_readfirstlane(*g.maskA) : 7u;
-        const unsigned mb = g.maskB ? (unsigned)__builtin_amdgcn_readfirstlane(*g.maskB) : 7u;
+        const unsigned ma = qg_plane_mask(g.maskA);
+        const unsigned mb = qg_plane_mask(g.maskB);
         const bool two_planes_suffice = ((ma | mb) & 4u) == 0;
         if (two_planes_suffice != (LA == 2)) return;   // the other kernel of this launch pair does the work
     }
@@ -359,8 +359,8 @@ template <int LA, int LB, int WGM, int WGN, int TI, int TJ, bool DBUF, bool EP, 
 __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
 {
     if constexpr (SA == 3 && SB == 3) {   // plane masks: see k_mfma; a 3 x 3 launch is the pair <3,3> + <2,2 on 3-plane storage>
-        const unsigned ma = g.maskA ? (unsigned)__builtin_amdgcn_readfirstlane(*g.maskA) : 7u;
-        const unsigned mb = g.maskB ? (unsigned)__builtin_amdgcn_readfirstlane(*g.maskB) : 7u;
+        const unsigned ma = qg_plane_mask(g.maskA);
+        const unsigned mb = qg_plane_mask(g.maskB);
         const bool two_planes_suffice = ((ma | mb) & 4u) == 0;
         if (two_planes_suffice != (LA == 2)) return;   // the other kernel of this launch pair does the work
     }

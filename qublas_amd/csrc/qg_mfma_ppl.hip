@@ -293,8 +293,8 @@ __device__ __forceinline__ void ppl_body(const QMfmaArgs& g)
 template <bool FAST, int CB>
 __global__ __launch_bounds__(512) void k_mfma_ppl(QMfmaArgs g)
 {
-    const unsigned ma = g.maskA ? (unsigned)__builtin_amdgcn_readfirstlane(*g.maskA) : 7u;
-    const unsigned mb = g.maskB ? (unsigned)__builtin_amdgcn_readfirstlane(*g.maskB) : 7u;
+    const unsigned ma = qg_plane_mask(g.maskA);
+    const unsigned mb = qg_plane_mask(g.maskB);
     if (((ma | mb) & 4u) == 0) ppl_body<2, 2, 3, 3, FAST, CB>(g);
     else ppl_body<3, 3, 3, 3, FAST, CB>(g);
 }

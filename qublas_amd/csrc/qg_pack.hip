@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_pack_limb32(QOperandGeom g, QPackedGeom
     if (p.trailer) {   // plane mask of the operand: one atomic per wave that saw a non-zero limb
 #pragma unroll
         for (int o = 32; o; o >>= 1) mask |= __shfl_xor(mask, o);
-        if ((t & 63) == 0 && mask) atomicOr((unsigned*)(dst + p.trailer), mask);
+        if ((t & 63) == 0 && mask) atomicOr((unsigned*)(dst + p.trailer) + ((blockIdx.x * 4 + (t >> 6)) & (QG_MASK_WORDS - 1)), mask);
     }
     if (check && bad) atomicOr(flag, 1);
 }
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void k_pack(QOperandGeom g, QPackedGeom p, con
     if (p.trailer) {   // plane mask of the operand: one atomic per wave that saw a non-zero limb
 #pragma unroll
         for (int o = 32; o; o >>= 1) mask |= __shfl_xor(mask, o);
-        if (tx == 0 && mask) atomicOr((unsigned*)(dst + p.trailer), mask);
+        if (tx == 0 && mask) atomicOr((unsigned*)(dst + p.trailer) + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (QG_MASK_WORDS - 1)), mask);
     }
     if (bad) atomicOr(flag, 1);
 }

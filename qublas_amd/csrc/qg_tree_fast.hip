@@ -9,7 +9,7 @@
 //     b = bh*2^s + bl (bl unsigned), a*b = (a*bh)*2^s + a*bl, so floor(a*b / 2^s) = a*bh + ((a*bl) >> s)
 //     and the discarded low bits are (a*bl) & (2^s-1) — two 32-bit multiplies, split done once per
 //     staged B element instead of once per MAC;
-//   * each lane owns a 4x2 block of outputs; the tree is streamed as a binary counter whose lower
+//   * each lane owns 4 rows x 2 columns (tx and tx + 16 of the block) of outputs; the tree is streamed as a binary counter whose lower
 //     four levels (16 leaves) are fully unrolled in registers and whose upper levels are a
 //     statically indexed register array, so nothing spills to scratch;
 //   * per-level formats and modes stay runtime values (wave-uniform scalar loads and scalar
@@ -255,8 +255,11 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
                 for (int i = 0; i < 4; ++i) a4[i] = *(const int4*)&sA[ty * 4 + i][kb * 16 + kq * 4];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    bh4[j] = *(const int4*)&sBh[tx * 2 + j][kb * 16 + kq * 4];
-                    if (SPLIT) bl4[j] = *(const int4*)&sBl[tx * 2 + j][kb * 16 + kq * 4];
+                    // a lane's two columns are tx and tx + 16: the 16 lanes of a ds_read_b128 group then read 16 CONSECUTIVE rows,
+                    // 36 dwords apart — 16 distinct 4-bank slots.  (Columns 2 tx + j, 72 dwords apart, put tx and tx + 8 on the
+                    // same banks: SQ_LDS_BANK_CONFLICT = 4096^3 / 128 per launch in profiles/r03d_c3T.json.)
+                    bh4[j] = *(const int4*)&sBh[tx + 16 * j][kb * 16 + kq * 4];
+                    if (SPLIT) bl4[j] = *(const int4*)&sBl[tx + 16 * j][kb * 16 + kq * 4];
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int64_t m = m0 + ty * 4 + i, n = n0 + tx * 2 + j;
+            const int64_t m = m0 + ty * 4 + i, n = n0 + tx + 16 * j;
             if (m < g.M && n < g.N) {
                 const int64_t idx = m * g.N + n;
                 const int r = v[i * 2 + j];

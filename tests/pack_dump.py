@@ -45,6 +45,12 @@ def dump(flags):
                 ctx.sync()
                 buf = np.zeros(pb[0 if op == capi.OPERAND_A else 1], dtype=np.uint8)
                 ctx.d2h(buf, pk)
+                if plan.info.limbs[0 if op == capi.OPERAND_A else 1] > 1:
+                    # the plane mask is the OR of the trailer's 64 words; which word a wave ORs into is the kernel's business
+                    tr = buf[-256:].view(np.uint32)
+                    m = np.bitwise_or.reduce(tr)
+                    tr[:] = 0
+                    tr[0] = m
                 rec["A" if op == capi.OPERAND_A else "B"] = hashlib.sha256(buf.tobytes()).hexdigest()
                 ctx.free(hd)
                 ctx.free(pk)
