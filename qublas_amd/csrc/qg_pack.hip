@@ -111,15 +111,21 @@ template <bool R_FAST, bool VEC = false>
 __global__ __launch_bounds__(256) void k_pack_limb32(QOperandGeom g, QPackedGeom p, const int32_t* __restrict__ src, int8_t* __restrict__ dst,
                                                      int check, int* flag)
 {
+    // grid-stride over the 64 x 64 blocks: a workgroup ORs what its blocks saw into ONE plane-mask atomic at the end (an atomic
+    // per wave and block — 16 384 for a 4096^2 operand, all on the trailer's memory channel — cost 0.06-0.17 ms on top of a
+    // 0.03 ms pack)
     const int kt = (int)(p.K_p / 64);
-    const int tk = (int)(blockIdx.x % kt), tr64 = (int)(blockIdx.x / kt);
+    const int64_t nblk = (int64_t)kt * (p.rows_p / 64);
     const int t = threadIdx.x;
     const int row_l = R_FAST ? (t & 63) : (t >> 2), kc = R_FAST ? (t >> 6) : (t & 3);
-    const int64_t r = (int64_t)tr64 * 64 + row_l, k0 = (int64_t)tk * 64 + kc * 16;
     const int W = g.W[0];
     const int64_t lo = g.S[0] ? -((int64_t)1 << W) : 0, hi = ((int64_t)1 << W) - 1;
-    int32_t v[16];
+    unsigned mask = 0;
     bool bad = false;
+    for (int64_t blk_id = blockIdx.x; blk_id < nblk; blk_id += gridDim.x) {
+    const int tk = (int)(blk_id % kt), tr64 = (int)(blk_id / kt);
+    const int64_t r = (int64_t)tr64 * 64 + row_l, k0 = (int64_t)tk * 64 + kc * 16;
+    int32_t v[16];
     const bool row_in = r < g.rows;
     const int32_t* q = src + r * g.rs + k0 * g.ks;
     if (VEC && row_in && k0 + 16 <= g.K) {
@@ -144,7 +150,6 @@ __global__ __launch_bounds__(256) void k_pack_limb32(QOperandGeom g, QPackedGeom
     const int c = p.bk == 64 ? kc : (tk & 1) * 4 + kc;   // 16-byte chunk of this thread inside its k-tile
     const int64_t blk = ((r / p.tr) * (p.K_p / p.bk) + (p.bk == 64 ? tk : tk >> 1)) * p.limbs;
     int8_t* out = dst + (blk * p.tr + rl) * p.bk + ((c ^ sw) * 16);
-    unsigned mask = 0;
     for (int l = 0; l < p.limbs; ++l) {
         uint32_t w[4] = {0, 0, 0, 0};
         uint32_t any = 0;
@@ -158,10 +163,17 @@ __global__ __launch_bounds__(256) void k_pack_limb32(QOperandGeom g, QPackedGeom
         *(uint4*)(out + (int64_t)l * p.tr * p.bk) = make_uint4(w[0], w[1], w[2], w[3]);
         mask |= any ? (1u << l) : 0u;
     }
-    if (p.trailer) {   // plane mask of the operand: one atomic per wave that saw a non-zero limb
+    }
+    if (p.trailer) {   // plane mask of the operand: one atomic per workgroup that saw a non-zero limb
+        __shared__ unsigned wmask[4];
 #pragma unroll
         for (int o = 32; o; o >>= 1) mask |= __shfl_xor(mask, o);
-        if ((t & 63) == 0 && mask) atomicOr((unsigned*)(dst + p.trailer) + ((blockIdx.x * 4 + (t >> 6)) & (QG_MASK_WORDS - 1)), mask);
+        if ((t & 63) == 0) wmask[t >> 6] = mask;
+        __syncthreads();
+        if (t == 0) {
+            const unsigned m = wmask[0] | wmask[1] | wmask[2] | wmask[3];
+            if (m) atomicOr((unsigned*)(dst + p.trailer) + (blockIdx.x & (QG_MASK_WORDS - 1)), m);
+        }
     }
     if (check && bad) atomicOr(flag, 1);
 }
@@ -376,7 +388,8 @@ hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const voi
     const bool no_fast = generic != 0;   // QG_OPT_GENERIC_LAYOUT: the any-format kernel (byte-identical; the equivalence test)
     if (!no_fast && g.parts == 1 && g.elem_bytes == 4 && g.sb[0] == 4 && g.off[0] == 0 && p.limbs >= 1 && p.limbs <= 3 && !p.digit6 && (p.bk == 64 || p.bk == 128) &&
         p.tr % 64 == 0 && p.rows_p % p.tr == 0 && p.K_p % p.bk == 0 && g.W[0] <= 30 && ((uintptr_t)src & 3) == 0 && ((uintptr_t)dst & 15) == 0) {
-        const unsigned nb = (unsigned)((p.K_p / 64) * (p.rows_p / 64));
+        const int64_t nblk = (p.K_p / 64) * (p.rows_p / 64);
+        const unsigned nb = (unsigned)(nblk < 2048 ? nblk : 2048);   // grid-stride beyond 8 workgroups per CU
         if (g.rs == 1 && g.ks != 1) hipLaunchKernelGGL(k_pack_limb32<true>, dim3(nb), dim3(256), 0, st, g, p, (const int32_t*)src, (int8_t*)dst, check_range, range_flag);
         else if (g.ks == 1 && g.rs % 4 == 0 && ((uintptr_t)src & 15) == 0)
             hipLaunchKernelGGL((k_pack_limb32<false, true>), dim3(nb), dim3(256), 0, st, g, p, (const int32_t*)src, (int8_t*)dst, check_range, range_flag);
