@@ -45,6 +45,7 @@ constexpr int TM = 256, TN = 256, BK = 128;
 constexpr int HALF = 128 * BK;     // one half-tile: 128 rows of 128 bytes
 constexpr int BUF = 4 * HALF;      // A[0] A[1] B[0] B[1]
 constexpr int TILE_BYTES = TM * BK;   // a (row tile, k tile) block of a packed operand
+constexpr bool PP_TWO_PHASES = false; // k_mfma_pp's default phase structure (PH2)
 
 // the walk over the output tiles (as k_mfma16): groups of 8 tile rows, column by column inside a group
 __device__ __forceinline__ void tile_of(int w, int tiles_m, int tiles_n, int& tile_m, int& tile_n)
@@ -77,7 +78,10 @@ __device__ __forceinline__ void tile_of(int w, int tiles_m, int tiles_n, int& ti
 // two waves feeding one SIMD's matrix pipe at the same time cost far more than the release does.  A start offset between the
 // workgroups of an XCD, to spread the epilogues' stores in time: no gain for 1- and 2-byte C once the epilogue was straight-
 // line code, profiles/r2g_measure_pp.jsonl.)
-template <bool PERSIST, bool FAST, int CB, bool STAMP = false>
+// PH2: two phases of 32 MFMAs per k-tile instead of four of 16 (half the barriers): phase A = row half 0 (reads A[0], B[0], B[1];
+// quadrants (0,0), (0,1)), phase B = row half 1 (reads A[1]; quadrants (1,1), (1,0)); A[1], B[1] of k-tile kt+1 are issued in
+// phase A, A[0], B[0] of kt+2 in phase B; waits vmcnt(8) / vmcnt(6).
+template <bool PERSIST, bool FAST, int CB, bool STAMP = false, bool PH2 = PP_TWO_PHASES>
 __global__ __launch_bounds__(512) void k_mfma_pp(QMfmaArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -179,6 +183,14 @@ __global__ __launch_bounds__(512) void k_mfma_pp(QMfmaArgs g)
     // end of a LOAD interval: this wave's pieces of the half-tile read next are in (all but the 10 youngest vector-memory
     // operations: the epilogue's stores of the previous tile count too and are older than any piece that may still fly, so
     // the wait is at worst early), its own fragment reads are back, then the workgroup barrier
+    auto load_done_n = [&](auto n) {   // PH2: counts differ per phase
+        if constexpr (decltype(n)::value == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto load_done = [&](bool wait_dma) {
         if (wait_dma) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -202,9 +214,10 @@ __global__ __launch_bounds__(512) void k_mfma_pp(QMfmaArgs g)
     cur1 = advance(cur1);
     issue(BUF, 0, cur1);
     issue(BUF, 2, cur1);
-    issue(BUF, 3, cur1);
+    if constexpr (!PH2) issue(BUF, 3, cur1);
     Cursor cur2 = advance(cur1);       // k-tile g + 2 (A[0], B[0], B[1] issued in phases 1, 2, 3 of k-tile g)
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // A[0], B[0] of k-tile 0
+    if constexpr (PH2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A[0], B[0], B[1] of k-tile 0 (12 pieces issued)
+    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");               // A[0], B[0] of k-tile 0 (14 issued)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
@@ -226,6 +239,36 @@ __global__ __launch_bounds__(512) void k_mfma_pp(QMfmaArgs g)
 
         for (int kt = 0; kt < nk; ++kt) {
             const int oth = BUF - cur;
+            if constexpr (PH2) {
+                // phase A: row half 0
+                read_a(cur, 0);
+                read_b(fb0, cur, 0);
+                read_b(fb1, cur, 1);
+                issue(oth, 3, cur1);
+                issue(oth, 1, cur1);
+                load_done_n(std::integral_constant<int, 8>{});   // A[1] of this k-tile is in
+                if constexpr (STAMP) { if (kt == 0) stamp(ti, 1); }
+                __builtin_amdgcn_s_setprio(1);
+                mfmas(acc[0][0], fb0);
+                mfmas(acc[0][1], fb1);
+                __builtin_amdgcn_s_setprio(0);
+                mfma_done();
+                // phase B: row half 1
+                read_a(cur, 1);
+                issue(cur, 0, cur2);
+                issue(cur, 2, cur2);
+                load_done_n(std::integral_constant<int, 6>{});   // A[0], B[0], B[1] of the next k-tile are in
+                if constexpr (STAMP) { if (kt == 0) stamp(ti, 5); }
+                __builtin_amdgcn_s_setprio(1);
+                mfmas(acc[1][1], fb1);
+                mfmas(acc[1][0], fb0);
+                __builtin_amdgcn_s_setprio(0);
+                mfma_done();
+                cur1 = cur2;
+                cur2 = advance(cur2);
+                cur = oth;
+                continue;
+            }
             // phase 0: quadrant (0, 0)
             read_a(cur, 0);
             read_b(fb0, cur, 0);
@@ -446,6 +489,20 @@ hipError_t qg_launch_mfma_pp(const QMfmaArgs& a, hipStream_t st)
     if (grid > blocks) grid = (blocks + 7) / 8 * 8;   // (fewer tiles than CUs: surplus workgroups find their list empty)
 #ifdef QG_DIAG
     if (a.dbg) return launch_pp_modes<true, true>(b, (unsigned)grid, lds + 4096, st);
+    if (QG_DIAG_ENV("QG_PP_PH2") || QG_DIAG_ENV("QG_PP_PH4")) {   // A/B of the phase structure (fast 1-byte variant only)
+        const QStep& q = a.to_c;
+        if (a.cbytes == 1 && !q.identity && q.O == QG_SAT_TCPL && q.Q == QG_TRN_TCPL && q.d >= 0) {
+            static std::atomic<uint64_t> d2{0}, d4{0};
+            if (QG_DIAG_ENV("QG_PP_PH2")) {
+                if (hipError_t er = qg_lds_attr((const void*)k_mfma_pp<true, true, 1, false, true>, lds, d2); er != hipSuccess) return er;
+                hipLaunchKernelGGL((k_mfma_pp<true, true, 1, false, true>), dim3((unsigned)grid), dim3(512), lds, st, b);
+            } else {
+                if (hipError_t er = qg_lds_attr((const void*)k_mfma_pp<true, true, 1, false, false>, lds, d4); er != hipSuccess) return er;
+                hipLaunchKernelGGL((k_mfma_pp<true, true, 1, false, false>), dim3((unsigned)grid), dim3(512), lds, st, b);
+            }
+            return hipGetLastError();
+        }
+    }
 #endif
     return launch_pp_modes<true>(b, (unsigned)grid, lds, st);
 }

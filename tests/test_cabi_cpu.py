@@ -29,6 +29,26 @@ def test_library_exports_every_declared_symbol():
     assert L.qgemul_strerror(0) == b"ok"
 
 
+def test_product_library_has_no_diagnostic_switches():
+    """The product library reads NO environment variable and contains no ablation kernel variant: the A/B switches of
+    tools/ (QG_ABLATE selects kernels that are wrong by construction, QG_NO_PLANE_MASK drops a launch the result depends on)
+    exist only in libqugemm_diag.so (-DQG_DIAG).  Checked on the built file: neither the switch names nor `getenv` nor a
+    symbol of an ablation instantiation are in it."""
+    import os
+    import subprocess
+    path = capi.LIB_PATH
+    assert path.endswith("libqugemm.so")
+    blob = open(path, "rb").read()
+    for name in (b"QG_ABLATE", b"QG_NO_PLANE_MASK", b"QG_LIMB32", b"QG_NO_DEEP", b"QG_PP_", b"QG_NO_KARA", b"QG_GEMV_CH", b"QG_NO_FAST_PACK"):
+        assert name not in blob, name
+    nm = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True).stdout
+    assert "getenv" not in nm
+    assert b"qgemul_diag_set_stamps" not in blob
+    diag = os.path.join(os.path.dirname(path), "libqugemm_diag.so")
+    if os.path.exists(diag):                      # built by tools users; when present it must be the one that has them
+        assert b"QG_ABLATE" in open(diag, "rb").read()
+
+
 def test_struct_layout_matches_header():
     # sizeof(qgemul_desc): 4+4 + 3*8 + 6*8 + 8*8 + 4+4 + 2*2*40*8
     assert C.sizeof(qgemul_desc) == 8 + 24 + 48 + 64 + 8 + 1280

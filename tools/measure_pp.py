@@ -36,8 +36,9 @@ def main():
             arm_list = [("pp", 0, None), ("lockstep", capi.OPT_LOCKSTEP_TILES, None)]
             if os.environ.get("QUBLAS_AMD_DIAG") == "1":   # diagnostic library: the launch-per-tile form of the same kernel, start staggers
                 arm_list.insert(1, ("pp_launch_per_tile", 0, ("QG_PP_LAUNCH_PER_TILE", "1")))
-                for sv in os.environ.get("TAILS", "").split():
-                    arm_list.append((f"pp_tail_{sv}", 0, ("QG_PP_TAIL", sv)))
+                if os.environ.get("PHASES"):
+                    arm_list.append(("pp_two_phases", 0, ("QG_PP_PH2", "1")))
+                    arm_list.append(("pp_four_phases", 0, ("QG_PP_PH4", "1")))
             for name, flags, envname in arm_list:
                 plan = capi.Plan(ctx, d, flags)
                 pb = plan.info.packed_bytes
