@@ -45,7 +45,7 @@ constexpr int TM = 256, TN = 256, BK = 128;
 constexpr int HALF = 128 * BK;     // one half-tile: 128 rows of 128 bytes
 constexpr int BUF = 4 * HALF;      // A[0] A[1] B[0] B[1]
 constexpr int TILE_BYTES = TM * BK;   // a (row tile, k tile) block of a packed operand
-constexpr bool PP_TWO_PHASES = false; // k_mfma_pp's default phase structure (PH2)
+constexpr bool PP_TWO_PHASES = true;  // k_mfma_pp's default phase structure (PH2): measured 2-6 % faster than four phases
 
 // the walk over the output tiles (as k_mfma16): groups of 8 tile rows, column by column inside a group
 __device__ __forceinline__ void tile_of(int w, int tiles_m, int tiles_n, int& tile_m, int& tile_n)
@@ -78,9 +78,12 @@ __device__ __forceinline__ void tile_of(int w, int tiles_m, int tiles_n, int& ti
 // two waves feeding one SIMD's matrix pipe at the same time cost far more than the release does.  A start offset between the
 // workgroups of an XCD, to spread the epilogues' stores in time: no gain for 1- and 2-byte C once the epilogue was straight-
 // line code, profiles/r2g_measure_pp.jsonl.)
-// PH2: two phases of 32 MFMAs per k-tile instead of four of 16 (half the barriers): phase A = row half 0 (reads A[0], B[0], B[1];
-// quadrants (0,0), (0,1)), phase B = row half 1 (reads A[1]; quadrants (1,1), (1,0)); A[1], B[1] of k-tile kt+1 are issued in
-// phase A, A[0], B[0] of kt+2 in phase B; waits vmcnt(8) / vmcnt(6).
+// PH2 (the default): two phases of 32 MFMAs per k-tile instead of the four of 16 described at the top of this file — half the
+// barriers, intervals of 512 matrix-pipe cycles: phase A = row half 0 (reads A[0], B[0], B[1]: 16 ds_read_b128; quadrants (0,0),
+// (0,1)), phase B = row half 1 (reads A[1]: 8; quadrants (1,1), (1,0)); B[1], A[1] of k-tile kt+1 are issued in phase A, A[0],
+// B[0] of kt+2 in phase B (4 pieces per wave each); waits vmcnt(8) (A[1] of this k-tile) / vmcnt(6) (A[0], B[0], B[1] of the
+// next).  Same ordering rules.  16384^2 x 4096: 0.781 against 0.800 ms, 8192^2 x 4096: 0.193 against 0.204 ms, a 2048-row shard
+// 0.099 against 0.106 ms on four phases, same process (profiles/r04_pp_two_phases.jsonl; QG_PP_PH4 in the diagnostic build).
 template <bool PERSIST, bool FAST, int CB, bool STAMP = false, bool PH2 = PP_TWO_PHASES>
 __global__ __launch_bounds__(512) void k_mfma_pp(QMfmaArgs g)
 {
