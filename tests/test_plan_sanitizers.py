@@ -1,0 +1,83 @@
+"""The planner (qublas_amd/csrc/qg_plan.cpp) under AddressSanitizer + UndefinedBehaviorSanitizer on the CPU — the reference
+builds all of its tests that way (CMakeLists.txt:17,26).  Descriptors: every reference-generated golden GEMM, the element-wise
+cases, and a few thousand random ones (valid, borderline and deliberately malformed: huge shifts, negative widths, level counts
+at the array bound).  The sanitized driver must agree with the product library's classification and report nothing."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import pytest
+
+import golden_io as G
+from qublas_amd import capi
+from qublas_amd.desc import Qu, Tags, desc_from_dict, lower, qgemul_desc, qgemul_epilogue
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build_driver(tmp):
+    exe = os.path.join(tmp, "plan_san")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+           os.path.join(ROOT, "tests", "san", "plan_san_driver.cpp"), os.path.join(ROOT, "qublas_amd", "csrc", "qg_plan.cpp"), "-o", exe]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def random_descs(n, seed):
+    rng = random.Random(seed)
+    out = []
+    while len(out) < n:
+        wa, wb = rng.randint(1, 30), rng.randint(1, 30)
+        fa, fb = rng.randint(-4, 12), rng.randint(-4, 12)
+        ea = Qu(max(wa - max(fa, 0), 0), fa, rng.random() < 0.7, rng.randint(0, 6), rng.randint(0, 3))
+        eb = Qu(max(wb - max(fb, 0), 0), fb, rng.random() < 0.7, rng.randint(0, 6), rng.randint(0, 3))
+        ec = Qu(rng.randint(0, 40), rng.randint(-6, 20), rng.random() < 0.7, rng.randint(0, 6), rng.randint(0, 4))
+        kw = {}
+        if rng.random() < 0.6:
+            kw["mul_args"] = Tags(rng.randint(0, 40), rng.randint(-4, 24))
+        if rng.random() < 0.6:
+            kw["add_args"] = [Qu(rng.randint(0, 50), rng.randint(-4, 24), True, rng.randint(0, 6), rng.randint(0, 3)) for _ in range(rng.randint(1, 3))]
+        M, N, K = rng.choice([1, 7, 64, 4096, 70000]), rng.choice([1, 5, 256, 16384]), rng.choice([1, 2, 3, 100, 1024, 4096, 65536, 200000])
+        try:
+            d = lower(ea, eb, ec, M, N, K, **kw)
+        except (ValueError, OverflowError):
+            continue
+        if rng.random() < 0.1:      # malformed on purpose: the planner must reject, not misbehave
+            which = rng.randint(0, 3)
+            if which == 0:
+                d.n_levels = rng.choice([0, 39, 40, 41, 1000])
+            elif which == 1:
+                d.c[0].F = rng.choice([-30000, 30000])
+            elif which == 2:
+                d.mul[0].I = rng.choice([-200, 32767])
+            else:
+                d.a[0].Q = 200
+        out.append(d)
+    return out
+
+
+def test_planner_under_asan_ubsan(tmp_path):
+    exe = build_driver(str(tmp_path))
+    descs = [desc_from_dict(j) for j in G.gemm_cases("real") + G.gemm_cases("cplx")] + random_descs(3000, 5)
+    blob = bytearray()
+    ep0 = qgemul_epilogue()
+    for d in descs:
+        blob += bytes(d) + bytes(ep0)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe], input=bytes(blob), capture_output=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert b"runtime error" not in r.stderr and b"AddressSanitizer" not in r.stderr, r.stderr.decode()[-3000:]
+    lines = r.stdout.decode().splitlines()
+    assert len(lines) == len(descs)
+    # same verdicts as the product library (the same source compiled by hipcc)
+    L = capi.lib()
+    n_ok = 0
+    for ln, d in zip(lines, descs):
+        _, st, cls, bits, *_ = ln.split()
+        info = capi.qgemul_info()
+        assert L.qgemul_classify(C.byref(d), 0, C.byref(info)) == int(st)
+        if int(st) == 0:
+            assert info.cls == int(cls) and info.max_bits == int(bits)
+            n_ok += 1
+    assert n_ok > 500
