@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         a4[p][i] = *(const int4*)&sA[p][ty * 2 + i][kb * 16 + kq * 4];
-                        b4[p][i] = *(const int4*)&sB[p][tx * 2 + i][kb * 16 + kq * 4];
+                        b4[p][i] = *(const int4*)&sB[p][tx + 16 * i][kb * 16 + kq * 4];   // columns tx and tx + 16: 16 consecutive rows per read group, no bank conflict (qg_tree_fast.hip)
                     }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int64_t m = m0 + ty * 2 + i, n = n0 + tx * 2 + j;
+                const int64_t m = m0 + ty * 2 + i, n = n0 + tx + 16 * j;
                 if (m < g.M && n < g.N) {
                     const int64_t idx = ((int64_t)p * g.M + m) * g.N + n;
                     const int r = v[p][i * 2 + j];
