@@ -19,6 +19,9 @@
 //             waits (all but the N youngest):         phase 0: 7 (A1 of kt);   phase 1: 8 (A2 of kt);   phase 2: 6 (A0, B of kt+1)
 //     2 x 2:  phase 0 issues B1, A1 of k-tile kt+1;  phase 1: A0, B0 of kt+2
 //             waits:                                  phase 0: 4 (A1 of kt);   phase 1: 3 (A0, B0, B1 of kt+1)
+// (Two phases per k-tile — planes 0 and 1 of A, then plane 2: four barriers instead of six — measured the same within noise,
+// 0.364 against 0.361 ms at 4096^3, profiles/r04_ppl_two_vs_three_phases.jsonl: the k-loop already runs 2 304 MFMA-issue cycles in
+// about 2 500.  Not kept.)
 // Ordering rules as in qg_mfma_pp.hip: a wave waits for its own pieces of a plane BEFORE the barrier that closes the LOAD
 // interval preceding the first read of that plane by group 0, and retires its fragment reads (lgkmcnt(0)) BEFORE the barrier
 // that closes its LOAD interval.  Workgroups are persistent (one per CU, a list of tiles each) and the LDS-DMA pipeline runs

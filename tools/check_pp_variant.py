@@ -13,18 +13,24 @@ from qublas_amd import capi  # noqa: E402
 from qublas_amd.desc import Qu, Tags, lower  # noqa: E402
 
 E43 = Qu(4, 3)
+E88 = Qu(8, 8, True, 5, 1)
 
 
 def main():
     var = sys.argv[1]
     with capi.Context(0) as ctx:
-        for M, N, K in ((4096, 4096, 128), (4096, 4096, 256), (4100, 4300, 1000), (8192, 8192, 4096)):
-            d = lower(E43, E43, E43, M, N, K, mul_args=Tags(9, 6), add_args=[Qu(21, 6)])
+        limb = var.startswith("QG_PPL")
+        for M, N, K in (((2048, 2048, 64), (2048, 2048, 128), (2100, 2200, 1000), (4096, 4096, 4096)) if limb else
+                        ((4096, 4096, 128), (4096, 4096, 256), (4100, 4300, 1000), (8192, 8192, 4096))):
+            if limb:
+                d = lower(E88, E88, Qu(23, 8), M, N, K, mul_args=Tags(17, 16), add_args=[Qu(29, 16)])
+            else:
+                d = lower(E43, E43, E43, M, N, K, mul_args=Tags(9, 6), add_args=[Qu(21, 6)])
             plan = capi.Plan(ctx, d)
             pb = plan.info.packed_bytes
             pA, pB, pC = ctx.alloc(pb[0]), ctx.alloc(pb[1]), ctx.alloc(pb[2])
-            plan.fill(capi.OPERAND_A, 1, 1, pA)
-            plan.fill(capi.OPERAND_B, 2, 1, pB)
+            plan.fill(capi.OPERAND_A, 1, 0 if limb else 1, pA)
+            plan.fill(capi.OPERAND_B, 2, 0 if limb else 1, pB)
             outs = []
             for on in (False, True):
                 if on:

@@ -34,9 +34,10 @@ def main():
                 d = lower(E43, E43, E43, M, N, K, mul_args=Tags(9, 6), add_args=[Qu(21, 6)])
             arms = []
             arm_list = [("pp", 0, None), ("lockstep", capi.OPT_LOCKSTEP_TILES, None)]
-            if os.environ.get("QUBLAS_AMD_DIAG") == "1":   # diagnostic library: the launch-per-tile form of the same kernel, start staggers
-                arm_list.insert(1, ("pp_launch_per_tile", 0, ("QG_PP_LAUNCH_PER_TILE", "1")))
-                if os.environ.get("PHASES"):
+            if os.environ.get("QUBLAS_AMD_DIAG") == "1":   # diagnostic library: the launch-per-tile form of the same kernel, phase structures
+                if not limb:
+                    arm_list.insert(1, ("pp_launch_per_tile", 0, ("QG_PP_LAUNCH_PER_TILE", "1")))
+                if os.environ.get("PHASES") and not limb:
                     arm_list.append(("pp_two_phases", 0, ("QG_PP_PH2", "1")))
                     arm_list.append(("pp_four_phases", 0, ("QG_PP_PH4", "1")))
             for name, flags, envname in arm_list:
