@@ -60,6 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--prewarm", type=int, default=300, help="untimed launches before the warm-up steps (lets the GPU clock settle); 0 for counter passes")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="--gpus N parent: seconds to wait for rank 0 before killing every rank")
     ap.add_argument("--c4-steps", type=int, default=20)
     ap.add_argument("--c4-chunks", type=int, default=0, help="row chunks of a rank's configuration-4 shard gathered while later chunks compute (0 = one per 256 tiles)")
     return ap.parse_args(argv)
@@ -78,7 +79,13 @@ def launch_ranks(args, argv) -> int:
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
-    out0 = procs[0].communicate()[0]
+    try:
+        out0 = procs[0].communicate(timeout=args.launch_timeout)[0]   # a rank stuck in a collective must not hang the caller for ever
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            p.kill()
+        print(f"bench.py: rank 0 did not finish within {args.launch_timeout} s; all ranks killed", file=sys.stderr)
+        return 1
     rcs = [procs[0].returncode]
     deadline = time.time() + 120
     for p in procs[1:]:
