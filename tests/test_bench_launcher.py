@@ -16,7 +16,7 @@ def test_parent_imports_no_gpu_module_before_spawning():
         "class P:\n"
         "    returncode = 0\n"
         "    def __init__(self, cmd, env=None, **kw): started.append((cmd, env)); self.i = len(started) - 1\n"
-        "    def communicate(self): return ('{\"ok\": 1}\\n', None)\n"
+        "    def communicate(self, timeout=None): return ('{\"ok\": 1}\\n', None)\n"
         "    def wait(self, timeout=None): return 0\n"
         "    def poll(self): return 0\n"
         "bench.subprocess.Popen = P\n"
@@ -40,7 +40,7 @@ def test_nonzero_child_exit_fails_the_parent():
         "class P:\n"
         "    n = 0\n"
         "    def __init__(self, cmd, env=None, **kw): self.returncode = 0 if P.n == 0 else 3; P.n += 1\n"
-        "    def communicate(self): return ('{\"ok\": 1}\\n', None)\n"
+        "    def communicate(self, timeout=None): return ('{\"ok\": 1}\\n', None)\n"
         "    def wait(self, timeout=None): return self.returncode\n"
         "    def poll(self): return self.returncode\n"
         "bench.subprocess.Popen = P\n"
