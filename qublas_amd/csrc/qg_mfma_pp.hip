@@ -84,7 +84,7 @@ __device__ __forceinline__ void tile_of(int w, int tiles_m, int tiles_n, int& ti
 // B[0] of kt+2 in phase B (4 pieces per wave each); waits vmcnt(8) (A[1] of this k-tile) / vmcnt(6) (A[0], B[0], B[1] of the
 // next).  Same ordering rules.  16384^2 x 4096: 0.781 against 0.800 ms, 8192^2 x 4096: 0.193 against 0.204 ms, a 2048-row shard
 // 0.099 against 0.106 ms on four phases, same process (profiles/r04_pp_two_phases.jsonl; QG_PP_PH4 in the diagnostic build).
-template <bool PERSIST, bool FAST, int CB, bool STAMP = false, bool PH2 = PP_TWO_PHASES>
+template <bool PERSIST, bool FAST, int CB, bool STAMP = false, bool PH2 = PP_TWO_PHASES, bool D26 = false>   // D26 (diagnostic A/B): 2 pieces in phase A, 6 in phase B
 __global__ __launch_bounds__(512) void k_mfma_pp(QMfmaArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -217,9 +217,10 @@ __global__ __launch_bounds__(512) void k_mfma_pp(QMfmaArgs g)
     cur1 = advance(cur1);
     issue(BUF, 0, cur1);
     issue(BUF, 2, cur1);
-    if constexpr (!PH2) issue(BUF, 3, cur1);
+    if constexpr (!PH2 || D26) issue(BUF, 3, cur1);
     Cursor cur2 = advance(cur1);       // k-tile g + 2 (A[0], B[0], B[1] issued in phases 1, 2, 3 of k-tile g)
-    if constexpr (PH2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A[0], B[0], B[1] of k-tile 0 (12 pieces issued)
+    if constexpr (PH2 && D26) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // A[0], B[0], B[1] of k-tile 0 (14 pieces issued)
+    else if constexpr (PH2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A[0], B[0], B[1] of k-tile 0 (12 pieces issued)
     else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");               // A[0], B[0] of k-tile 0 (14 issued)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(512) void k_mfma_pp(QMfmaArgs g)
                 read_a(cur, 0);
                 read_b(fb0, cur, 0);
                 read_b(fb1, cur, 1);
-                issue(oth, 3, cur1);
+                if constexpr (!D26) issue(oth, 3, cur1);
                 issue(oth, 1, cur1);
                 load_done_n(std::integral_constant<int, 8>{});   // A[1] of this k-tile is in
                 if constexpr (STAMP) { if (kt == 0) stamp(ti, 1); }
@@ -260,7 +261,8 @@ __global__ __launch_bounds__(512) void k_mfma_pp(QMfmaArgs g)
                 read_a(cur, 1);
                 issue(cur, 0, cur2);
                 issue(cur, 2, cur2);
-                load_done_n(std::integral_constant<int, 6>{});   // A[0], B[0], B[1] of the next k-tile are in
+                if constexpr (D26) { issue(cur, 3, cur2); load_done_n(std::integral_constant<int, 8>{}); }
+                else load_done_n(std::integral_constant<int, 6>{});   // A[0], B[0], B[1] of the next k-tile are in
                 if constexpr (STAMP) { if (kt == 0) stamp(ti, 5); }
                 __builtin_amdgcn_s_setprio(1);
                 mfmas(acc[1][1], fb1);
@@ -492,6 +494,15 @@ hipError_t qg_launch_mfma_pp(const QMfmaArgs& a, hipStream_t st)
     if (grid > blocks) grid = (blocks + 7) / 8 * 8;   // (fewer tiles than CUs: surplus workgroups find their list empty)
 #ifdef QG_DIAG
     if (a.dbg) return launch_pp_modes<true, true>(b, (unsigned)grid, lds + 4096, st);
+    if (QG_DIAG_ENV("QG_PP_D26")) {
+        const QStep& q = a.to_c;
+        if (a.cbytes == 1 && !q.identity && q.O == QG_SAT_TCPL && q.Q == QG_TRN_TCPL && q.d >= 0) {
+            static std::atomic<uint64_t> d26{0};
+            if (hipError_t er = qg_lds_attr((const void*)k_mfma_pp<true, true, 1, false, true, true>, lds, d26); er != hipSuccess) return er;
+            hipLaunchKernelGGL((k_mfma_pp<true, true, 1, false, true, true>), dim3((unsigned)grid), dim3(512), lds, st, b);
+            return hipGetLastError();
+        }
+    }
     if (QG_DIAG_ENV("QG_PP_PH2") || QG_DIAG_ENV("QG_PP_PH4")) {   // A/B of the phase structure (fast 1-byte variant only)
         const QStep& q = a.to_c;
         if (a.cbytes == 1 && !q.identity && q.O == QG_SAT_TCPL && q.Q == QG_TRN_TCPL && q.d >= 0) {

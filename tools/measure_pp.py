@@ -40,6 +40,7 @@ def main():
                 if os.environ.get("PHASES") and not limb:
                     arm_list.append(("pp_two_phases", 0, ("QG_PP_PH2", "1")))
                     arm_list.append(("pp_four_phases", 0, ("QG_PP_PH4", "1")))
+                    arm_list.append(("pp_two_phases_dma_2_6", 0, ("QG_PP_D26", "1")))
             for name, flags, envname in arm_list:
                 plan = capi.Plan(ctx, d, flags)
                 pb = plan.info.packed_bytes
