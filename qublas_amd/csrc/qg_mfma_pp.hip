@@ -45,6 +45,7 @@ constexpr int TM = 256, TN = 256, BK = 128;
 constexpr int HALF = 128 * BK;     // one half-tile: 128 rows of 128 bytes
 constexpr int BUF = 4 * HALF;      // A[0] A[1] B[0] B[1]
 constexpr int TILE_BYTES = TM * BK;   // a (row tile, k tile) block of a packed operand
+constexpr int PP_DMA_SPLIT = 1;       // PH2: LDS-DMA pieces per wave in phase A / phase B: 0 = 4 / 4, 1 = 2 / 6 (shipped), 2 = 0 / 8
 constexpr bool PP_TWO_PHASES = true;  // k_mfma_pp's default phase structure (PH2): measured 2-6 % faster than four phases
 
 // the walk over the output tiles (as k_mfma16): groups of 8 tile rows, column by column inside a group
@@ -80,11 +81,13 @@ __device__ __forceinline__ void tile_of(int w, int tiles_m, int tiles_n, int& ti
 // line code, profiles/r2g_measure_pp.jsonl.)
 // PH2 (the default): two phases of 32 MFMAs per k-tile instead of the four of 16 described at the top of this file — half the
 // barriers, intervals of 512 matrix-pipe cycles: phase A = row half 0 (reads A[0], B[0], B[1]: 16 ds_read_b128; quadrants (0,0),
-// (0,1)), phase B = row half 1 (reads A[1]: 8; quadrants (1,1), (1,0)); B[1], A[1] of k-tile kt+1 are issued in phase A, A[0],
-// B[0] of kt+2 in phase B (4 pieces per wave each); waits vmcnt(8) (A[1] of this k-tile) / vmcnt(6) (A[0], B[0], B[1] of the
-// next).  Same ordering rules.  16384^2 x 4096: 0.781 against 0.800 ms, 8192^2 x 4096: 0.193 against 0.204 ms, a 2048-row shard
+// (0,1)), phase B = row half 1 (reads A[1]: 8; quadrants (1,1), (1,0)).  LDS-DMA (DM = 1, shipped): phase A, which carries
+// 16 of the 24 fragment reads, issues only A[1] of k-tile kt+1 (2 pieces per wave), phase B issues A[0], B[0], B[1] of kt+2 (6);
+// waits vmcnt(8) in both (A[1] of this k-tile; A[0], B[0], B[1] of the next).  (DM = 0: 4 + 4 pieces — B[1], A[1] of kt+1 in phase A —
+// with waits 8 / 6; DM = 2: all 8 in phase B.  16384^2 x 4096, same process: 0.776 / 0.767 / 0.774 ms for 4+4 / 2+6 / 0+8,
+// profiles/r04_pp_dma_split.jsonl.)  Same ordering rules.  16384^2 x 4096: 0.781 against 0.800 ms, 8192^2 x 4096: 0.193 against 0.204 ms, a 2048-row shard
 // 0.099 against 0.106 ms on four phases, same process (profiles/r04_pp_two_phases.jsonl; QG_PP_PH4 in the diagnostic build).
-template <bool PERSIST, bool FAST, int CB, bool STAMP = false, bool PH2 = PP_TWO_PHASES, bool D26 = false>   // D26 (diagnostic A/B): 2 pieces in phase A, 6 in phase B
+template <bool PERSIST, bool FAST, int CB, bool STAMP = false, bool PH2 = PP_TWO_PHASES, int DM = PP_DMA_SPLIT>
 __global__ __launch_bounds__(512) void k_mfma_pp(QMfmaArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -217,9 +220,10 @@ __global__ __launch_bounds__(512) void k_mfma_pp(QMfmaArgs g)
     cur1 = advance(cur1);
     issue(BUF, 0, cur1);
     issue(BUF, 2, cur1);
-    if constexpr (!PH2 || D26) issue(BUF, 3, cur1);
+    constexpr bool D26 = PH2 && DM == 1, D08 = PH2 && DM == 2;
+    if constexpr (!PH2 || D26 || D08) issue(BUF, 3, cur1);
     Cursor cur2 = advance(cur1);       // k-tile g + 2 (A[0], B[0], B[1] issued in phases 1, 2, 3 of k-tile g)
-    if constexpr (PH2 && D26) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // A[0], B[0], B[1] of k-tile 0 (14 pieces issued)
+    if constexpr (D26 || D08) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // A[0], B[0], B[1] of k-tile 0 (14 pieces issued)
     else if constexpr (PH2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A[0], B[0], B[1] of k-tile 0 (12 pieces issued)
     else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");               // A[0], B[0] of k-tile 0 (14 issued)
     __builtin_amdgcn_s_barrier();
@@ -248,9 +252,10 @@ __global__ __launch_bounds__(512) void k_mfma_pp(QMfmaArgs g)
                 read_a(cur, 0);
                 read_b(fb0, cur, 0);
                 read_b(fb1, cur, 1);
-                if constexpr (!D26) issue(oth, 3, cur1);
-                issue(oth, 1, cur1);
-                load_done_n(std::integral_constant<int, 8>{});   // A[1] of this k-tile is in
+                if constexpr (!D26 && !D08) issue(oth, 3, cur1);
+                if constexpr (!D08) issue(oth, 1, cur1);
+                if constexpr (D08) load_done_n(std::integral_constant<int, 6>{});   // A[1] of this k-tile is in (6 younger pieces)
+                else load_done_n(std::integral_constant<int, 8>{});                 // A[1] of this k-tile is in
                 if constexpr (STAMP) { if (kt == 0) stamp(ti, 1); }
                 __builtin_amdgcn_s_setprio(1);
                 mfmas(acc[0][0], fb0);
@@ -259,9 +264,10 @@ __global__ __launch_bounds__(512) void k_mfma_pp(QMfmaArgs g)
                 mfma_done();
                 // phase B: row half 1
                 read_a(cur, 1);
+                if constexpr (D08) issue(oth, 1, cur1);           // A[1] of k-tile kt+1 (first: it is needed first)
                 issue(cur, 0, cur2);
                 issue(cur, 2, cur2);
-                if constexpr (D26) { issue(cur, 3, cur2); load_done_n(std::integral_constant<int, 8>{}); }
+                if constexpr (D26 || D08) { issue(cur, 3, cur2); load_done_n(std::integral_constant<int, 8>{}); }
                 else load_done_n(std::integral_constant<int, 6>{});   // A[0], B[0], B[1] of the next k-tile are in
                 if constexpr (STAMP) { if (kt == 0) stamp(ti, 5); }
                 __builtin_amdgcn_s_setprio(1);
@@ -494,13 +500,25 @@ hipError_t qg_launch_mfma_pp(const QMfmaArgs& a, hipStream_t st)
     if (grid > blocks) grid = (blocks + 7) / 8 * 8;   // (fewer tiles than CUs: surplus workgroups find their list empty)
 #ifdef QG_DIAG
     if (a.dbg) return launch_pp_modes<true, true>(b, (unsigned)grid, lds + 4096, st);
-    if (QG_DIAG_ENV("QG_PP_D26")) {
+    if (const char* dm = getenv("QG_PP_DMA")) {   // A/B: DMA pieces per phase (fast 1-byte variant only)
         const QStep& q = a.to_c;
         if (a.cbytes == 1 && !q.identity && q.O == QG_SAT_TCPL && q.Q == QG_TRN_TCPL && q.d >= 0) {
-            static std::atomic<uint64_t> d26{0};
-            if (hipError_t er = qg_lds_attr((const void*)k_mfma_pp<true, true, 1, false, true, true>, lds, d26); er != hipSuccess) return er;
-            hipLaunchKernelGGL((k_mfma_pp<true, true, 1, false, true, true>), dim3((unsigned)grid), dim3(512), lds, st, b);
-            return hipGetLastError();
+            static std::atomic<uint64_t> d0{0}, d1{0}, d2{0};
+            switch (atoi(dm)) {
+            case 0:
+                if (hipError_t er = qg_lds_attr((const void*)k_mfma_pp<true, true, 1, false, true, 0>, lds, d0); er != hipSuccess) return er;
+                hipLaunchKernelGGL((k_mfma_pp<true, true, 1, false, true, 0>), dim3((unsigned)grid), dim3(512), lds, st, b);
+                return hipGetLastError();
+            case 1:
+                if (hipError_t er = qg_lds_attr((const void*)k_mfma_pp<true, true, 1, false, true, 1>, lds, d1); er != hipSuccess) return er;
+                hipLaunchKernelGGL((k_mfma_pp<true, true, 1, false, true, 1>), dim3((unsigned)grid), dim3(512), lds, st, b);
+                return hipGetLastError();
+            case 2:
+                if (hipError_t er = qg_lds_attr((const void*)k_mfma_pp<true, true, 1, false, true, 2>, lds, d2); er != hipSuccess) return er;
+                hipLaunchKernelGGL((k_mfma_pp<true, true, 1, false, true, 2>), dim3((unsigned)grid), dim3(512), lds, st, b);
+                return hipGetLastError();
+            default: break;
+            }
         }
     }
     if (QG_DIAG_ENV("QG_PP_PH2") || QG_DIAG_ENV("QG_PP_PH4")) {   // A/B of the phase structure (fast 1-byte variant only)

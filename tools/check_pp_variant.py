@@ -18,6 +18,7 @@ E88 = Qu(8, 8, True, 5, 1)
 
 def main():
     var = sys.argv[1]
+    val = sys.argv[2] if len(sys.argv) > 2 else "1"
     with capi.Context(0) as ctx:
         limb = var.startswith("QG_PPL")
         for M, N, K in (((2048, 2048, 64), (2048, 2048, 128), (2100, 2200, 1000), (4096, 4096, 4096)) if limb else
@@ -34,7 +35,7 @@ def main():
             outs = []
             for on in (False, True):
                 if on:
-                    os.environ[var] = "1"
+                    os.environ[var] = val
                 plan.execute(pC, pA, pB)
                 ctx.sync()
                 os.environ.pop(var, None)

@@ -40,7 +40,8 @@ def main():
                 if os.environ.get("PHASES") and not limb:
                     arm_list.append(("pp_two_phases", 0, ("QG_PP_PH2", "1")))
                     arm_list.append(("pp_four_phases", 0, ("QG_PP_PH4", "1")))
-                    arm_list.append(("pp_two_phases_dma_2_6", 0, ("QG_PP_D26", "1")))
+                    for dm, nm in (("0", "4_4"), ("1", "2_6"), ("2", "0_8")):
+                        arm_list.append((f"pp_two_phases_dma_{nm}", 0, ("QG_PP_DMA", dm)))
             for name, flags, envname in arm_list:
                 plan = capi.Plan(ctx, d, flags)
                 pb = plan.info.packed_bytes
