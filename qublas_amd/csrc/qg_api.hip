@@ -529,7 +529,7 @@ int qgemul_pack_f64(qgemul_plan* p, int operand, const double* src_dev, int64_t 
     QG_ON_DEVICE(p->ctx);
     QOperandGeom g = operand_geom(p, operand, ld);
     const QPackedGeom& pg = operand == QG_OPERAND_A ? p->pa : p->pb;
-    QG_HIP(qg_launch_pack_f64(g, pg, src_dev, packed_dev, p->ctx->stream));
+    QG_HIP(qg_launch_pack_f64(g, pg, src_dev, packed_dev, p->ctx->stream, (p->flags & QG_OPT_GENERIC_LAYOUT) ? 1 : 0));
     return QG_OK;
 }
 

@@ -80,7 +80,7 @@ hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const voi
                           int* range_flag, hipStream_t st, int generic = 0);   // generic: the any-format kernel even where a fast path exists
 // the same with a column-major tensor of DOUBLES as source (complex: {re, im} pairs), quantised on load with each
 // part's own QuMode / OfMode exactly as Qu_s(double) does (QuBLAS.h:2387-2393)
-hipError_t qg_launch_pack_f64(const QOperandGeom& g, const QPackedGeom& p, const void* src, void* dst, hipStream_t st);
+hipError_t qg_launch_pack_f64(const QOperandGeom& g, const QPackedGeom& p, const void* src, void* dst, hipStream_t st, int generic = 0);
 hipError_t qg_launch_fill(const QOperandGeom& g, const QPackedGeom& p, uint64_t seed, int dist, void* dst, hipStream_t st);
 hipError_t qg_launch_unpack_c(const QCGeom& c, const void* packed, void* dst, hipStream_t st, int generic = 0);
 

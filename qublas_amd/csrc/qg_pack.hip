@@ -107,7 +107,9 @@ __device__ __forceinline__ unsigned put_packed(const QPackedGeom& p, char* dst, 
 // (tests/test_gpu_resources.py::test_fast_pack_paths_write_the_bytes_of_the_generic_kernels; QG_NO_FAST_PACK=1 disables).
 // VEC (k contiguous, source and leading dimension 16-byte aligned): a thread's 16 consecutive k are four 16-byte loads instead
 // of sixteen 4-byte ones (the B operand of 4096^2 int<8,8>: 0.042 -> see profiles/).
-template <bool R_FAST, bool VEC = false>
+// F64 (quantise-on-load, qgemul_pack_f64): the source is a tensor of doubles; every value goes through quantize_f64 (the element
+// type's own QuMode, then OfMode: Qu_s(double), QuBLAS.h:2387-2393) and then takes the same limb split and the same stores.
+template <bool R_FAST, bool VEC = false, bool F64 = false>
 __global__ __launch_bounds__(256) void k_pack_limb32(QOperandGeom g, QPackedGeom p, const int32_t* __restrict__ src, int8_t* __restrict__ dst,
                                                      int check, int* flag)
 {
@@ -128,6 +130,22 @@ __global__ __launch_bounds__(256) void k_pack_limb32(QOperandGeom g, QPackedGeom
     int32_t v[16];
     const bool row_in = r < g.rows;
     const int32_t* q = src + r * g.rs + k0 * g.ks;
+    if constexpr (F64) {
+        const double* qd = (const double*)src + r * g.rs + k0 * g.ks;
+        if (VEC && row_in && k0 + 16 <= g.K) {      // k contiguous: eight 16-byte loads of two doubles
+            const double2* q2 = (const double2*)qd;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double2 x = q2[j];
+                v[2 * j] = (int32_t)quantize_f64(x.x, W, g.S[0], g.F[0], g.Q[0], g.O[0]);
+                v[2 * j + 1] = (int32_t)quantize_f64(x.y, W, g.S[0], g.F[0], g.Q[0], g.O[0]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                v[j] = (row_in && k0 + j < g.K) ? (int32_t)quantize_f64(qd[(int64_t)j * g.ks], W, g.S[0], g.F[0], g.Q[0], g.O[0]) : 0;
+        }
+    } else
     if (VEC && row_in && k0 + 16 <= g.K) {
         const int4* q4 = (const int4*)q;
 #pragma unroll
@@ -401,12 +419,22 @@ hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const voi
     return hipGetLastError();
 }
 
-hipError_t qg_launch_pack_f64(const QOperandGeom& g, const QPackedGeom& p, const void* src, void* dst, hipStream_t st)
+hipError_t qg_launch_pack_f64(const QOperandGeom& g, const QPackedGeom& p, const void* src, void* dst, hipStream_t st, int generic)
 {
     int64_t blocks = ((p.K_p + 63) / 64) * ((p.rows_p + 63) / 64) * g.parts;
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
     if (hipError_t e = zero_trailer(p, dst, st); e != hipSuccess) return e;
+    if (!generic && g.parts == 1 && p.limbs >= 1 && p.limbs <= 3 && !p.digit6 && (p.bk == 64 || p.bk == 128) && p.tr % 64 == 0 && p.rows_p % p.tr == 0 &&
+        p.K_p % p.bk == 0 && g.W[0] <= 30 && ((uintptr_t)src & 7) == 0 && ((uintptr_t)dst & 15) == 0) {
+        const int64_t nblk = (p.K_p / 64) * (p.rows_p / 64);
+        const unsigned nb = (unsigned)(nblk < 2048 ? nblk : 2048);
+        if (g.rs == 1 && g.ks != 1) hipLaunchKernelGGL((k_pack_limb32<true, false, true>), dim3(nb), dim3(256), 0, st, g, p, (const int32_t*)src, (int8_t*)dst, 0, (int*)nullptr);
+        else if (g.ks == 1 && g.rs % 2 == 0 && ((uintptr_t)src & 15) == 0)
+            hipLaunchKernelGGL((k_pack_limb32<false, true, true>), dim3(nb), dim3(256), 0, st, g, p, (const int32_t*)src, (int8_t*)dst, 0, (int*)nullptr);
+        else hipLaunchKernelGGL((k_pack_limb32<false, false, true>), dim3(nb), dim3(256), 0, st, g, p, (const int32_t*)src, (int8_t*)dst, 0, (int*)nullptr);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_pack, dim3((unsigned)blocks), dim3(256), 0, st, g, p, (const char*)src, (char*)dst, 0, (int*)nullptr, 2, 0ull, 0);
     return hipGetLastError();
 }

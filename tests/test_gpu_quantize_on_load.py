@@ -118,3 +118,48 @@ def test_pack_f64_complex_and_limbs(oracle):
         ctx.d2h(got, dC)
         plan.close()
     assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("ta", [False, True])
+@pytest.mark.parametrize("e,M,K,pad", [
+    (Qu(8, 8, True, RND.POS_INF, SAT.ZERO), 300, 200, 0),     # 3 limbs
+    (Qu(8, 8, True, TRN.SMGN, WRP.TCPL), 257, 130, 3),        # odd leading dimension: scalar loads
+    (Qu(4, 3, True, RND.INF, SAT.SMGN), 515, 1000, 2),        # 1 limb, ragged K
+    (Qu(7, 7, False, RND.ZERO, SAT.TCPL), 128, 256, 4),       # 2 limbs, unsigned
+    (Qu(4, 3), 4096, 256, 0),                                 # the 256-row / 128-byte k-tile layout
+])
+def test_fast_pack_f64_writes_the_bytes_of_the_generic_kernel(e, M, K, pad, ta):
+    """k_pack_limb32<F64> (both axis orders, 16-byte and scalar loads) against k_pack's quantise-on-load path
+    (QG_OPT_GENERIC_LAYOUT): the same packed bytes for awkward doubles (ties, subnormals, huge values, NaN, infinities)."""
+    rng = np.random.default_rng(M + K)
+    ld = (K if ta else M) + pad
+    cols = M if ta else K
+    x = np.zeros(ld * cols)
+    x.reshape(cols, ld)[:, :(K if ta else M)] = awkward_doubles(rng, M * K, 2.0 ** (e.intBits - 1)).reshape(cols, -1)
+    N = 4096 if M == 4096 else 64
+    d = lower(e, e, Qu(20, 6), M, N, K, mul_args=Tags(e.intBits * 2 + 1, e.fracBits * 2), add_args=[Qu(e.intBits * 2 + 13, e.fracBits * 2)], transposed_a=ta)
+    outs = []
+    with capi.Context() as ctx:
+        dX = ctx.alloc(x.nbytes)
+        ctx.h2d(dX, x)
+        for flags in (0, capi.OPT_GENERIC_LAYOUT):
+            plan = capi.Plan(ctx, d, flags)
+            assert capi.KERNEL_NAMES[plan.info.kernel].startswith("mfma_i8")
+            nb = int(plan.info.packed_bytes[0])
+            pA = ctx.alloc(nb)
+            ctx.h2d(pA, np.full(nb, 0xee, np.uint8))
+            plan.pack_f64(capi.OPERAND_A, dX, pA, ld)
+            ctx.sync()
+            buf = np.zeros(nb, np.uint8)
+            ctx.d2h(buf, pA)
+            if plan.info.limbs[0] > 1:      # the plane mask is the OR of the trailer's 64 words
+                tr = buf[-256:].view(np.uint32)
+                m = np.bitwise_or.reduce(tr)
+                tr[:] = 0
+                tr[0] = m
+            outs.append(buf)
+            ctx.free(pA)
+            plan.close()
+        ctx.free(dX)
+    assert np.array_equal(outs[0], outs[1])
+    assert np.count_nonzero(outs[0]) > 0.3 * M * K

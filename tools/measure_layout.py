@@ -46,7 +46,10 @@ def main():
             tB = torch.empty(int(pb[1]), dtype=torch.uint8, device=dev)
             tC = torch.empty(int(pb[2]), dtype=torch.uint8, device=dev)
             torch.cuda.synchronize()
+            fA = (torch.randn(M * K, dtype=torch.float64, device=dev) * float(2 ** (e.intBits - 2)))   # doubles for quantise-on-load
+            torch.cuda.synchronize()
             steps = {"pack_a": lambda: plan.pack(capi.OPERAND_A, hA.data_ptr(), tA.data_ptr()),
+                     "pack_a_from_doubles": lambda: plan.pack_f64(capi.OPERAND_A, fA.data_ptr(), tA.data_ptr()),
                      "pack_b": lambda: plan.pack(capi.OPERAND_B, hB.data_ptr(), tB.data_ptr()),
                      "gemm_packed_c": lambda: plan.execute(tC.data_ptr(), tA.data_ptr(), tB.data_ptr()),
                      "unpack_c": lambda: plan.unpack_c(tC.data_ptr(), hC.data_ptr()),
@@ -55,6 +58,7 @@ def main():
             for _ in range(5):
                 for k, fn in steps.items():
                     res[k].append(timed(ctx, fn, 20))
+            plan.pack(capi.OPERAND_A, hA.data_ptr(), tA.data_ptr())   # (the last pack_a_from_doubles left quantised doubles in tA)
             rec = {"case": name, "epilogue_stores_host_layout": bool(plan.stores_host_c)}
             for k, v in res.items():
                 v.sort()
