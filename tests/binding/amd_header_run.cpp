@@ -16,6 +16,9 @@ static void print_matrix(const char* name, const T& m)
 
 int main()
 {
+#ifdef QUBLAS_TEST_ALL_DEVICES
+    QgemulRunFlags() |= QG_OPT_ALL_DEVICES;   // every Qgemul<...> below is row-sharded over all visible gfx950 devices (qgemul_run_sharded)
+#endif
     try {
         using e88z = Qu<intBits<8>, fracBits<8>, isSigned<true>, QuMode<TRN::TCPL>, OfMode<SAT::ZERO>>;
         using mat = Qu<dim<4, 4>, e88z>;

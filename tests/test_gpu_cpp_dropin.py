@@ -61,6 +61,19 @@ def test_standalone_header_runs_on_gpu(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="needs AMD clang (C++23)")
+def test_standalone_header_all_devices_flag(tmp_path):
+    """The same README-style program with `QgemulRunFlags() |= QG_OPT_ALL_DEVICES`: every Qgemul<...> goes through
+    qgemul_run_sharded over all visible devices (one here) and must print the same matrices."""
+    exe = tmp_path / "amd_header_run_all"
+    lib = os.path.join(ROOT, "qublas_amd")
+    subprocess.check_call([CLANG, "-std=c++23", "-O1", "-w", "-DQUBLAS_TEST_ALL_DEVICES", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "binding", "amd_header_run.cpp"), "-o", str(exe), "-L" + lib, "-lqugemm",
+                           "-Wl,-rpath," + lib])
+    out = subprocess.check_output([str(exe)], text=True)
+    assert _check(out.strip().splitlines()) == 4
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs AMD clang (C++23)")
 def test_standalone_header_elementwise_chain_on_gpu(tmp_path, oracle):
     """Qgemul<…, QgemulResult<CT>>(D, A, B, ThenMul<…>(s), ThenAdd<>(Bias), ThenRsub<…>(off)) through QuBLAS_amd.h:
     the C++ lowering must resolve the formats the Python mirror resolves, and D must be the oracle's."""
