@@ -196,8 +196,9 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
         static const bool no_kara = QG_DIAG_ENV("QG_NO_KARA");   // A/B switch
         auto ubits = [](qfmt f) { return (int)f.I + (int)f.F + (f.S ? 1 : 0); };
         // (problems small enough for the 64x64 tiles are latency-bound: measured 9.5 vs 8.9 us at 1024^3, schoolbook kept there)
-        if (!no_kara && !d->is_complex && LA == 2 && LB == 2 && (kernel == QG_KERNEL_MFMA_I8_LIMB) && cfg.variant == 3 && ubits(d->a[0]) <= 12 &&
+        if (!no_kara && !d->is_complex && LA == 2 && LB == 2 && (kernel == QG_KERNEL_MFMA_I8_LIMB) && (cfg.variant == 3 || cfg.variant == 10) && ubits(d->a[0]) <= 12 &&
             ubits(d->b[0]) <= 12 && d->K * (int64_t)(126 * 126) < (1ll << 31)) {
+            cfg.variant = 3;   // three products on the lock-step Karatsuba kernel (same tiles and k-tiles as variant 10)
             for (QPackedGeom* g : {pa, pb}) {
                 const qfmt f = g == pa ? d->a[0] : d->b[0];
                 g->digit6 = 1;

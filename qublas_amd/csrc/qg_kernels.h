@@ -150,9 +150,9 @@ struct QMfmaArgs {
 hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a, hipStream_t st);
 // single limb, 256x256 tiles, 128-byte k-tiles, two wave groups alternating on the matrix cores (qg_mfma_pp.hip; variant 9)
 hipError_t qg_launch_mfma_pp(const QMfmaArgs& a, hipStream_t st);
-// 3 x 3 limbs, 128x128 tiles, the two-group scheme with one A limb plane per phase (qg_mfma_ppl.hip; variant 10)
+// 3 x 3 and 2 x 2 limbs, 128x128 tiles, the two-group scheme with one A limb plane per phase (qg_mfma_ppl.hip; variant 10)
 bool qg_mfma_ppl_applies(int LA, int LB, const QMfmaArgs& a);
-hipError_t qg_launch_mfma_ppl(const QMfmaArgs& a, hipStream_t st);
+hipError_t qg_launch_mfma_ppl(int limbs, const QMfmaArgs& a, hipStream_t st);   // limbs: 3 (3 x 3, plane masks) or 2 (2 x 2 on two-plane storage)
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is set once per DEVICE (one process may drive several: qgemul_run_sharded);
 // `done` holds one bit per device ordinal of the calling thread's current device

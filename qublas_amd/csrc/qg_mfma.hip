@@ -775,7 +775,8 @@ QMfmaCfg qg_mfma_pick(int LA, int LB, int64_t M, int64_t N, uint32_t opt_flags)
         static const bool no_small = QG_DIAG_ENV("QG_NO_SMALL_TILES");
         const int64_t mid = ((M + 127) / 128) * ((N + 127) / 128);
         // 3 x 3 limbs with at least a tile per CU: the two-group kernel (qg_mfma_ppl.hip; same packed layout as variant 3)
-        if (LA == 3 && LB == 3 && mid >= 256 && !(opt_flags & QG_OPT_LOCKSTEP_TILES)) return QMfmaCfg{10, 128, 128, 64};
+        // (2 x 2: unless the operands are Karatsuba-eligible, which plan_geometry decides and then returns to variant 3)
+        if (((LA == 3 && LB == 3) || (LA == 2 && LB == 2)) && mid >= 256 && !(opt_flags & QG_OPT_LOCKSTEP_TILES)) return QMfmaCfg{10, 128, 128, 64};
         if (!no_small && mid <= 128 && ((M + 63) / 64) * ((N + 63) / 64) > mid) return QMfmaCfg{6, 64, 64, 64};
     }
     return QMfmaCfg{3, 128, 128, 64};
@@ -797,7 +798,7 @@ static constexpr int ablation() { return 0; }
 
 hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a_in, hipStream_t st)
 {
-    if (a_in.variant == 10 && qg_mfma_ppl_applies(LA, LB, a_in)) return qg_launch_mfma_ppl(a_in, st);
+    if (a_in.variant == 10 && qg_mfma_ppl_applies(LA, LB, a_in)) return qg_launch_mfma_ppl(LA, a_in, st);
     QMfmaArgs a_v3;
     if (a_in.variant == 10) { a_v3 = a_in; a_v3.variant = 3; }   // (fused chain, narrow C: the lock-step kernel on the same packed layout)
     const QMfmaArgs& a = a_in.variant == 10 ? a_v3 : a_in;

@@ -302,6 +302,24 @@ __global__ __launch_bounds__(512) void k_mfma_ppl(QMfmaArgs g)
     else ppl_body<3, 3, 3, 3, FAST, CB>(g);
 }
 
+// two-limb operands on two-plane storage (13..15 storage bits that are not Karatsuba-eligible, and the stacked real GEMM of the
+// complex linear class): the 2 x 2 path on its own
+template <bool FAST, int CB>
+__global__ __launch_bounds__(512) void k_mfma_ppl22(QMfmaArgs g)
+{
+    ppl_body<2, 2, 2, 2, FAST, CB>(g);
+}
+
+template <bool FAST, int CB>
+hipError_t launch_ppl22(const QMfmaArgs& a, unsigned grid, hipStream_t st)
+{
+    constexpr int lds = 2 * 4 * PLANE;
+    static std::atomic<uint64_t> attr_done{0};   // one bit per device (qg_lds_attr)
+    if (hipError_t e = qg_lds_attr((const void*)k_mfma_ppl22<FAST, CB>, lds, attr_done); e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_mfma_ppl22<FAST, CB>), dim3(grid), dim3(512), lds, st, a);
+    return hipGetLastError();
+}
+
 template <bool FAST, int CB>
 hipError_t launch_ppl(const QMfmaArgs& a, unsigned grid, hipStream_t st)
 {
@@ -312,10 +330,15 @@ hipError_t launch_ppl(const QMfmaArgs& a, unsigned grid, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_ppl_modes(const QMfmaArgs& a, unsigned grid, hipStream_t st)
+hipError_t launch_ppl_modes(int limbs, const QMfmaArgs& a, unsigned grid, hipStream_t st)
 {
     const QStep& q = a.to_c;
     const bool fast = !q.identity && q.O == QG_SAT_TCPL && q.Q == QG_TRN_TCPL && q.d >= 0;
+    if (limbs == 2) {
+        if (a.cbytes == 4) return fast ? launch_ppl22<true, 4>(a, grid, st) : launch_ppl22<false, 4>(a, grid, st);
+        if (a.cbytes == 8) return fast ? launch_ppl22<true, 8>(a, grid, st) : launch_ppl22<false, 8>(a, grid, st);
+        return hipErrorInvalidValue;
+    }
     if (a.cbytes == 4) return fast ? launch_ppl<true, 4>(a, grid, st) : launch_ppl<false, 4>(a, grid, st);
     if (a.cbytes == 8) return fast ? launch_ppl<true, 8>(a, grid, st) : launch_ppl<false, 8>(a, grid, st);
     return hipErrorInvalidValue;
@@ -325,12 +348,12 @@ hipError_t launch_ppl_modes(const QMfmaArgs& a, unsigned grid, hipStream_t st)
 
 bool qg_mfma_ppl_applies(int LA, int LB, const QMfmaArgs& a)
 {
-    if (!(LA == 3 && LB == 3) || a.has_ep || a.kara || a.variant != 10) return false;
+    if (!((LA == 3 && LB == 3) || (LA == 2 && LB == 2)) || a.has_ep || a.kara || a.variant != 10) return false;
     if (a.cbytes != 4 && a.cbytes != 8) return false;
     return (a.Mp / TM) * (a.Np / TN) >= 256;   // persistent: one workgroup per CU with at least a tile each
 }
 
-hipError_t qg_launch_mfma_ppl(const QMfmaArgs& a, hipStream_t st)
+hipError_t qg_launch_mfma_ppl(int limbs, const QMfmaArgs& a, hipStream_t st)
 {
     const int64_t blocks = (a.Mp / TM) * (a.Np / TN);
     if (blocks <= 0) return hipSuccess;
@@ -341,5 +364,5 @@ hipError_t qg_launch_mfma_ppl(const QMfmaArgs& a, hipStream_t st)
     int64_t grid = cus / 8 * 8;
     if (grid < 8) grid = 8;
     if (grid > blocks) grid = (blocks + 7) / 8 * 8;
-    return launch_ppl_modes(a, (unsigned)grid, st);
+    return launch_ppl_modes(limbs, a, (unsigned)grid, st);
 }

@@ -31,7 +31,7 @@ def main():
         for it in range(cases):
             limb = rng.random() < 0.5
             if limb:       # 3 x 3 limbs: 17..23 storage bits, 128^2 tiles, >= 256 tiles
-                w = rng.choice([16, 16, 17, 20, 22])
+                w = rng.choice([16, 16, 17, 20, 22, 14, 13])   # 13, 14: two limbs (k_mfma_ppl22)
                 M, N = rng.randint(1921, 2400), rng.randint(1921, 2400)
                 K = rng.choice([1, 63, 64, 65, 128, 129, 320, 1000, 1500, 4096])
             else:          # single limb: <= 8 storage bits, 256^2 tiles, >= 256 tiles

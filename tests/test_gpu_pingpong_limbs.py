@@ -15,13 +15,13 @@ E88 = Qu(8, 8, True, TRN.TCPL, SAT.ZERO)
 KW = dict(mul_args=Tags(17, 16), add_args=[Qu(29, 16)])
 
 
-def run_both(d, dist, seeds=(1, 2)):
+def run_both(d, dist, seeds=(1, 2), limbs=3):
     outs = []
     for flags in (0, capi.OPT_LOCKSTEP_TILES):
         with capi.Context() as ctx:
             plan = capi.Plan(ctx, d, flags)
             info = plan.info
-            assert capi.KERNEL_NAMES[info.kernel] == "mfma_i8_limb" and list(info.limbs)[:2] == [3, 3]
+            assert capi.KERNEL_NAMES[info.kernel] == "mfma_i8_limb" and list(info.limbs)[:2] == [limbs, limbs]
             pb = info.packed_bytes
             pA, pB, pC = ctx.alloc(pb[0]), ctx.alloc(pb[1]), ctx.alloc(pb[2])
             nbytes = d.M * d.N * info.host_elem_bytes[2]
@@ -39,9 +39,9 @@ def run_both(d, dist, seeds=(1, 2)):
     return outs
 
 
-def check(oracle, d, ec, got, rows, cols, dist, seeds=(1, 2)):
-    A = oracle.fill(E88, d.M * d.K, seeds[0], dist)
-    B = oracle.fill(E88, d.K * d.N, seeds[1], dist)
+def check(oracle, d, ec, got, rows, cols, dist, seeds=(1, 2), e=E88):
+    A = oracle.fill(e, d.M * d.K, seeds[0], dist)
+    B = oracle.fill(e, d.K * d.N, seeds[1], dist)
     cdt = oracle.host_dtype(ec)
     exp = np.zeros(d.M * d.N, dtype=cdt)
     oracle.gemm(d, A, B, ec, rows=rows, cols=cols, nthreads=16, out=exp)
@@ -82,3 +82,26 @@ def test_every_container_and_mode(oracle, ec):
     pp, ls = run_both(d, 0)
     assert np.array_equal(pp, ls)
     check(oracle, d, ec, pp, rows=(1000, 1016), cols=(1024, 1280), dist=0)
+
+
+E77 = Qu(7, 7)      # 15 storage bits: two limbs, not Karatsuba-eligible (more than 12 value + sign bits)
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 2048, 64), (2048, 2048, 192), (2100, 2000, 1000), (4096, 1024, 512)])
+def test_two_limb_operands_on_the_two_group_kernel(oracle, M, N, K):
+    """2 x 2 limbs on two-plane storage (k_mfma_ppl22): 4-byte and 8-byte C, against the lock-step kernel and the oracle."""
+    for ec in (Qu(20, 8), Qu(28, 14, True, RND.CONV, SAT.SMGN)):
+        d = lower(E77, E77, ec, M, N, K, mul_args=Tags(15, 14), add_args=[Qu(27, 14)])
+        pp, ls = run_both(d, 0, limbs=2)
+        assert np.array_equal(pp, ls)
+        check(oracle, d, ec, pp, rows=(0, 8), cols=(0, 256), dist=0, e=E77)
+        check(oracle, d, ec, pp, rows=(M - 9, M - 1), cols=(N - 200, N), dist=0, e=E77)
+
+
+def test_karatsuba_eligible_two_limb_operands_keep_their_kernel(oracle):
+    """int<6,5> (12 value + sign bits): three products on the lock-step Karatsuba kernel, whatever the tile count."""
+    e = Qu(6, 5)
+    d = lower(e, e, Qu(20, 8), 2048, 2048, 256, mul_args=Tags(13, 10), add_args=[Qu(25, 10)])
+    a, b = run_both(d, 0, limbs=2)
+    assert np.array_equal(a, b)
+    check(oracle, d, Qu(20, 8), a, rows=(100, 108), cols=(0, 256), dist=0, e=e)
