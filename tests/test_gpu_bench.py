@@ -45,6 +45,14 @@ def test_self_launcher_two_ranks_gloo():
     assert c4["value_one_gather"] > 0 and c4["chunks"] >= 2 and c4["value_chunked_gather"] > 0
 
 
+def test_self_launcher_three_ranks_ragged_partition():
+    """16384 rows over 3 ranks: 64 blocks of 256 rows do not divide — bands of 22 / 21 / 21 blocks; the gather pads to the largest."""
+    j = run_bench("--gpus", "3", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--prewarm", "10", "--no-cpu", "--c4-steps", "2")
+    c4 = check_common(j, 3)
+    assert c4["rows_per_rank"] == [5632, 5376, 5376] and c4["gather_bytes_per_rank"] == 5632 * 16384
+    assert c4["value_one_gather"] > 0
+
+
 def test_nccl_branch_with_one_rank():
     j = run_bench("--gpus", "1", "--force-dist", "--steps", "5", "--warmup", "2", "--prewarm", "20", "--no-cpu", "--c4-steps", "3")
     c4 = check_common(j, 1)

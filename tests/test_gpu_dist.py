@@ -33,9 +33,9 @@ def _worker(rank, world, port, name, q):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_row_sharded_with_the_engine(name):
-    world = 2
+def test_row_sharded_with_the_engine(name, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
