@@ -270,12 +270,13 @@ int qgemul_time_execute(qgemul_plan* p, void* packedC, const void* packedA, cons
  *        Qu<dim<M,N>, T1> t = Qmul<t1...>(C, s);      Qu<dim<M,N>, DT> D = Qadd<t2...>(t, Bias);
  * are, per element,  D[i] = cvt_DT( Qadd<t2>( cvt_T1( Qmul<t1>(C[i], s) ), Bias[i] ) ).  The epilogue below runs that
  * chain inside the GEMM kernel's own epilogue, on the value the kernel has just converted into C's element type, so
- * neither C nor the intermediate tensors go to memory.  Real GEMMs only.
+ * neither C nor the intermediate tensors go to memory.  (Complex GEMMs: qgemul_epilogue_cplx below.)
  *   x_0 = C[i,j] (format desc.c[0]);   y_k = Qop_k(x_k, e_k) or Qop_k(e_k, x_k), format stage[k].r;
  *   x_{k+1} = cvt_{stage[k].t}(y_k) for k < n-1;   D[i,j] = cvt_d(y_{n-1})   (cvt = the identity when source and
  *   target agree in all five fields).  n = 0:  D = C converted element by element (:2766-2777). */
 #define QG_MAX_EW 4
-enum { QG_EW_ADD = 1, QG_EW_SUB = 2, QG_EW_MUL = 3 };
+enum { QG_EW_ADD = 1, QG_EW_SUB = 2, QG_EW_MUL = 3,
+       QG_EW_PASS = 4 /* complex chains only: this part goes through the operator unchanged (qgemul_epilogue_cplx) */ };
 typedef struct qgemul_ew_stage {
     uint8_t op;        /* QG_EW_* */
     uint8_t x_first;   /* 1: Qop(x, e)   0: Qop(e, x)  — the order matters for QG_EW_SUB */
@@ -295,6 +296,7 @@ typedef struct qgemul_epilogue {
 typedef struct qgemul_ep_args {
     const void* e_packed[QG_MAX_EW];
     int64_t e_scalar[QG_MAX_EW];
+    int64_t e_scalar_im[QG_MAX_EW];   /* complex chains (qgemul_epilogue_cplx): the scalar the IMAGINARY parts' stage k uses */
 } qgemul_ep_args;
 
 /* classify / plan with an epilogue: info.host_elem_bytes[2] and info.packed_bytes[2] then describe D, and
@@ -316,6 +318,37 @@ int qgemul_time_execute_ep(qgemul_plan* p, void* packedD, const void* packedA, c
  * one scalar element; D (ldc from opts) is fully overwritten */
 int qgemul_run_ep(const qgemul_desc* d, const qgemul_epilogue* ep, void* D, const void* A, const void* B,
                   const void* const* E, const qgemul_opts* o);
+
+/* ---- element-wise operators after a COMPLEX GEMM ----
+ * Complex Qadd / Qsub (QuBLAS.h:3549-3589) and every operator between a complex and a REAL value (Qmul :3604-3644,
+ * Qadd :3648-3676, Qsub :3680-3707) act on the real and the imaginary parts independently, each part with its own tags
+ * (realT<...> / imagT<...>, :3537-3547), and a complex tensor's converting assignment converts part by part (:2527-2530).
+ * A chain of them after a complex Qgemul is therefore TWO real chains, part[0] over the real parts and part[1] over the
+ * imaginary parts, with the same number of stages:
+ *   complex (+|-) complex      both parts: ADD / SUB with that part of the operand
+ *   complex  *  real           both parts: MUL with the real operand
+ *   complex  +  real, real + complex, complex - real
+ *                              real part: ADD / SUB with the operand; imaginary part: QG_EW_PASS (carried over in its own
+ *                              format, :3670 / :3654 / :3701)
+ *   real - complex             real part: SUB (e, x); imaginary part: SUB (e, x) with a scalar operand of the real
+ *                              operand's format whose value is 0 (:3686: Qsub<tags>(Qu_s<realArgs1...>(), f2.imag))
+ * complex x complex multiplication (BasicComplexMul / TFComplexMul, :3426-3534) mixes the parts and is not an epilogue
+ * stage (the headers refuse to lower it).  The chain always runs as its own pass after the complex kernel.
+ * Operands: stage k's tensor operand is ONE packed buffer; e_complex[k] = 1: a complex tensor packed like the plan's
+ * packed C ([2][M][N], both parts in the container of the wider one), part p reads its half; 0: a real tensor, which
+ * either part may read.  Scalars: e_scalar[k] for part[0], e_scalar_im[k] for part[1]. */
+typedef struct qgemul_epilogue_cplx {
+    qgemul_epilogue part[2];
+    uint8_t e_complex[QG_MAX_EW];
+    uint8_t reserved[4];
+} qgemul_epilogue_cplx;
+int qgemul_classify_epc(const qgemul_desc* d, const qgemul_epilogue_cplx* ep, uint32_t opt_flags, qgemul_info* out);
+int qgemul_plan_create_epc(qgemul_ctx* c, const qgemul_desc* d, const qgemul_epilogue_cplx* ep, uint32_t opt_flags, qgemul_plan** out);
+/* one-shot, host pointers: E[k] points to stage k's tensor (tight, column-major M x N; {re, im} elements when
+ * e_complex[k]) or to its one scalar element; qgemul_packed_e_bytes / qgemul_pack_e / qgemul_execute_ep /
+ * qgemul_unpack_c serve plans of both kinds */
+int qgemul_run_epc(const qgemul_desc* d, const qgemul_epilogue_cplx* ep, void* D, const void* A, const void* B,
+                   const void* const* E, const qgemul_opts* o);
 
 /* ---- several GPUs in one process ----
  * The M x N outputs are independent: device i computes a band of whole 256-row blocks of C from the matching rows of A' and

@@ -437,6 +437,10 @@ int qoracle_eltwise(const qgemul_epilogue* ep, qfmt c, int64_t n, const int64_t*
         qfmt f = c;
         for (uint32_t k = 0; k < ep->n_stages; ++k) {
             const qgemul_ew_stage* s = &ep->stage[k];
+            if (s->op == QG_EW_PASS) {   /* complex chains: the part the operator carries over (QuBLAS.h:3654, :3670, :3701) */
+                if (k + 1 < ep->n_stages) { v = qo_cvt(v, f, s->t); f = s->t; }
+                continue;
+            }
             const qi ev = s->e_scalar ? e[k][0] : e[k][i];
             const qi a = s->x_first ? v : ev, b = s->x_first ? ev : v;
             const qfmt fa = s->x_first ? f : s->e, fb = s->x_first ? s->e : f;

@@ -127,6 +127,13 @@ def eltwise(ep: qgemul_epilogue, c: Qu, x: np.ndarray, E) -> np.ndarray:
     return out
 
 
+def eltwise_cplx(epc, c, x_re: np.ndarray, x_im: np.ndarray, E_re, E_im):
+    """A complex chain (qgemul_epilogue_cplx) = the chain of the real parts and the chain of the imaginary parts
+    (QuBLAS.h:3549-3589, :3604-3707: every supported operator is part-wise).  E_re[k] / E_im[k]: the values stage k of that
+    part reads (array or 1 element; anything for a PASS stage).  Returns (D_re, D_im) raw values."""
+    return (eltwise(epc.part[0], c.real, x_re, E_re), eltwise(epc.part[1], c.imag, x_im, E_im))
+
+
 def bitstream(f: Qu, x: np.ndarray, tensor_chunk: int = 0, elem_chunk: int = 0) -> bytes:
     """CPU restatement of BitStream<tensorProcessT, elemProcessT>(tensor): x = raw values in storage order; chunk 0 = l2r,
     k > 0 = r2l<k>.  Returns the '0'/'1' characters."""

@@ -13,7 +13,8 @@ from typing import Optional
 
 import numpy as np
 
-from .desc import (Qcomplex, Qu, host_layout, qgemul_desc, qgemul_ep_args, qgemul_epilogue, qgemul_info, qgemul_opts)
+from .desc import (Qcomplex, Qu, host_layout, qgemul_desc, qgemul_ep_args, qgemul_epilogue, qgemul_epilogue_cplx, qgemul_info,
+                   qgemul_opts)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # QUBLAS_AMD_DIAG=1 (tools/ only) loads the diagnostic build: environment A/B switches and ablation variants exist there and
@@ -34,7 +35,7 @@ EXPORTS = [
     "qgemul_dev_alloc", "qgemul_dev_free", "qgemul_memcpy_h2d", "qgemul_memcpy_d2h",
     "qgemul_pack", "qgemul_pack_f64", "qgemul_unpack_c", "qgemul_execute", "qgemul_fill_packed", "qgemul_time_execute",
     "qgemul_classify_ep", "qgemul_plan_create_ep", "qgemul_packed_e_bytes", "qgemul_pack_e", "qgemul_execute_ep",
-    "qgemul_time_execute_ep", "qgemul_run_ep", "qgemul_plan_fuses_epilogue",
+    "qgemul_time_execute_ep", "qgemul_run_ep", "qgemul_plan_fuses_epilogue", "qgemul_classify_epc", "qgemul_plan_create_epc", "qgemul_run_epc",
     "qgemul_bitstream_bytes", "qgemul_export_bitstream", "qgemul_run_release", "qgemul_run_sharded", "qgemul_execute_host_c", "qgemul_plan_stores_host_c",
 ]
 
@@ -89,6 +90,10 @@ def lib() -> C.CDLL:
         pa = C.POINTER(qgemul_ep_args)
         L.qgemul_classify_ep.argtypes = [pd, pe, u32, C.POINTER(qgemul_info)]
         L.qgemul_plan_create_ep.argtypes = [vp, pd, pe, u32, C.POINTER(vp)]
+        pec = C.POINTER(qgemul_epilogue_cplx)
+        L.qgemul_classify_epc.argtypes = [pd, pec, u32, C.POINTER(qgemul_info)]
+        L.qgemul_plan_create_epc.argtypes = [vp, pd, pec, u32, C.POINTER(vp)]
+        L.qgemul_run_epc.argtypes = [pd, pec, vp, vp, vp, C.POINTER(vp), C.POINTER(qgemul_opts)]
         L.qgemul_plan_fuses_epilogue.argtypes = [vp]
         L.qgemul_run_release.argtypes = []
         L.qgemul_run_release.restype = None
@@ -121,22 +126,25 @@ def run_release():
     lib().qgemul_run_release()
 
 
-def classify_ep_status(desc: qgemul_desc, ep: qgemul_epilogue, flags: int = 0):
+def classify_ep_status(desc: qgemul_desc, ep, flags: int = 0):
     info = qgemul_info()
-    st = lib().qgemul_classify_ep(C.byref(desc), C.byref(ep), flags, C.byref(info))
+    fn = lib().qgemul_classify_epc if isinstance(ep, qgemul_epilogue_cplx) else lib().qgemul_classify_ep
+    st = fn(C.byref(desc), C.byref(ep), flags, C.byref(info))
     return st, info
 
 
-def run_ep(desc: qgemul_desc, ep: qgemul_epilogue, D_out: np.ndarray, A: np.ndarray, B: np.ndarray, E, *, lda: int = 0,
+def run_ep(desc: qgemul_desc, ep, D_out: np.ndarray, A: np.ndarray, B: np.ndarray, E, *, lda: int = 0,
            ldb: int = 0, ldc: int = 0, device: int = -1, flags: int = 0) -> np.ndarray:
-    """qgemul_run_ep: E[k] = host-layout tensor (tight, column-major flattening) or a 1-element array for a scalar stage."""
+    """qgemul_run_ep / qgemul_run_epc: E[k] = host-layout tensor (tight, column-major flattening) or a 1-element array for a
+    scalar stage ({re, im} structured elements for a complex operand)."""
     A = np.ascontiguousarray(A)
     B = np.ascontiguousarray(B)
     E = [np.ascontiguousarray(e) for e in E]
     ptrs = (C.c_void_p * max(1, len(E)))(*[e.ctypes.data for e in E])
     o = qgemul_opts(lda, ldb, ldc, device, flags)
-    _chk(lib().qgemul_run_ep(C.byref(desc), C.byref(ep), D_out.ctypes.data_as(C.c_void_p), A.ctypes.data_as(C.c_void_p),
-                             B.ctypes.data_as(C.c_void_p), ptrs, C.byref(o)), "qgemul_run_ep")
+    fn = lib().qgemul_run_epc if isinstance(ep, qgemul_epilogue_cplx) else lib().qgemul_run_ep
+    _chk(fn(C.byref(desc), C.byref(ep), D_out.ctypes.data_as(C.c_void_p), A.ctypes.data_as(C.c_void_p),
+            B.ctypes.data_as(C.c_void_p), ptrs, C.byref(o)), "qgemul_run_ep")
     return D_out
 
 
@@ -213,13 +221,15 @@ class Context:
 
 
 class Plan:
-    def __init__(self, ctx: Context, desc: qgemul_desc, flags: int = 0, epilogue: Optional[qgemul_epilogue] = None):
+    def __init__(self, ctx: Context, desc: qgemul_desc, flags: int = 0, epilogue=None):
         self.ctx = ctx
         self.desc = desc
         self.epilogue = epilogue
         self.h = C.c_void_p()
         if epilogue is None:
             _chk(lib().qgemul_plan_create(ctx.h, C.byref(desc), flags, C.byref(self.h)), "qgemul_plan_create")
+        elif isinstance(epilogue, qgemul_epilogue_cplx):
+            _chk(lib().qgemul_plan_create_epc(ctx.h, C.byref(desc), C.byref(epilogue), flags, C.byref(self.h)), "qgemul_plan_create_epc")
         else:
             _chk(lib().qgemul_plan_create_ep(ctx.h, C.byref(desc), C.byref(epilogue), flags, C.byref(self.h)), "qgemul_plan_create_ep")
         self.info = qgemul_info()
@@ -271,12 +281,14 @@ class Plan:
         _chk(lib().qgemul_pack_e(self.h, stage, C.c_void_p(src_dev), ld, C.c_void_p(packed_dev)), "qgemul_pack_e")
 
     @staticmethod
-    def ep_args(packed=(), scalars=()) -> qgemul_ep_args:
+    def ep_args(packed=(), scalars=(), scalars_im=()) -> qgemul_ep_args:
         a = qgemul_ep_args()
         for k, ptr in enumerate(packed):
             a.e_packed[k] = ptr or None
         for k, v in enumerate(scalars):
             a.e_scalar[k] = int(v or 0)
+        for k, v in enumerate(scalars_im):
+            a.e_scalar_im[k] = int(v or 0)
         return a
 
     def execute_ep(self, pD: int, pA: int, pB: int, args: qgemul_ep_args):

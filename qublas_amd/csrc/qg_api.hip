@@ -71,13 +71,20 @@ struct qgemul_plan {
     int has_ep;
     qgemul_epilogue ep;
     QEpTable ept;
+    // complex chain (qgemul_epilogue_cplx): ep / ept are the chain of the real parts, ep_im / ept_im of the imaginary parts
+    int ep_cplx;
+    qgemul_epilogue ep_im;
+    QEpTable ept_im;
+    uint8_t e_cplx[QG_MAX_EW];
     QCGeom pc_c;
     void* cwork;
     int32_t* wide_ws;     // single-limb MFMA with a left-shifting epilogue that leaves 32 bits: raw int32 dot products
     void* hostc_pc;       // qgemul_execute_host_c on a kernel that cannot store the reference layout: its packed C
 };
 
-struct HostC { void* C; int64_t ld; };   // execute_kernel: store the reference layout directly (kernels that can)
+struct HostC { void* C; int64_t ld; };
+// an element-wise chain as the planner sees it: a real chain (im == nullptr) or the two part chains of a complex one
+struct EpView { const qgemul_epilogue* re; const qgemul_epilogue* im; const uint8_t* e_cplx; };   // execute_kernel: store the reference layout directly (kernels that can)
 
 static int pow2_bytes(int storage_bits)
 {
@@ -87,13 +94,15 @@ static int pow2_bytes(int storage_bits)
     return c;
 }
 
+static bool same_fmt(const qfmt& x, const qfmt& y) { return x.I == y.I && x.F == y.F && x.S == y.S && x.Q == y.Q && x.O == y.O; }
 static int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // fill info + geometry for a descriptor; no GPU access
 static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qgemul_info* info, int* pLA, int* pLB, QMfmaCfg* pVar,
                          QPackedGeom* pa, QPackedGeom* pb, QCGeom* pc, QHostElem* ha, QHostElem* hb, QHostElem* hc,
-                         const qgemul_epilogue* ep = nullptr, QEpTable* ept = nullptr, QCGeom* pc_c = nullptr)
+                         const EpView* ev = nullptr, QEpTable* ept = nullptr, QCGeom* pc_c = nullptr, QEpTable* ept_im = nullptr)
 {
+    const qgemul_epilogue* ep = ev ? ev->re : nullptr;
     qg_analyze(d, an);
     memset(info, 0, sizeof *info);
     snprintf(info->reason, sizeof info->reason, "%s", an->reason);
@@ -216,30 +225,66 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     if (pc_c) *pc_c = *pc;
     if (ep) {
         // D replaces C as the stored result: same index space, D's container and host element
+        if ((d->is_complex != 0) != (ev->im != nullptr)) {
+            info->supported = 0;
+            snprintf(info->reason, sizeof info->reason, d->is_complex ? "complex GEMM: the chain is a qgemul_epilogue_cplx" : "real GEMM: the chain is a qgemul_epilogue");
+            return QG_EINVAL;
+        }
+        QEpTable local[2];
+        QEpTable* t[2] = {ept ? ept : &local[0], ept_im ? ept_im : &local[1]};
+        qfmt df[2] = {ep->d, ep->d};
+        for (int part = 0; part < parts; ++part) {
+            const qgemul_epilogue* e = part ? ev->im : ep;
+            int ep_bits = 0;
+            char why[96];
+            const int st = qg_analyze_ep(d->c[part], e, t[part], &ep_bits, why, sizeof why);
+            if (st != QG_OK) {
+                info->supported = 0;
+                snprintf(info->reason, sizeof info->reason, "%s", why);
+                return st;
+            }
+            if (ep_bits > info->max_bits) info->max_bits = ep_bits;
+            df[part] = e->d;
+            if (!d->is_complex)
+                for (uint32_t k = 0; k < e->n_stages; ++k)
+                    if (e->stage[k].op == QG_EW_PASS) {
+                        info->supported = 0;
+                        snprintf(info->reason, sizeof info->reason, "QG_EW_PASS: complex chains only");
+                        return QG_EINVAL;
+                    }
+        }
         if (d->is_complex) {
-            info->supported = 0;
-            snprintf(info->reason, sizeof info->reason, "element-wise epilogue: real GEMMs only");
-            return QG_EUNSUPPORTED;
+            // the two chains describe the same operators: same length; a tensor operand is one packed buffer in one container;
+            // a real operand has no imaginary half to read
+            if (ev->im->n_stages != ep->n_stages) {
+                info->supported = 0;
+                snprintf(info->reason, sizeof info->reason, "complex chain: the part chains differ in length");
+                return QG_EINVAL;
+            }
+            for (int k = 0; k < t[0]->n; ++k) {
+                QEpStage &a = t[0]->st[k], &b = t[1]->st[k];
+                const bool ta = a.op != QG_EW_PASS && !a.scalar, tb = b.op != QG_EW_PASS && !b.scalar;
+                if (ev->e_cplx[k] && ta != tb) {
+                    info->supported = 0;
+                    snprintf(info->reason, sizeof info->reason, "complex chain: a complex tensor operand feeds both parts");
+                    return QG_EINVAL;
+                }
+                if (!ev->e_cplx[k] && ta && tb && !same_fmt(ep->stage[k].e, ev->im->stage[k].e)) {
+                    info->supported = 0;
+                    snprintf(info->reason, sizeof info->reason, "complex chain: a real tensor operand has one format");
+                    return QG_EINVAL;
+                }
+                if (ta && tb) a.ebytes = b.ebytes = a.ebytes > b.ebytes ? a.ebytes : b.ebytes;
+            }
+            t[0]->dbytes = t[1]->dbytes = t[0]->dbytes > t[1]->dbytes ? t[0]->dbytes : t[1]->dbytes;
         }
-        QEpTable local;
-        QEpTable* t = ept ? ept : &local;
-        int ep_bits = 0;
-        char why[96];
-        const int st = qg_analyze_ep(d->c[0], ep, t, &ep_bits, why, sizeof why);
-        if (st != QG_OK) {
-            info->supported = 0;
-            snprintf(info->reason, sizeof info->reason, "%s", why);
-            return st;
-        }
-        if (ep_bits > info->max_bits) info->max_bits = ep_bits;
-        const qfmt df[2] = {ep->d, ep->d};
-        *hc = qg_host_elem(df, 0);
-        pc->cbytes = t->dbytes;
+        *hc = qg_host_elem(df, d->is_complex);
+        pc->cbytes = t[0]->dbytes;
         pc->elem_bytes = hc->size;
-        pc->off[0] = hc->off[0];
-        pc->sb[0] = hc->sb[0];
+        for (int part = 0; part < 2; ++part) { pc->off[part] = hc->off[part]; pc->sb[part] = hc->sb[part]; }
         info->host_elem_bytes[2] = hc->size;
-        info->packed_bytes[2] = pc->Mp * pc->Np * pc->cbytes;
+        info->host_imag_off[2] = hc->off[1];
+        info->packed_bytes[2] = (int64_t)parts * pc->Mp * pc->Np * pc->cbytes;
     }
     return QG_OK;
 }
@@ -298,7 +343,7 @@ const char* qgemul_strerror(int st)
 
 int qgemul_classify(const qgemul_desc* d, uint32_t opt_flags, qgemul_info* out) { return qgemul_classify_ep(d, nullptr, opt_flags, out); }
 
-int qgemul_classify_ep(const qgemul_desc* d, const qgemul_epilogue* ep, uint32_t opt_flags, qgemul_info* out)
+static int classify_view(const qgemul_desc* d, const EpView* ev, uint32_t opt_flags, qgemul_info* out)
 {
     if (!d || !out) return QG_EINVAL;
     QAnalysis* an = new (std::nothrow) QAnalysis;
@@ -308,9 +353,22 @@ int qgemul_classify_ep(const qgemul_desc* d, const qgemul_epilogue* ep, uint32_t
     QPackedGeom pa, pb;
     QCGeom pc;
     QHostElem ha, hb, hc;
-    int st = plan_geometry(d, opt_flags, an, out, &LA, &LB, &variant, &pa, &pb, &pc, &ha, &hb, &hc, ep);
+    int st = plan_geometry(d, opt_flags, an, out, &LA, &LB, &variant, &pa, &pb, &pc, &ha, &hb, &hc, ev);
     delete an;
     return st;
+}
+
+int qgemul_classify_ep(const qgemul_desc* d, const qgemul_epilogue* ep, uint32_t opt_flags, qgemul_info* out)
+{
+    const EpView v = {ep, nullptr, nullptr};
+    return classify_view(d, ep ? &v : nullptr, opt_flags, out);
+}
+
+int qgemul_classify_epc(const qgemul_desc* d, const qgemul_epilogue_cplx* ep, uint32_t opt_flags, qgemul_info* out)
+{
+    if (!ep) return QG_EINVAL;
+    const EpView v = {&ep->part[0], &ep->part[1], ep->e_complex};
+    return classify_view(d, &v, opt_flags, out);
 }
 
 int qgemul_ctx_create(int device, qgemul_ctx** out)
@@ -394,7 +452,22 @@ int qgemul_plan_create(qgemul_ctx* c, const qgemul_desc* d, uint32_t opt_flags, 
     return qgemul_plan_create_ep(c, d, nullptr, opt_flags, out);
 }
 
+static int plan_create_view(qgemul_ctx* c, const qgemul_desc* d, const EpView* ev, uint32_t opt_flags, qgemul_plan** out);
+
 int qgemul_plan_create_ep(qgemul_ctx* c, const qgemul_desc* d, const qgemul_epilogue* ep, uint32_t opt_flags, qgemul_plan** out)
+{
+    const EpView v = {ep, nullptr, nullptr};
+    return plan_create_view(c, d, ep ? &v : nullptr, opt_flags, out);
+}
+
+int qgemul_plan_create_epc(qgemul_ctx* c, const qgemul_desc* d, const qgemul_epilogue_cplx* ep, uint32_t opt_flags, qgemul_plan** out)
+{
+    if (!ep) return QG_EINVAL;
+    const EpView v = {&ep->part[0], &ep->part[1], ep->e_complex};
+    return plan_create_view(c, d, &v, opt_flags, out);
+}
+
+static int plan_create_view(qgemul_ctx* c, const qgemul_desc* d, const EpView* ev, uint32_t opt_flags, qgemul_plan** out)
 {
     if (!c || !d || !out) return QG_EINVAL;
     qgemul_plan* p = new (std::nothrow) qgemul_plan;
@@ -403,9 +476,17 @@ int qgemul_plan_create_ep(qgemul_ctx* c, const qgemul_desc* d, const qgemul_epil
     p->ctx = c;
     p->desc = *d;
     p->flags = opt_flags;
-    if (ep) { p->has_ep = 1; p->ep = *ep; }
+    if (ev) {
+        p->has_ep = 1;
+        p->ep = *ev->re;
+        if (ev->im) {
+            p->ep_cplx = 1;
+            p->ep_im = *ev->im;
+            memcpy(p->e_cplx, ev->e_cplx, sizeof p->e_cplx);
+        }
+    }
     int st = plan_geometry(d, opt_flags, &p->an, &p->info, &p->LA, &p->LB, &p->cfg, &p->pa, &p->pb, &p->pc, &p->ha, &p->hb, &p->hc,
-                           ep, &p->ept, &p->pc_c);
+                           ev, &p->ept, &p->pc_c, &p->ept_im);
     if (st != QG_OK) { delete p; return st; }
     p->variant = p->cfg.variant;
     DeviceScope scope(c->device);
@@ -435,7 +516,7 @@ int qgemul_plan_create_ep(qgemul_ctx* c, const qgemul_desc* d, const qgemul_epil
     }
     if (p->has_ep && !fuses_epilogue(p)) {
         // the tree kernels store C; the chain then runs as a pass over it
-        const size_t cb = (size_t)(p->pc_c.Mp * p->pc_c.Np) * (size_t)p->pc_c.cbytes;
+        const size_t cb = (size_t)(p->pc_c.parts * p->pc_c.Mp * p->pc_c.Np) * (size_t)p->pc_c.cbytes;
         if (hipMalloc(&p->cwork, cb ? cb : 16) != hipSuccess) {
             hipFree(p->dev_table);
             hipFree(p->workspace);
@@ -603,7 +684,7 @@ int qgemul_execute_ep(qgemul_plan* p, void* packedD, const void* packedA, const 
     if (!p->has_ep) return args ? QG_EINVAL : qgemul_execute(p, packedD, packedA, packedB);
     if (!args && p->ept.n > 0) return QG_EINVAL;
     for (int k = 0; k < p->ept.n; ++k)
-        if (!p->ept.st[k].scalar && !args->e_packed[k]) return QG_EINVAL;
+        if ((!p->ept.st[k].scalar || (p->ep_cplx && !p->ept_im.st[k].scalar)) && !args->e_packed[k]) return QG_EINVAL;
     if (p->desc.M == 0 || p->desc.N == 0) return QG_OK;
     QG_ON_DEVICE(p->ctx);
     QEpArgs a;
@@ -646,25 +727,51 @@ int qgemul_execute_ep(qgemul_plan* p, void* packedD, const void* packedA, const 
     g.t = p->ept;
     g.a = a;
     QG_HIP(qg_launch_eltwise(g, st));
+    if (p->ep_cplx) {
+        // the chain of the imaginary parts: the second half of packed C, of packed D and of every complex tensor operand
+        g.C += g.n * g.cbytes;
+        g.D += g.n * p->ept.dbytes;
+        g.t = p->ept_im;
+        for (int k = 0; k < p->ept_im.n; ++k) {
+            if (g.a.e[k] && p->e_cplx[k]) g.a.e[k] += g.n * p->ept_im.st[k].ebytes;
+            g.a.scalar[k] = args->e_scalar_im[k];
+        }
+        QG_HIP(qg_launch_eltwise(g, st));
+    }
     return QG_OK;
 }
 
 int qgemul_plan_fuses_epilogue(const qgemul_plan* p) { return p && p->has_ep && fuses_epilogue(p) ? 1 : 0; }
 
+// the stage entry that reads stage k's tensor operand (nullptr: the stage has no tensor operand)
+static const QEpStage* stage_tensor(const qgemul_plan* p, int k)
+{
+    if (!p->ept.st[k].scalar) return &p->ept.st[k];
+    if (p->ep_cplx && !p->ept_im.st[k].scalar) return &p->ept_im.st[k];
+    return nullptr;
+}
+
 int64_t qgemul_packed_e_bytes(const qgemul_plan* p, int stage)
 {
-    if (!p || !p->has_ep || stage < 0 || stage >= p->ept.n || p->ept.st[stage].scalar) return 0;
-    return p->pc.Mp * p->pc.Np * (int64_t)p->ept.st[stage].ebytes;
+    if (!p || !p->has_ep || stage < 0 || stage >= p->ept.n) return 0;
+    const QEpStage* t = stage_tensor(p, stage);
+    if (!t) return 0;
+    return (p->ep_cplx && p->e_cplx[stage] ? 2 : 1) * p->pc.Mp * p->pc.Np * (int64_t)t->ebytes;
 }
 
 int qgemul_pack_e(qgemul_plan* p, int stage, const void* src_dev, int64_t ld, void* packed_dev)
 {
-    if (!p || !src_dev || !packed_dev || !p->has_ep || stage < 0 || stage >= p->ept.n || p->ept.st[stage].scalar) return QG_EINVAL;
+    if (!p || !src_dev || !packed_dev || !p->has_ep || stage < 0 || stage >= p->ept.n) return QG_EINVAL;
+    const QEpStage* t = stage_tensor(p, stage);
+    if (!t) return QG_EINVAL;
     if (ld && ld < p->desc.M) return QG_EINVAL;
     QG_ON_DEVICE(p->ctx);
-    const qfmt f = p->ep.stage[stage].e;
-    const int src_bytes = (1 + (int)f.I + (int)f.F) <= 32 ? 4 : 8;
-    QG_HIP(qg_launch_pack_e(p->pc, src_dev, ld ? ld : p->desc.M, src_bytes, packed_dev, p->ept.st[stage].ebytes, p->ctx->stream));
+    const bool cplx = p->ep_cplx && p->e_cplx[stage];
+    // host element of the operand tensor: int32 / int64 raw values, {re, im} structs for a complex operand (QuBLAS.h:2512-2513)
+    const qfmt f[2] = {t == &p->ept.st[stage] ? p->ep.stage[stage].e : p->ep_im.stage[stage].e, p->ep_im.stage[stage].e};
+    const QHostElem h = qg_host_elem(f, cplx ? 1 : 0);
+    for (int part = 0; part < (cplx ? 2 : 1); ++part)
+        QG_HIP(qg_launch_pack_e(p->pc, part, src_dev, ld ? ld : p->desc.M, h.size, h.off[part], h.sb[part], packed_dev, t->ebytes, p->ctx->stream));
     return QG_OK;
 }
 
@@ -753,7 +860,7 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
         g.Np = 2 * p->pb.rows_p;
         g.tm = p->cfg.TM;
         g.tn = p->cfg.TN;
-        g.cbytes = p->pc.cbytes;
+        g.cbytes = pcg.cbytes;
         for (int i = 0; i < 4; ++i) g.sh[i] = p->an.lin.sh[i];
         g.to_c[0] = p->an.lin.to_c[0];
         g.to_c[1] = p->an.lin.to_c[1];
@@ -773,7 +880,7 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
     case QG_KERNEL_TREE_CPLX_I32:
         QG_HIP(qg_launch_tree_cplx_fast(p->dev_table, (int)p->desc.n_levels, (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : p->an.cplx_fixed_ok,
                                         packedA, packedB, packedC, p->desc.M, p->desc.N,
-                                        p->pa.K_p, p->pc.cbytes, st));
+                                        p->pa.K_p, pcg.cbytes, st));
         return QG_OK;
     case QG_KERNEL_TREE_I64:
         if (p->an.tree64_ok && !(p->flags & QG_OPT_GENERIC_TREE)) {
@@ -885,8 +992,8 @@ struct RunCache {
     int device = -2;
     qgemul_plan* plan = nullptr;
     qgemul_desc pd;
-    qgemul_epilogue pe;
-    bool has_pe = false;
+    qgemul_epilogue_cplx pe;          // a real chain is part[0]
+    bool has_pe = false, pe_cplx = false;
     uint32_t pflags = 0;
     enum { NBUF = 6 + 16 };   // 0-5: host-layout A, B, C and packed A, B, C; behind them: the epilogue operands (2 per stage) or, on the
                               // root of a sharded call, the landing buffers of the other bands
@@ -908,7 +1015,6 @@ thread_local RunCacheReaper g_reaper;
 
 // descriptors are compared field by field: padding and reserved bytes of a caller's struct are not part of its meaning, and a
 // descriptor that was not built with `{}` must still hit the cache
-bool same_fmt(const qfmt& x, const qfmt& y) { return x.I == y.I && x.F == y.F && x.S == y.S && x.Q == y.Q && x.O == y.O; }
 bool same_desc(const qgemul_desc& x, const qgemul_desc& y)
 {
     if (x.abi != y.abi || x.transA != y.transA || x.is_complex != y.is_complex || x.cmul != y.cmul || x.M != y.M || x.N != y.N ||
@@ -976,10 +1082,27 @@ void qgemul_run_release(void)
     }
 }
 
+static int run_view(const qgemul_desc* d, const EpView* ev, void* C, const void* A, const void* B, const void* const* E, const qgemul_opts* o);
+
 int qgemul_run_ep(const qgemul_desc* d, const qgemul_epilogue* ep, void* C, const void* A, const void* B, const void* const* E,
                   const qgemul_opts* o)
 {
+    const EpView v = {ep, nullptr, nullptr};
+    return run_view(d, ep ? &v : nullptr, C, A, B, E, o);
+}
+
+int qgemul_run_epc(const qgemul_desc* d, const qgemul_epilogue_cplx* ep, void* C, const void* A, const void* B, const void* const* E,
+                   const qgemul_opts* o)
+{
+    if (!ep) return QG_EINVAL;
+    const EpView v = {&ep->part[0], &ep->part[1], ep->e_complex};
+    return run_view(d, &v, C, A, B, E, o);
+}
+
+static int run_view(const qgemul_desc* d, const EpView* ev, void* C, const void* A, const void* B, const void* const* E, const qgemul_opts* o)
+{
     if (!d || !C || !A || !B) return QG_EINVAL;
+    const qgemul_epilogue* ep = ev ? ev->re : nullptr;
     qgemul_opts opts;
     memset(&opts, 0, sizeof opts);
     opts.device = -1;
@@ -1001,11 +1124,13 @@ int qgemul_run_ep(const qgemul_desc* d, const qgemul_epilogue* ep, void* C, cons
         return qgemul_run_sharded(d, C, A, B, &opts, list, n);
     }
     const bool same_plan = c.plan && c.pflags == opts.flags && same_desc(c.pd, *d) && c.has_pe == (ep != nullptr) &&
-                           (!ep || same_epilogue(c.pe, *ep)) && (opts.device < 0 || opts.device == c.device);
+                           (!ep || (same_epilogue(c.pe.part[0], *ep) && c.pe_cplx == (ev->im != nullptr) &&
+                                    (!ev->im || (same_epilogue(c.pe.part[1], *ev->im) && !memcmp(c.pe.e_complex, ev->e_cplx, ep->n_stages))))) &&
+                           (opts.device < 0 || opts.device == c.device);
     if (!same_plan) {
         // validate before touching the device so that descriptor errors are reported without a GPU
         qgemul_info info;
-        int st = qgemul_classify_ep(d, ep, opts.flags, &info);
+        int st = classify_view(d, ev, opts.flags, &info);
         if (st != QG_OK) return st;
     }
     if (ep)
@@ -1024,11 +1149,13 @@ int qgemul_run_ep(const qgemul_desc* d, const qgemul_epilogue* ep, void* C, cons
     qgemul_ctx* ctx = c.ctx;
     if (!same_plan) {
         if (c.plan) { qgemul_plan_destroy(c.plan); c.plan = nullptr; }
-        st = qgemul_plan_create_ep(ctx, d, ep, opts.flags, &c.plan);
+        st = plan_create_view(ctx, d, ev, opts.flags, &c.plan);
         if (st != QG_OK) { c.plan = nullptr; return st; }
         c.pd = *d;
         c.has_pe = ep != nullptr;
-        if (ep) c.pe = *ep;
+        c.pe_cplx = ev && ev->im;
+        if (ep) c.pe.part[0] = *ep;
+        if (c.pe_cplx) { c.pe.part[1] = *ev->im; memcpy(c.pe.e_complex, ev->e_cplx, sizeof c.pe.e_complex); }
         c.pflags = opts.flags;
     }
     qgemul_plan* p = c.plan;
@@ -1063,20 +1190,35 @@ int qgemul_run_ep(const qgemul_desc* d, const qgemul_epilogue* ep, void* C, cons
         } else {
             qgemul_ep_args ea;
             memset(&ea, 0, sizeof ea);
+            auto raw = [](const void* q, qfmt f) { return (1 + (int)f.I + (int)f.F) <= 32 ? (int64_t) * (const int32_t*)q : *(const int64_t*)q; };
             for (uint32_t k = 0; k < ep->n_stages && !st; ++k) {
-                const qfmt f = ep->stage[k].e;
-                const size_t eb = (1 + (int)f.I + (int)f.F) <= 32 ? 4 : 8;
-                if (ep->stage[k].e_scalar) {
-                    ea.e_scalar[k] = eb == 4 ? (int64_t) * (const int32_t*)E[k] : *(const int64_t*)E[k];
+                const qgemul_ew_stage& sr = ep->stage[k];
+                const qgemul_ew_stage* si = ev->im ? &ev->im->stage[k] : nullptr;
+                const bool cplx = si && ev->e_cplx[k];
+                const bool t_re = sr.op != QG_EW_PASS && !sr.e_scalar, t_im = si && si->op != QG_EW_PASS && !si->e_scalar;
+                if (!t_re && !t_im) {
+                    // scalar operand: one element ({re, im} for a complex one); a real scalar feeds both parts, except where the
+                    // imaginary part's stage takes the zero of the operand's type (real - complex, QuBLAS.h:3686)
+                    if (sr.op != QG_EW_PASS) ea.e_scalar[k] = raw(E[k], sr.e);
+                    if (si && si->op != QG_EW_PASS) {
+                        if (cplx) {
+                            const qfmt f[2] = {sr.e, si->e};
+                            ea.e_scalar_im[k] = raw((const char*)E[k] + qg_host_elem(f, 1).off[1], si->e);
+                        } else {
+                            ea.e_scalar_im[k] = si->op == QG_EW_MUL ? raw(E[k], si->e) : 0;
+                        }
+                    }
                     continue;
                 }
-                const size_t bytesE = (size_t)d->M * (size_t)d->N * eb;
+                const qfmt f[2] = {t_re ? sr.e : si->e, si ? si->e : sr.e};
+                const size_t bytesE = (size_t)d->M * (size_t)d->N * (size_t)qg_host_elem(f, cplx ? 1 : 0).size;
                 void *dE, *pE;
                 if ((st = cache_buffer(c, 6 + 2 * (int)k, bytesE, &dE)) || (st = cache_buffer(c, 7 + 2 * (int)k, (size_t)qgemul_packed_e_bytes(p, (int)k), &pE)))
                     break;
                 if (hipMemcpyAsync(dE, E[k], bytesE, hipMemcpyHostToDevice, s) != hipSuccess) { st = QG_EHIP; break; }
                 if ((st = qgemul_pack_e(p, (int)k, dE, 0, pE))) break;
                 ea.e_packed[k] = pE;
+                // (real - complex with a tensor operand: the imaginary part's stage has the scalar 0, set by the memset above)
             }
             if (st) break;
             if ((st = qgemul_execute_ep(p, pC, pA, pB, &ea))) break;

@@ -56,6 +56,10 @@ __device__ __forceinline__ int64_t qg_ep_load_one(const char* p, int64_t idx, in
 template <class T, int N>
 __device__ __forceinline__ void qg_ep_stage(T (&v)[N], const T (&e)[N], const QEpStage& s)
 {
+    if (s.op == QG_EW_PASS) {
+        qg_step_all<T, N>(v, s.cvt);
+        return;
+    }
     if (s.op == QG_EW_MUL) {
 #pragma unroll
         for (int o = 0; o < N; ++o) v[o] *= e[o];

@@ -4,7 +4,8 @@
 //    (the exact tree kernels).  C, the tensor operands and D share ONE index space (the plan's packed-C layout),
 //    so the pass is linear in memory: every lane handles 16 consecutive elements.  HBM-bound:
 //    (cbytes + sum ebytes + dbytes) bytes per element.
-//  * k_pack_e: a tensor operand in reference layout (column-major M x N, QuBLAS.h:2680-2692) -> that index space.
+//  * k_pack_e: a tensor operand in reference layout (column-major M x N, QuBLAS.h:2680-2692) -> that index space
+//    (one launch per part of a complex operand).
 #include <hip/hip_runtime.h>
 
 #include "qg_eltwise.h"
@@ -56,8 +57,10 @@ __global__ __launch_bounds__(256) void k_eltwise(QEltwiseArgs g)
     }
 }
 
-// host column-major (m fastest) -> packed-C index space; 64 x 64 tile through LDS so that both sides are coalesced
-__global__ __launch_bounds__(256) void k_pack_e(QCGeom c, const char* __restrict__ src, int64_t ld, int src_bytes, char* __restrict__ dst, int ebytes)
+// host column-major (m fastest) -> packed-C index space; 64 x 64 tile through LDS so that both sides are coalesced.
+// A host element is `stride` bytes; this part's raw value sits `off` bytes into it (complex operands: {re, im} structs).
+__global__ __launch_bounds__(256) void k_pack_e(QCGeom c, int part, const char* __restrict__ src, int64_t ld, int stride, int off, int src_bytes,
+                                                char* __restrict__ dst, int ebytes)
 {
     __shared__ int64_t tile[64][65];
     const int64_t nt = (c.N + 63) / 64;
@@ -66,7 +69,10 @@ __global__ __launch_bounds__(256) void k_pack_e(QCGeom c, const char* __restrict
     for (int i = ty; i < 64; i += 4) {
         const int64_t m = tm * 64 + tx, n = tn * 64 + i;
         int64_t v = 0;
-        if (m < c.M && n < c.N) v = src_bytes == 4 ? (int64_t)((const int32_t*)src)[m + n * ld] : ((const int64_t*)src)[m + n * ld];
+        if (m < c.M && n < c.N) {
+            const char* q = src + (m + n * ld) * stride + off;
+            v = src_bytes == 4 ? (int64_t) * (const int32_t*)q : *(const int64_t*)q;
+        }
         tile[tx][i] = v;   // tile[m_local][n_local]
     }
     __syncthreads();
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256) void k_pack_e(QCGeom c, const char* __restrict
     for (int i = ty; i < 64; i += 4) {
         const int ml = m_fast ? tx : i, nl = m_fast ? i : tx;
         const int64_t m = tm * 64 + ml, n = tn * 64 + nl;
-        if (m < c.M && n < c.N) store_one(dst, qg_c_index(c, 0, m, n), ebytes, tile[ml][nl]);
+        if (m < c.M && n < c.N) store_one(dst, qg_c_index(c, part, m, n), ebytes, tile[ml][nl]);
     }
 }
 
@@ -89,12 +95,14 @@ hipError_t qg_launch_eltwise(const QEltwiseArgs& g, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t qg_launch_pack_e(const QCGeom& c, const void* src, int64_t ld, int src_bytes, void* dst, int ebytes, hipStream_t st)
+hipError_t qg_launch_pack_e(const QCGeom& c, int part, const void* src, int64_t ld, int stride, int off, int src_bytes, void* dst, int ebytes,
+                            hipStream_t st)
 {
     const int64_t blocks = ((c.N + 63) / 64) * ((c.M + 63) / 64);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
-    if (hipError_t e = hipMemsetAsync(dst, 0, (size_t)(c.Mp * c.Np) * ebytes, st); e != hipSuccess) return e;  // padding = 0
-    hipLaunchKernelGGL(k_pack_e, dim3((unsigned)blocks), dim3(256), 0, st, c, (const char*)src, ld, src_bytes, (char*)dst, ebytes);
+    // padding = 0 (this part's region of the packed tensor)
+    if (hipError_t e = hipMemsetAsync((char*)dst + (size_t)(part * c.Mp * c.Np) * ebytes, 0, (size_t)(c.Mp * c.Np) * ebytes, st); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_pack_e, dim3((unsigned)blocks), dim3(256), 0, st, c, part, (const char*)src, ld, stride, off, src_bytes, (char*)dst, ebytes);
     return hipGetLastError();
 }

@@ -177,7 +177,8 @@ inline hipError_t qg_lds_attr(const void* fn, int bytes, std::atomic<uint64_t>& 
 
 // element-wise epilogue as its own pass (kernels that do not fuse it) and the operand packer; see qg_eltwise.h
 hipError_t qg_launch_eltwise(const QEltwiseArgs& g, hipStream_t st);
-hipError_t qg_launch_pack_e(const QCGeom& c, const void* src, int64_t ld, int src_bytes, void* dst, int ebytes, hipStream_t st);
+hipError_t qg_launch_pack_e(const QCGeom& c, int part, const void* src, int64_t ld, int stride, int off, int src_bytes, void* dst, int ebytes,
+                            hipStream_t st);
 
 // BitStream export of packed C (qg_pack.hip): n = M*N elements of `width` characters each
 struct QBitsArgs {

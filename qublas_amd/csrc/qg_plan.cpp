@@ -218,7 +218,23 @@ int qg_analyze_ep(qfmt cfmt, const qgemul_epilogue* ep, QEpTable* out, int* max_
         bool ok = true;
         for (uint32_t k = 0; k < ep->n_stages && ok; ++k) {
             const qgemul_ew_stage& s = ep->stage[k];
-            if (s.op < QG_EW_ADD || s.op > QG_EW_MUL) { c.fail(QG_EINVAL, "unknown element-wise op"); ok = false; break; }
+            if (s.op < QG_EW_ADD || s.op > QG_EW_PASS) { c.fail(QG_EINVAL, "unknown element-wise op"); ok = false; break; }
+            if (s.op == QG_EW_PASS) {
+                // the part is carried over in its own format (the imaginary part under a real operand, QuBLAS.h:3654/3670/3701);
+                // only the assignment to the stage's tensor touches it
+                QEpStage& t = out->st[k];
+                memset(&t, 0, sizeof t);
+                t.op = QG_EW_PASS;
+                t.scalar = 1;                       // no operand is read
+                t.ebytes = 1;
+                t.node.q.identity = 1;
+                t.cvt.identity = 1;
+                if (k + 1 < ep->n_stages) {
+                    if (!fmt_ok(c, s.t)) { ok = false; break; }
+                    x = do_cvt(c, x, s.t, &t.cvt);
+                }
+                continue;
+            }
             if (!fmt_ok(c, s.e) || !fmt_ok(c, s.r)) { ok = false; break; }
             Val e;
             e.f = s.e;

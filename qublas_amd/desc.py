@@ -67,7 +67,7 @@ class qgemul_opts(C.Structure):
 
 
 QG_MAX_EW = 4
-EW_ADD, EW_SUB, EW_MUL = 1, 2, 3
+EW_ADD, EW_SUB, EW_MUL, EW_PASS = 1, 2, 3, 4
 
 
 class qgemul_ew_stage(C.Structure):
@@ -79,8 +79,12 @@ class qgemul_epilogue(C.Structure):
     _fields_ = [("n_stages", C.c_uint32), ("reserved", C.c_uint32), ("stage", qgemul_ew_stage * QG_MAX_EW), ("d", qfmt)]
 
 
+class qgemul_epilogue_cplx(C.Structure):
+    _fields_ = [("part", qgemul_epilogue * 2), ("e_complex", C.c_uint8 * QG_MAX_EW), ("reserved", C.c_uint8 * 4)]
+
+
 class qgemul_ep_args(C.Structure):
-    _fields_ = [("e_packed", C.c_void_p * QG_MAX_EW), ("e_scalar", C.c_int64 * QG_MAX_EW)]
+    _fields_ = [("e_packed", C.c_void_p * QG_MAX_EW), ("e_scalar", C.c_int64 * QG_MAX_EW), ("e_scalar_im", C.c_int64 * QG_MAX_EW)]
 
 
 class qgemul_info(C.Structure):
@@ -446,3 +450,69 @@ def lower_epilogue(c: "Qu", stages, d: "Qu") -> qgemul_epilogue:
         ep.stage[k].t = x.c()
     ep.d = d.c()
     return ep
+
+
+# ---- the same after a COMPLEX Qgemul: two part-wise chains (include/qgemul.h, qgemul_epilogue_cplx) ----
+
+@dataclass(frozen=True)
+class EwC:
+    """One lazy tensor operator on a complex running value x.  e: Qcomplex (complex Qadd / Qsub, QuBLAS.h:3549-3589) or
+    Qu (an operator between a complex and a real value: Qmul :3604-3644, Qadd :3648-3676, Qsub :3680-3707).
+    real_tags / imag_tags = realT<...> / imagT<...> (or the two types of the <Qu1, Qu2> form, :3566-3568); tags = loose
+    tags, which a part without its own wrapper sees (the extractor's default realT<toArgs...>, :3551-3552).  complex (+|-) real
+    hands ALL its tags to the one real Qadd / Qsub (:3654, :3670, :3686, :3701): only `tags` applies there."""
+    op: str
+    e: "Elem"
+    tags: TagLike = None
+    real_tags: TagLike = None
+    imag_tags: TagLike = None
+    x_first: bool = True
+    scalar: bool = False
+    into: Optional["Qcomplex"] = None
+
+
+def lower_epilogue_cplx(c: "Qcomplex", stages, d: "Qcomplex") -> qgemul_epilogue_cplx:
+    stages = list(stages)
+    if len(stages) > QG_MAX_EW:
+        raise ValueError("too many element-wise stages")
+    epc = qgemul_epilogue_cplx()
+    x = [c.real, c.imag]
+    opc = {"add": EW_ADD, "sub": EW_SUB, "mul": EW_MUL}
+    for p in range(2):
+        epc.part[p].n_stages = len(stages)
+    for k, st in enumerate(stages):
+        cplx = isinstance(st.e, Qcomplex)
+        if cplx and st.op == "mul":
+            raise ValueError("complex x complex multiplication mixes the parts: not an element-wise epilogue stage")
+        epc.e_complex[k] = 1 if cplx else 0
+        r = [None, None]
+        for p in range(2):
+            sg = epc.part[p].stage[k]
+            e = (st.e.real, st.e.imag)[p] if cplx else st.e
+            own = st.real_tags if p == 0 else st.imag_tags
+            sg.x_first = 1 if st.x_first else 0
+            sg.e_scalar = 1 if st.scalar else 0
+            sg.e = e.c()
+            if cplx or st.op == "mul":
+                t = _pick(own, st.tags)
+            else:
+                t = _tags(st.tags)
+                if p == 1 and (st.op == "add" or st.x_first):
+                    sg.op = EW_PASS                 # the imaginary part is carried over
+                    sg.e_scalar = 1
+                    r[p] = x[p]
+                    sg.r = r[p].c()
+                    continue
+                if p == 1:
+                    sg.e_scalar = 1                 # real - complex: Qsub(zero of the operand's type, x.imag)
+            first, second = (x[p], e) if st.x_first else (e, x[p])
+            r[p] = mul_merge(first, second, t) if st.op == "mul" else add_merge(first, second, t)
+            sg.op = opc[st.op]
+            sg.r = r[p].c()
+        for p in range(2):
+            x[p] = ((st.into.real, st.into.imag)[p] if (st.into is not None and k + 1 < len(stages)) else r[p])
+            epc.part[p].stage[k].t = x[p].c()
+    epc.part[0].d = d.real.c()
+    epc.part[1].d = d.imag.c()
+    return epc
+

@@ -105,6 +105,44 @@ def eltwise_epilogue(j):
     return ep, Qu.from_tuple(j["c"]), E
 
 
+def cplx_eltwise_cases():
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLD, "ref_cplx_eltwise_*.jsonl.gz"))):
+        out.extend(_records(p))
+    return out
+
+
+def cplx_eltwise_epilogue(j):
+    """(qgemul_epilogue_cplx, C type, operand values of the real-part chain, of the imaginary-part chain) of a golden
+    record of oracle/ref_cases_cplx_eltwise.cpp.  The record holds what the reference did: the operator, the operand and
+    the two result formats; which stage each PART runs follows include/qgemul.h's table (complex operand or Qmul: both
+    parts the operator; real operand of Qadd / Qsub: the imaginary part is carried over, or — real - complex — taken
+    from the zero of the operand's type)."""
+    from qublas_amd.desc import EW_ADD, EW_MUL, EW_PASS, EW_SUB, Qcomplex, Qu, qgemul_epilogue_cplx
+    epc = qgemul_epilogue_cplx()
+    E = ([], [])
+    for p in range(2):
+        epc.part[p].n_stages = len(j["stages"])
+        epc.part[p].d = Qu.from_tuple(j["d"][p]).c()
+    for k, s in enumerate(j["stages"]):
+        epc.e_complex[k] = s["e_complex"]
+        for p in range(2):
+            st = epc.part[p].stage[k]
+            st.op, st.x_first, st.e_scalar = s["op"], s["x_first"], s["scalar"]
+            st.e = Qu.from_tuple(s["e"][p]).c()
+            st.r = Qu.from_tuple(s["r"][p]).c()
+            st.t = Qu.from_tuple(s["t"][p]).c()
+            vals = np.asarray(s["Ere"] if (p == 0 or not s["e_complex"]) else s["Eim"], dtype=np.int64)
+            if p == 1 and not s["e_complex"] and s["op"] != EW_MUL:
+                if s["op"] == EW_ADD or s["x_first"]:
+                    st.op, st.e_scalar = EW_PASS, 1
+                else:
+                    st.e_scalar, vals = 1, np.zeros(1, dtype=np.int64)
+            E[p].append(vals)
+    c = Qcomplex(Qu.from_tuple(j["c"][0]), Qu.from_tuple(j["c"][1]))
+    return epc, c, E[0], E[1]
+
+
 def bitstream_cases():
     out = []
     for p in sorted(glob.glob(os.path.join(GOLD, "ref_bitstream_*.jsonl.gz"))):
