@@ -309,6 +309,7 @@ template <typename... A> struct bcT {}; template <typename... A> struct acbdT {}
 template <typename... A> struct abT {}; template <typename... A> struct cdT {}; template <typename... A> struct baT {};
 template <typename... A> struct abcT {}; template <typename... A> struct cdbT {}; template <typename... A> struct badT {};
 template <typename... A> struct ABT {}; template <typename... A> struct BCT {};
+template <typename... A> struct realT {}; template <typename... A> struct imagT {};   // per-part tags of complex Qadd / Qsub / complex x real Qmul (QuBLAS.h:3537-3547)
 
 template <typename... A> struct QgemulAddArgs {};
 template <typename... A> struct QgemulMulArgs {};
@@ -326,6 +327,17 @@ template <template <typename...> class W, typename... All> struct sub_tags {
     };
     template <typename T0, typename... Tail> struct search<T0, Tail...> : search<Tail...> {};
     static constexpr TagSet value = search<All...>::found ? search<All...>::value : parse<All...>::value;
+};
+
+// the tag set one PART of a complex element-wise operator sees: realT<…> / imagT<…> if present, else every argument
+// (QuBLAS.h:3551-3552); two bare scalar types are <realT<first>, imagT<second>> (:3566-3568)
+template <int P, typename... Tags> struct part_tags {
+    static constexpr TagSet value = P == 0 ? sub_tags<realT, Tags...>::value : sub_tags<imagT, Tags...>::value;
+};
+template <int P, int I1, int F1, bool S1, class Q1, class O1, int I2, int F2, bool S2, class Q2, class O2>
+struct part_tags<P, Qu_s<intBits<I1>, fracBits<F1>, isSigned<S1>, QuMode<Q1>, OfMode<O1>>, Qu_s<intBits<I2>, fracBits<F2>, isSigned<S2>, QuMode<Q2>, OfMode<O2>>> {
+    static constexpr TagSet value = P == 0 ? parse<Qu_s<intBits<I1>, fracBits<F1>, isSigned<S1>, QuMode<Q1>, OfMode<O1>>>::value
+                                           : parse<Qu_s<intBits<I2>, fracBits<F2>, isSigned<S2>, QuMode<Q2>, OfMode<O2>>>::value;
 };
 
 template <class E> constexpr Fmt re_fmt() { if constexpr (E::is_complex) return E::realType::fmt; else return E::fmt; }
@@ -490,7 +502,8 @@ void Qgemul(TC& C, const TA& A, const TB& B)
 // QgemulResult<CT> names the element type the Qgemul result WOULD have (C's type above).  Then{Mul,Add,Sub}<Into, tags…>(e)
 // is Qop<tags…>(x, e) with x the running value; ThenRsub is Qsub<tags…>(e, x).  Into = the element type of the tensor
 // the operator's result is assigned to before the next operator (void: the operator's own result type); the last
-// operator's result is assigned to D.  e is a tensor of D's shape or a scalar.  Real GEMMs only.
+// operator's result is assigned to D.  e is a tensor of D's shape or a scalar.  After a complex Qgemul: complex operands
+// for ThenAdd / ThenSub / ThenRsub (realT<…> / imagT<…> tags), real operands for all four; no complex x complex ThenMul.
 template <class CT> struct QgemulResult {};
 
 namespace detail {
@@ -499,14 +512,34 @@ struct EwStage {
     const Operand& e;
     static constexpr int op = OP;
     static constexpr bool x_first = XFIRST;
-    static constexpr bool scalar = requires { Operand::fmt; };   // scalars carry a format, tensors an elem_t
-    static constexpr Fmt efmt = [] { if constexpr (requires { Operand::fmt; }) return Operand::fmt; else return Operand::elem_t::fmt; }();
+    static constexpr bool scalar = !requires { typename Operand::elem_t; };   // tensors have an element type
+    template <class O, bool = !requires { typename O::elem_t; }> struct elem { using type = O; };
+    template <class O> struct elem<O, false> { using type = typename O::elem_t; };
+    using e_t = typename elem<Operand>::type;
+    static constexpr bool e_complex = e_t::is_complex;
+    static constexpr Fmt efmt = re_fmt<e_t>();
     static constexpr Fmt result(Fmt x)
     {
         const Fmt a = XFIRST ? x : efmt, b = XFIRST ? efmt : x;
         return OP == QG_EW_MUL ? merge_mul(a, b, parse<Tags...>::value) : merge_add(a, b, parse<Tags...>::value);
     }
     static constexpr Fmt into(Fmt r) { if constexpr (std::is_void_v<Into>) return r; else return Into::fmt; }
+    // ---- on a complex running value: the stage of part P (include/qgemul.h's table) and its result format
+    template <int P> static constexpr Fmt efmt_part() { return P == 0 ? re_fmt<e_t>() : im_fmt<e_t>(); }
+    template <int P> static constexpr int op_part() { return (P == 1 && !e_complex && OP != QG_EW_MUL && (OP == QG_EW_ADD || XFIRST)) ? int(QG_EW_PASS) : OP; }
+    template <int P> static constexpr bool scalar_part() { return scalar || (P == 1 && !e_complex && OP != QG_EW_MUL); }
+    template <int P> static constexpr Fmt result_part(Fmt x)
+    {
+        if (op_part<P>() == QG_EW_PASS) return x;
+        // complex (+|-) real hands ALL its tags to the one real Qadd / Qsub (QuBLAS.h:3654, :3670, :3686, :3701)
+        const TagSet t = (e_complex || OP == QG_EW_MUL) ? part_tags<P, Tags...>::value : parse<Tags...>::value;
+        const Fmt e = efmt_part<P>(), a = XFIRST ? x : e, b = XFIRST ? e : x;
+        return OP == QG_EW_MUL ? merge_mul(a, b, t) : merge_add(a, b, t);
+    }
+    template <int P> static constexpr Fmt into_part(Fmt r)
+    {
+        if constexpr (std::is_void_v<Into>) return r; else return P == 0 ? re_fmt<Into>() : im_fmt<Into>();
+    }
 };
 template <class... Tags> struct pick_result { using type = void; };
 template <class CT, class... Rest> struct pick_result<QgemulResult<CT>, Rest...> { using type = CT; };
@@ -534,6 +567,37 @@ constexpr qgemul_epilogue lower_chain(Fmt c, Fmt d)
     ep.d = d.c();
     return ep;
 }
+
+template <class... Stages>
+constexpr qgemul_epilogue_cplx lower_chain_cplx(Fmt cre, Fmt cim, Fmt dre, Fmt dim_)
+{
+    static_assert(sizeof...(Stages) <= QG_MAX_EW, "at most QG_MAX_EW element-wise operators");
+    static_assert((!(Stages::e_complex && Stages::op == QG_EW_MUL) && ...), "complex x complex multiplication mixes the parts: not an element-wise stage");
+    qgemul_epilogue_cplx ep{};
+    ep.part[0].n_stages = ep.part[1].n_stages = sizeof...(Stages);
+    Fmt x[2] = {cre, cim};
+    uint32_t k = 0;
+    ([&] {
+        ep.e_complex[k] = Stages::e_complex;
+        auto one = [&]<int P>() {
+            qgemul_ew_stage& s = ep.part[P].stage[k];
+            const Fmt r = Stages::template result_part<P>(x[P]);
+            s.op = uint8_t(Stages::template op_part<P>());
+            s.x_first = Stages::x_first;
+            s.e_scalar = Stages::template scalar_part<P>();
+            s.e = Stages::template efmt_part<P>().c();
+            s.r = r.c();
+            x[P] = Stages::template into_part<P>(r);
+            s.t = x[P].c();
+        };
+        one.template operator()<0>();
+        one.template operator()<1>();
+        ++k;
+    }(), ...);
+    ep.part[0].d = dre.c();
+    ep.part[1].d = dim_.c();
+    return ep;
+}
 } // namespace detail
 
 template <class Into = void, typename... Tags, class Operand> auto ThenMul(const Operand& e) { return detail::EwStage<QG_EW_MUL, true, Into, Operand, Tags...>{e}; }
@@ -547,8 +611,19 @@ constexpr qgemul_epilogue Qgemul_lower_epilogue(const TD&, const Stages&...)
 {
     using CT = typename detail::pick_result<Tags...>::type;
     static_assert(!std::is_void_v<CT>, "Qgemul with element-wise operators needs QgemulResult<CT>: the element type of the Qgemul result");
-    static_assert(!CT::is_complex && !TD::elem_t::is_complex, "element-wise operators: real GEMMs only");
+    static_assert(!CT::is_complex && !TD::elem_t::is_complex, "a complex chain is lowered by Qgemul_lower_epilogue_cplx");
     return detail::lower_chain<Stages...>(CT::fmt, TD::elem_t::fmt);
+}
+// the same after a COMPLEX Qgemul (include/qgemul.h, qgemul_epilogue_cplx): complex operands for ThenAdd / ThenSub / ThenRsub
+// with realT<…> / imagT<…> tags (QuBLAS.h:3549-3589), real operands for all four (:3604-3707)
+template <typename... Tags, class TD, class... Stages>
+constexpr qgemul_epilogue_cplx Qgemul_lower_epilogue_cplx(const TD&, const Stages&...)
+{
+    using CT = typename detail::pick_result<Tags...>::type;
+    static_assert(!std::is_void_v<CT>, "Qgemul with element-wise operators needs QgemulResult<CT>: the element type of the Qgemul result");
+    static_assert(CT::is_complex && TD::elem_t::is_complex, "a complex chain runs from a complex Qgemul result into a complex tensor");
+    using DT = typename TD::elem_t;
+    return detail::lower_chain_cplx<Stages...>(CT::realType::fmt, CT::imagType::fmt, DT::realType::fmt, DT::imagType::fmt);
 }
 
 // D = the element-wise chain applied to A' * B
@@ -558,16 +633,22 @@ void Qgemul(TD& D, const TA& A, const TB& B, const S0& s0, const Stages&... st)
     using CT = typename detail::pick_result<Tags...>::type;
     static_assert(!std::is_void_v<CT>, "Qgemul with element-wise operators needs QgemulResult<CT>");
     const qgemul_desc d = Qgemul_lower_types<Tags...>(std::type_identity<Qu_s<typename TD::size, CT>>{}, std::type_identity<TA>{}, std::type_identity<TB>{});
-    const qgemul_epilogue ep = Qgemul_lower_epilogue<Tags...>(D, s0, st...);
     auto ptr = [](const auto& stage) -> const void* {
-        if constexpr (std::remove_cvref_t<decltype(stage)>::scalar) return &stage.e.data;
+        if constexpr (std::remove_cvref_t<decltype(stage)>::scalar) return &stage.e;   // one element as the tensors store them
         else {
             static_assert(std::is_same_v<typename std::remove_cvref_t<decltype(stage.e)>::size, typename TD::size>, "a tensor operand has D's shape");
             return stage.e.data.data();
         }
     };
     const void* E[QG_MAX_EW] = {ptr(s0), ptr(st)...};
-    const int rc = qgemul_run_ep(&d, &ep, D.data.data(), A.data.data(), B.data.data(), E, nullptr);
+    int rc;
+    if constexpr (CT::is_complex) {
+        const qgemul_epilogue_cplx ep = Qgemul_lower_epilogue_cplx<Tags...>(D, s0, st...);
+        rc = qgemul_run_epc(&d, &ep, D.data.data(), A.data.data(), B.data.data(), E, nullptr);
+    } else {
+        const qgemul_epilogue ep = Qgemul_lower_epilogue<Tags...>(D, s0, st...);
+        rc = qgemul_run_ep(&d, &ep, D.data.data(), A.data.data(), B.data.data(), E, nullptr);
+    }
     if (rc != QG_OK) throw std::runtime_error(std::string("Qgemul: ") + qgemul_strerror(rc));
 }
 

@@ -367,9 +367,13 @@ int qgemul_run_sharded(const qgemul_desc* d, void* C, const void* A, const void*
  * (column-major), with the element string's chunks of `elem_chunk` characters reversed (r2l<elem_chunk>, :4593-4611)
  * and the tensor's chunks of `tensor_chunk` elements reversed (r2l<tensor_chunk>, :4738-4752); chunk 0 = l2r.
  * The element width must be a multiple of elem_chunk and M*N of tensor_chunk (the reference throws / does not terminate
- * otherwise): QG_EINVAL.  Real tensors only (a complex element's string carries "(re, im)" punctuation, :2553-2556).
+ * otherwise): QG_EINVAL.
  * QG_BITS_ASCII writes the M*N*width characters '0' / '1'; QG_BITS_PACKED the same stream 8 characters per byte, first
- * character in bit 7.  For a plan with an epilogue the tensor is D. */
+ * character in bit 7.  For a plan with an epilogue the tensor is D.
+ * Complex tensors: an element's string is "(" + real bits + ", " + imaginary bits + ")" (:2553-2556), width = wr + wi + 4
+ * characters, and r2l<elem_chunk> reverses chunks of THAT string, punctuation included (:4672-4681), so elem_chunk must
+ * divide wr + wi + 4.  QG_BITS_ASCII writes exactly these characters; QG_BITS_PACKED writes only the binary characters of
+ * the stream, in stream order (what the reference's own reader keeps of it, :4779-4781): wr + wi bits per element. */
 enum { QG_BITS_ASCII = 0, QG_BITS_PACKED = 1 };
 int64_t qgemul_bitstream_bytes(const qgemul_plan* p, int format);
 int qgemul_export_bitstream(qgemul_plan* p, const void* packedC, int tensor_chunk, int elem_chunk, int format, void* out_dev);

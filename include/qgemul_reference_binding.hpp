@@ -206,6 +206,9 @@ void Qgemul(TC& C, const TA& A, const TB& B)
 //     Qgemul<…, QgemulResult<CT>>(D, A, B, ThenMul<T1, t1…>(s), ThenAdd<void, t2…>(Bias));
 // Every operator's result type is decltype of the header's own scalar Qmul / Qadd / Qsub<tags…> on the running element
 // type and the operand's element type, so the chain resolves exactly as the three statements above do.
+// After a COMPLEX Qgemul the same spelling takes complex operands for ThenAdd / ThenSub / ThenRsub (realT<…> / imagT<…>
+// tags, QuBLAS.h:3549-3589) and real operands for all four (:3604-3707); the chain is lowered to the two part-wise
+// chains of qgemul_epilogue_cplx.  complex x complex ThenMul does not compile (it mixes the parts).
 template <class CT> struct QgemulResult {};
 
 namespace qgemul_detail {
@@ -230,6 +233,35 @@ struct EwStage {
 template <class... Tags> struct pick_result { using type = void; };
 template <class CT, class... Rest> struct pick_result<QgemulResult<CT>, Rest...> { using type = CT; };
 template <class T, class... Rest> struct pick_result<T, Rest...> : pick_result<Rest...> {};
+
+// complex chains: stage k of the chain of part P (0 = real parts, 1 = imaginary parts) — include/qgemul.h's table
+template <class X> void fill_chain_cplx(qgemul_epilogue_cplx&, uint32_t) {}
+template <class X, class S0, class... Ss>
+void fill_chain_cplx(qgemul_epilogue_cplx& ep, uint32_t k)
+{
+    using e_t = typename S0::e_t;
+    using r_t = typename S0::template r_t<X>;
+    using n_t = typename S0::template next_t<X>;
+    static_assert(X::is_complex && r_t::is_complex && n_t::is_complex, "a complex chain runs on complex tensors");
+    static_assert(!(e_t::is_complex && S0::op == QG_EW_MUL), "complex x complex multiplication mixes the parts: not an element-wise stage");
+    ep.e_complex[k] = e_t::is_complex;
+    qgemul_ew_stage& re = ep.part[0].stage[k];
+    qgemul_ew_stage& im = ep.part[1].stage[k];
+    re.op = im.op = uint8_t(S0::op);
+    re.x_first = im.x_first = S0::x_first;
+    re.e_scalar = im.e_scalar = S0::scalar;
+    re.e = fmt_of<typename parts<e_t>::re>();
+    im.e = fmt_of<typename parts<e_t>::im>();
+    re.r = fmt_of<typename r_t::realType>();
+    im.r = fmt_of<typename r_t::imagType>();
+    re.t = fmt_of<typename n_t::realType>();
+    im.t = fmt_of<typename n_t::imagType>();
+    if constexpr (!e_t::is_complex && S0::op != QG_EW_MUL) {
+        if constexpr (S0::op == QG_EW_ADD || S0::x_first) im.op = QG_EW_PASS;   // the imaginary part is carried over (QuBLAS.h:3654, :3670, :3701)
+        im.e_scalar = 1;                                                        // real - complex: the zero of the operand's type (:3686)
+    }
+    fill_chain_cplx<n_t, Ss...>(ep, k + 1);
+}
 
 template <class X> void fill_chain(qgemul_epilogue&, uint32_t) {}
 template <class X, class S0, class... Ss>
@@ -258,11 +290,26 @@ qgemul_epilogue Qgemul_lower_epilogue(const TD&, const Stages&...)
     using CT = typename qgemul_detail::pick_result<Tags...>::type;
     static_assert(!std::is_void_v<CT>, "Qgemul with element-wise operators needs QgemulResult<CT>: the element type of the Qgemul result");
     static_assert(sizeof...(Stages) <= QG_MAX_EW, "at most QG_MAX_EW element-wise operators");
-    static_assert(!CT::is_complex && !TD::elem_t::is_complex, "element-wise operators: real GEMMs only");
+    static_assert(!CT::is_complex && !TD::elem_t::is_complex, "a complex chain is lowered by Qgemul_lower_epilogue_cplx");
     qgemul_epilogue ep{};
     ep.n_stages = sizeof...(Stages);
     qgemul_detail::fill_chain<CT, Stages...>(ep, 0);
     ep.d = qgemul_detail::fmt_of<typename TD::elem_t>();
+    return ep;
+}
+
+template <typename... Tags, class TD, class... Stages>
+qgemul_epilogue_cplx Qgemul_lower_epilogue_cplx(const TD&, const Stages&...)
+{
+    using CT = typename qgemul_detail::pick_result<Tags...>::type;
+    static_assert(!std::is_void_v<CT>, "Qgemul with element-wise operators needs QgemulResult<CT>: the element type of the Qgemul result");
+    static_assert(sizeof...(Stages) <= QG_MAX_EW, "at most QG_MAX_EW element-wise operators");
+    static_assert(CT::is_complex && TD::elem_t::is_complex, "a complex chain runs from a complex Qgemul result into a complex tensor");
+    qgemul_epilogue_cplx ep{};
+    ep.part[0].n_stages = ep.part[1].n_stages = sizeof...(Stages);
+    qgemul_detail::fill_chain_cplx<CT, Stages...>(ep, 0);
+    ep.part[0].d = qgemul_detail::fmt_of<typename TD::elem_t::realType>();
+    ep.part[1].d = qgemul_detail::fmt_of<typename TD::elem_t::imagType>();
     return ep;
 }
 
@@ -272,13 +319,20 @@ void Qgemul(TD& D, const TA& A, const TB& B, const S0& s0, const Stages&... st)
     using CT = typename qgemul_detail::pick_result<Tags...>::type;
     static_assert(!std::is_void_v<CT>, "Qgemul with element-wise operators needs QgemulResult<CT>");
     const qgemul_desc d = Qgemul_lower_types<Tags...>(std::type_identity<Qu_s<typename TD::size, CT>>{}, std::type_identity<TA>{}, std::type_identity<TB>{});
-    const qgemul_epilogue ep = Qgemul_lower_epilogue<Tags...>(D, s0, st...);
     auto ptr = [](const auto& stage) -> const void* {
-        if constexpr (std::remove_cvref_t<decltype(stage)>::scalar) return &stage.e.data.data;   // ArbiInt<N>::data, QuBLAS.h:353
+        // a scalar is one element as the tensors store them (ArbiInt<N>::data, QuBLAS.h:353; {real, imag} for a complex one, :2512-2513)
+        if constexpr (std::remove_cvref_t<decltype(stage)>::scalar) return &stage.e;
         else return stage.e.data.data();
     };
     const void* E[QG_MAX_EW] = {ptr(s0), ptr(st)...};
-    const int rc = qgemul_run_ep(&d, &ep, D.data.data(), A.data.data(), B.data.data(), E, nullptr);
+    int rc;
+    if constexpr (CT::is_complex) {
+        const qgemul_epilogue_cplx ep = Qgemul_lower_epilogue_cplx<Tags...>(D, s0, st...);
+        rc = qgemul_run_epc(&d, &ep, D.data.data(), A.data.data(), B.data.data(), E, nullptr);
+    } else {
+        const qgemul_epilogue ep = Qgemul_lower_epilogue<Tags...>(D, s0, st...);
+        rc = qgemul_run_ep(&d, &ep, D.data.data(), A.data.data(), B.data.data(), E, nullptr);
+    }
     if (rc != QG_OK) throw std::runtime_error(std::string("Qgemul: ") + qgemul_strerror(rc));
 }
 

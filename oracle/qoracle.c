@@ -423,6 +423,46 @@ int qoracle_bitstream(qfmt f, int64_t n, const int64_t* x, int tensor_chunk, int
     return 0;
 }
 
+/* ---- BitStream export of a COMPLEX tensor ----
+ * A complex element's string is "(" + real.toString() + ", " + imag.toString() + ")" (Qu_s<complex>::toString,
+ * /root/reference/include/QuBLAS.h:2553-2556), wr + wi + 4 characters; TensorString_s::fromQu hands exactly that string to the
+ * element processing (:4672-4681), so r2l<e> reverses e-character chunks of the WHOLE string, punctuation included, and its
+ * length must be a multiple of e; the tensor-level processing is that of a real tensor.  out receives n * (wr + wi + 4)
+ * characters. */
+int qoracle_bitstream_cplx(qfmt fre, qfmt fim, int64_t n, const int64_t* re, const int64_t* im, int tensor_chunk, int elem_chunk, char* out)
+{
+    const int wr = (int)fre.I + (int)fre.F + (fre.S ? 1 : 0), wi = (int)fim.I + (int)fim.F + (fim.S ? 1 : 0);
+    if (wr <= 0 || wr > 64 || wi <= 0 || wi > 64 || tensor_chunk < 0 || elem_chunk < 0) return -1;
+    const int w = wr + wi + 4;
+    if (elem_chunk > 0 && w % elem_chunk) return -1;
+    if (tensor_chunk > 0 && n % tensor_chunk) return -1;
+    char es[136], ts[136];
+    for (int64_t pos = 0; pos < n; ++pos) {
+        int64_t src = pos;
+        if (tensor_chunk > 0) {
+            const int64_t nch = n / tensor_chunk, c = pos / tensor_chunk;
+            src = (nch - 1 - c) * tensor_chunk + pos % tensor_chunk;
+        }
+        const uint64_t a = (uint64_t)re[src], b = (uint64_t)im[src];
+        int k = 0;
+        es[k++] = '(';
+        for (int j = 0; j < wr; ++j) es[k++] = ((a >> (wr - 1 - j)) & 1) ? '1' : '0';
+        es[k++] = ',';
+        es[k++] = ' ';
+        for (int j = 0; j < wi; ++j) es[k++] = ((b >> (wi - 1 - j)) & 1) ? '1' : '0';
+        es[k++] = ')';
+        if (elem_chunk > 0) {
+            const int nch = w / elem_chunk;
+            for (int q = 0; q < nch; ++q)
+                for (int r = 0; r < elem_chunk; ++r) ts[q * elem_chunk + r] = es[(nch - 1 - q) * elem_chunk + r];
+            memcpy(out + pos * w, ts, (size_t)w);
+        } else {
+            memcpy(out + pos * w, es, (size_t)w);
+        }
+    }
+    return 0;
+}
+
 /* ---- element-wise epilogue: the lazy tensor operators applied per element after a Qgemul ----
  * Restates MulExpression / AddExpression / SubExpression::operator[] (/root/reference/include/QuBLAS.h:3795-3798,
  * :3828-3831, :3861-3864: Qop<toArgs...>(autoCall(q1, i), autoCall(q2, i)), a scalar operand used as is

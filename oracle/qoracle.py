@@ -65,6 +65,8 @@ def lib() -> C.CDLL:
         L.qoracle_eltwise.restype = C.c_int
         L.qoracle_eltwise.argtypes = [C.POINTER(qgemul_epilogue), qfmt, C.c_int64, C.POINTER(C.c_int64),
                                       C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.c_int64)]
+        L.qoracle_bitstream_cplx.restype = C.c_int
+        L.qoracle_bitstream_cplx.argtypes = [qfmt, qfmt, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_char_p]
         L.qoracle_bitstream.restype = C.c_int
         L.qoracle_bitstream.argtypes = [qfmt, C.c_int64, C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_char_p]
         L.qoracle_elem_bytes.restype = C.c_int
@@ -144,3 +146,18 @@ def bitstream(f: Qu, x: np.ndarray, tensor_chunk: int = 0, elem_chunk: int = 0) 
     if st != 0:
         raise ValueError("invalid chunk for this tensor / element width")
     return buf.raw
+
+
+def bitstream_cplx(e: Qcomplex, re: np.ndarray, im: np.ndarray, tensor_chunk: int = 0, elem_chunk: int = 0) -> bytes:
+    """The same for a complex tensor: every element is "(re-bits, im-bits)" (QuBLAS.h:2553-2556) and the element-level chunk
+    reversal acts on that whole string."""
+    re = np.ascontiguousarray(re, dtype=np.int64)
+    im = np.ascontiguousarray(im, dtype=np.int64)
+    w = sum(f.intBits + f.fracBits + (1 if f.isSigned else 0) for f in (e.real, e.imag)) + 4
+    buf = C.create_string_buffer(int(re.size) * w)
+    p = C.POINTER(C.c_int64)
+    st = lib().qoracle_bitstream_cplx(e.real.c(), e.imag.c(), re.size, re.ctypes.data_as(p), im.ctypes.data_as(p), tensor_chunk, elem_chunk, buf)
+    if st != 0:
+        raise ValueError("invalid chunk for this tensor / element width")
+    return buf.raw
+

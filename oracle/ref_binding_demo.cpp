@@ -84,6 +84,41 @@ int main()
             for (size_t e = 0; e < 96; ++e) std::printf("%s%lld", e ? "," : "", (long long)d.data[e].data.data);
             std::printf("]}\n");
         }
+        {   // the same after a COMPLEX Qgemul: golden record "scale_cbias_real_sub" (tests/golden/ref_cplx_eltwise_2,
+            // oracle/ref_cases_cplx_eltwise.cpp case3: seeds 81 .. 84, dist 1).  X * (1 + 0i) with K = 1 and every product
+            // sub-operation in C's own part format reproduces the record's tensor; the three operators are a real scalar
+            // scale, a complex bias with a realT<> tag and a real tensor subtraction (the imaginary part is carried over).
+            using r206 = Qu<intBits<20>, fracBits<6>>;
+            using r104 = Qu<intBits<10>, fracBits<4>, QuMode<RND::CONV>, OfMode<SAT::SMGN>>;
+            using cw = Qcomplex<r206, r206>;
+            using cb = Qcomplex<Qu<intBits<5>, fracBits<4>>, Qu<intBits<3>, fracBits<2>>>;
+            using cd = Qcomplex<r104, Qu<intBits<8>, fracBits<2>, QuMode<TRN::TCPL>, OfMode<SAT::ZERO>>>;
+            using cq = Qcomplex<Qu<intBits<7>, fracBits<3>, QuMode<RND::ZERO>, OfMode<WRP::TCPL>>, Qu<intBits<9>, fracBits<1>, QuMode<TRN::SMGN>, OfMode<SAT::SMGN>>>;
+            using s22 = Qu<intBits<2>, fracBits<2>>;
+            using r32 = Qu<intBits<3>, fracBits<2>>;
+            using one_t = Qu<intBits<1>, fracBits<0>, isSigned<false>>;
+            constexpr size_t n = 48;
+            Qu<dim<n, 1>, cw> x;
+            Qu<dim<1, 1>, Qcomplex<one_t, one_t>> one;
+            Qu<dim<n, 1>, cb> bias;
+            Qu<dim<n, 1>, r32> off;
+            Qu<dim<n, 1>, cq> d;
+            for (size_t e = 0; e < n; ++e) {
+                refdrv::set_raw(x.data[e], refdrv::synth<r206>(81, 1, e, 0), refdrv::synth<r206>(81, 1, e, 1));
+                refdrv::set_raw(bias.data[e], refdrv::synth<cb::realType>(83, 1, e, 0), refdrv::synth<cb::imagType>(83, 1, e, 1));
+                off.data[e].data.data = refdrv::synth<r32>(84, 1, e, 0);
+            }
+            refdrv::set_raw(one.data[0], 1, 0);
+            s22 s;
+            s.data.data = refdrv::synth<s22>(82, 1, 0, 0);
+            Qgemul<QgemulMulArgs<BasicComplexMul<acT<r206>, bdT<r206>, adT<r206>, bcT<r206>, acbdT<r206>, adbcT<r206>>>, QgemulResult<cw>>(
+                d, x, one, ThenMul<cw>(s), ThenAdd<cd, realT<r104>>(bias), ThenSub<>(off));
+            std::printf("{\"epilogue_cplx\":\"scale_cbias_real_sub\",\"Dre\":[");
+            for (size_t e = 0; e < n; ++e) std::printf("%s%lld", e ? "," : "", (long long)d.data[e].real.data.data);
+            std::printf("],\"Dim\":[");
+            for (size_t e = 0; e < n; ++e) std::printf("%s%lld", e ? "," : "", (long long)d.data[e].imag.data.data);
+            std::printf("]}\n");
+        }
     } catch (const std::exception& e) {
         std::printf("{\"error\":\"%s\"}\n", e.what());
         return 3;

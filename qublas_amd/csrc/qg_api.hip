@@ -898,16 +898,18 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
     }
 }
 
-static int result_width(const qgemul_plan* p)
+static int result_width(const qgemul_plan* p, int part = 0)
 {
-    const qfmt f = p->has_ep ? p->ep.d : p->desc.c[0];
+    const qfmt f = p->has_ep ? (part ? p->ep_im.d : p->ep.d) : p->desc.c[part];
     return (int)f.I + (int)f.F + (f.S ? 1 : 0);
 }
 
 int64_t qgemul_bitstream_bytes(const qgemul_plan* p, int format)
 {
-    if (!p || p->desc.is_complex) return 0;
-    const int64_t bits = p->desc.M * p->desc.N * (int64_t)result_width(p);
+    if (!p) return 0;
+    const int64_t n = p->desc.M * p->desc.N;
+    // complex: "(re-bits, im-bits)" per element as characters; packed: the binary characters only
+    const int64_t bits = p->desc.is_complex ? n * (result_width(p, 0) + result_width(p, 1) + (format == QG_BITS_PACKED ? 0 : 4)) : n * (int64_t)result_width(p);
     // the packed form is written with 32-bit atomics: sized to whole words
     return format == QG_BITS_PACKED ? ((bits + 7) / 8 + 3) / 4 * 4 : bits;
 }
@@ -915,13 +917,43 @@ int64_t qgemul_bitstream_bytes(const qgemul_plan* p, int format)
 int qgemul_export_bitstream(qgemul_plan* p, const void* packedC, int tensor_chunk, int elem_chunk, int format, void* out_dev)
 {
     if (!p || !packedC || !out_dev || (format != QG_BITS_ASCII && format != QG_BITS_PACKED)) return QG_EINVAL;
-    if (p->desc.is_complex) return QG_EUNSUPPORTED;
-    const int w = result_width(p);
+    const int w = p->desc.is_complex ? result_width(p, 0) + result_width(p, 1) + 4 : result_width(p);
     const int64_t n = p->desc.M * p->desc.N;
     if (w <= 0 || tensor_chunk < 0 || elem_chunk < 0) return QG_EINVAL;
     if (elem_chunk > 0 && w % elem_chunk) return QG_EINVAL;      // the reference throws (QuBLAS.h:4599-4602)
     if (tensor_chunk > 0 && n % tensor_chunk) return QG_EINVAL;  // the reference's loop does not terminate (:4745)
     QG_ON_DEVICE(p->ctx);
+    if (p->desc.is_complex) {
+        const int wr = result_width(p, 0), wi = result_width(p, 1);
+        if (wr <= 0 || wi <= 0 || wr > 64 || wi > 64) return QG_EINVAL;
+        QBitsCplxArgs a;
+        memset(&a, 0, sizeof a);
+        a.c = p->pc;
+        a.packed = (const char*)packedC;
+        a.out = (char*)out_dev;
+        a.width = w;
+        a.nbits = wr + wi;
+        a.tensor_chunk = tensor_chunk;
+        a.packed_bits = format == QG_BITS_PACKED;
+        // the element string "(" re ", " im ")" (QuBLAS.h:2553-2556), MSB first per part, then its chunks reversed (:4593-4611)
+        uint8_t str[136];
+        int k = 0;
+        str[k++] = QG_BITS_LIT_OPEN;
+        for (int j = 0; j < wr; ++j) str[k++] = (uint8_t)(wr - 1 - j);
+        str[k++] = QG_BITS_LIT_COMMA;
+        str[k++] = QG_BITS_LIT_SPACE;
+        for (int j = 0; j < wi; ++j) str[k++] = (uint8_t)(64 + wi - 1 - j);
+        str[k++] = QG_BITS_LIT_CLOSE;
+        if (elem_chunk > 0) {
+            const int nch = w / elem_chunk;
+            for (int q = 0; q < nch; ++q)
+                for (int r = 0; r < elem_chunk; ++r) a.tab[q * elem_chunk + r] = str[(nch - 1 - q) * elem_chunk + r];
+        } else {
+            memcpy(a.tab, str, (size_t)w);
+        }
+        QG_HIP(qg_launch_bitstream_cplx(a, p->ctx->stream));
+        return QG_OK;
+    }
     QBitsArgs a;
     memset(&a, 0, sizeof a);
     a.c = p->pc;

@@ -188,3 +188,14 @@ struct QBitsArgs {
     int32_t width, tensor_chunk, elem_chunk, packed_bits;
 };
 hipError_t qg_launch_bitstream(const QBitsArgs& a, hipStream_t st);
+// ... of a packed COMPLEX C: an element is the string "(re-bits, im-bits)" after its chunk reversal; tab[j] says what output
+// character j of an element is: 0..63 bit k of the real part, 64..127 bit (k - 64) of the imaginary part, 128.. a literal
+enum { QG_BITS_LIT_OPEN = 128, QG_BITS_LIT_COMMA = 129, QG_BITS_LIT_SPACE = 130, QG_BITS_LIT_CLOSE = 131 };
+struct QBitsCplxArgs {
+    QCGeom c;
+    const char* packed;
+    char* out;
+    int32_t width, nbits, tensor_chunk, packed_bits;   // characters per element; binary characters per element (wr + wi)
+    uint8_t tab[136];
+};
+hipError_t qg_launch_bitstream_cplx(const QBitsCplxArgs& a, hipStream_t st);

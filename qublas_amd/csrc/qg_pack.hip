@@ -365,7 +365,59 @@ __global__ __launch_bounds__(256) void k_bitstream(QBitsArgs g)
     }
 }
 
+// The same for a complex tensor (QuBLAS.h:2553-2556: "(" + re + ", " + im + ")"): the host has folded the element-level
+// chunk reversal into g.tab.  ASCII: all width characters; packed: only the binary characters, in stream order.
+__global__ __launch_bounds__(256) void k_bitstream_cplx(QBitsCplxArgs g)
+{
+    const int64_t n = g.c.M * g.c.N;
+    const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pos >= n) return;
+    int64_t src = pos;
+    if (g.tensor_chunk > 0) {
+        const int64_t nch = n / g.tensor_chunk, ch = pos / g.tensor_chunk;
+        src = (nch - 1 - ch) * g.tensor_chunk + pos % g.tensor_chunk;
+    }
+    const int64_t m = src % g.c.M, col = src / g.c.M;
+    const uint64_t re = (uint64_t)load_container(g.packed, qg_c_index(g.c, 0, m, col), g.c.cbytes);
+    const uint64_t im = (uint64_t)load_container(g.packed, qg_c_index(g.c, 1, m, col), g.c.cbytes);
+    if (!g.packed_bits) {
+        char* o = g.out + pos * g.width;
+        for (int j = 0; j < g.width; ++j) {
+            const int t = g.tab[j];
+            char ch;
+            if (t < 64) ch = ((re >> t) & 1) ? '1' : '0';
+            else if (t < 128) ch = ((im >> (t - 64)) & 1) ? '1' : '0';
+            else ch = t == QG_BITS_LIT_OPEN ? '(' : t == QG_BITS_LIT_COMMA ? ',' : t == QG_BITS_LIT_SPACE ? ' ' : ')';
+            o[j] = ch;
+        }
+        return;
+    }
+    uint32_t* o32 = (uint32_t*)g.out;
+    int64_t b = pos * g.nbits;
+    for (int j = 0; j < g.width; ++j) {
+        const int t = g.tab[j];
+        if (t >= 128) continue;
+        const bool one = t < 64 ? ((re >> t) & 1) : ((im >> (t - 64)) & 1);
+        if (one) atomicOr(o32 + (b >> 5), 1u << (((b >> 3) & 3) * 8 + (7 - (b & 7))));
+        ++b;
+    }
+}
+
 } // namespace
+
+hipError_t qg_launch_bitstream_cplx(const QBitsCplxArgs& a, hipStream_t st)
+{
+    const int64_t n = a.c.M * a.c.N;
+    if (n <= 0) return hipSuccess;
+    const int64_t blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
+    if (a.packed_bits) {
+        const int64_t bytes = ((n * a.nbits + 7) / 8 + 3) / 4 * 4;
+        if (hipError_t e = hipMemsetAsync(a.out, 0, (size_t)bytes, st); e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_bitstream_cplx, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
 
 hipError_t qg_launch_bitstream(const QBitsArgs& a, hipStream_t st)
 {

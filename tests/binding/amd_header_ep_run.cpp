@@ -45,6 +45,35 @@ int main()
         std::printf(",\"D\":[");
         for (size_t e = 0; e < D.data.size(); ++e) std::printf("%s%lld", e ? "," : "", (long long)D.data[e].data);
         std::printf("]}\n");
+        {   // the same after a COMPLEX Qgemul (configuration 5's element type, TFComplexMul): a real scalar scale, a complex
+            // bias tensor with per-part tags, and `real tensor - x` (the imaginary part becomes 0 - x.imag)
+            using r63 = Qu<intBits<6>, fracBits<3>, QuMode<RND::POS_INF>, OfMode<SAT::TCPL>>;
+            using r6n3 = Qu<intBits<6>, fracBits<-3>, QuMode<RND::POS_INF>, OfMode<SAT::TCPL>>;
+            using c5 = Qcomplex<r63, r6n3>;
+            using cw = Qcomplex<Qu<intBits<18>, fracBits<6>>, Qu<intBits<18>, fracBits<6>>>;
+            using cbias = Qcomplex<Qu<intBits<5>, fracBits<4>>, Qu<intBits<3>, fracBits<2>>>;
+            using cdst = Qcomplex<Qu<intBits<10>, fracBits<4>, QuMode<RND::CONV>, OfMode<SAT::SMGN>>, Qu<intBits<20>, fracBits<12>>>;   // {int32; int64}
+            using s22 = Qu<intBits<2>, fracBits<2>>;
+            using r54 = Qu<intBits<5>, fracBits<4>>;
+            constexpr size_t cM = 12, cN = 9, cK = 32;
+            Qu<dim<cM, cK>, c5> cA;
+            Qu<dim<cK, cN>, c5> cB;
+            Qu<dim<cM, cN>, cbias> cBias;
+            Qu<dim<cM, cN>, r54> cOff;
+            Qu<dim<cM, cN>, cdst> cD;
+            for (size_t i = 0; i < cM * cK; ++i) { cA[i].real.fill(int64_t((i * 37ull) % 1024) - 512); cA[i].imag.fill(int64_t((i * 11ull + 3) % 16) - 8); }
+            for (size_t i = 0; i < cK * cN; ++i) { cB[i].real.fill(int64_t((i * 53ull + 1) % 1024) - 512); cB[i].imag.fill(int64_t((i * 7ull) % 16) - 8); }
+            for (size_t i = 0; i < cM * cN; ++i) { cBias[i].real.fill(int64_t((i * 29ull) % 1024) - 512); cBias[i].imag.fill(int64_t((i * 13ull) % 64) - 32); cOff[i].fill(int64_t((i * 41ull) % 1024) - 512); }
+            s22 cs;
+            cs.fill(-7);
+            Qgemul<QgemulMulArgs<TFComplexMul<>>, QgemulResult<cw>>(
+                cD, cA, cB, ThenMul<cw, realT<intBits<18>, fracBits<6>>, imagT<intBits<18>, fracBits<6>>>(cs), ThenAdd<void, imagT<intBits<19>>>(cBias), ThenRsub<>(cOff));
+            std::printf("{\"name\":\"cplx_scale_cbias_rsub\",\"M\":%zu,\"N\":%zu,\"K\":%zu,\"elem_bytes\":%zu,\"Dre\":[", cM, cN, cK, sizeof(cdst));
+            for (size_t e = 0; e < cD.data.size(); ++e) std::printf("%s%lld", e ? "," : "", (long long)cD.data[e].real.data);
+            std::printf("],\"Dim\":[");
+            for (size_t e = 0; e < cD.data.size(); ++e) std::printf("%s%lld", e ? "," : "", (long long)cD.data[e].imag.data);
+            std::printf("]}\n");
+        }
     } catch (const std::exception& e) {
         std::printf("{\"error\":\"%s\"}\n", e.what());
         return 3;

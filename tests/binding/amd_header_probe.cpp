@@ -110,5 +110,32 @@ int main()
         Qu<dim<4, 4>, d62w> D2;
         print_epilogue("sub_efirst_tags_wrap", Qgemul_lower_epilogue<QgemulResult<c238>>(D2, ThenRsub<void, fracBits<2>, QuMode<RND::CONV>>(Bias)));
     }
+    {   // complex chains: the operators of five golden cases (tests/golden/ref_cplx_eltwise_*)
+        using r206 = Qu<intBits<20>, fracBits<6>>;
+        using r54 = Qu<intBits<5>, fracBits<4>>;
+        using r32 = Qu<intBits<3>, fracBits<2>>;
+        using s22 = Qu<intBits<2>, fracBits<2>>;
+        using r104 = Qu<intBits<10>, fracBits<4>, QuMode<RND::CONV>, OfMode<SAT::SMGN>>;
+        using r82z = Qu<intBits<8>, fracBits<2>, QuMode<TRN::TCPL>, OfMode<SAT::ZERO>>;
+        using r73w = Qu<intBits<7>, fracBits<3>, QuMode<RND::ZERO>, OfMode<WRP::TCPL>>;
+        using r91s = Qu<intBits<9>, fracBits<1>, QuMode<TRN::SMGN>, OfMode<SAT::SMGN>>;
+        using cw = Qcomplex<r206, r206>;
+        using cb = Qcomplex<r54, r32>;
+        using cd = Qcomplex<r104, r82z>;
+        using cq = Qcomplex<r73w, r91s>;
+        Qu<dim<4, 4>, cd> D;
+        Qu<dim<4, 4>, cq> Dq;
+        Qu<dim<4, 4>, cb> Bias;
+        Qu<dim<4, 4>, r32> Off;
+        cb cs;
+        s22 s;
+        r54 rs;
+        print_epilogue_cplx("cadd_realT_imagT", Qgemul_lower_epilogue_cplx<QgemulResult<cw>>(D, ThenAdd<void, realT<r104>, imagT<intBits<12>, OfMode<SAT::ZERO>>>(Bias)));
+        print_epilogue_cplx("csub_efirst_scalar_two_type_form", Qgemul_lower_epilogue_cplx<QgemulResult<cw>>(D, ThenRsub<void, r104, r82z>(cs)));
+        print_epilogue_cplx("cmul_real_scalar_realT_imagT", Qgemul_lower_epilogue_cplx<QgemulResult<cw>>(D, ThenMul<void, realT<intBits<22>, fracBits<6>>, imagT<r104>>(s)));
+        print_epilogue_cplx("real_scalar_minus_complex_fulltag", Qgemul_lower_epilogue_cplx<QgemulResult<cw>>(Dq, ThenRsub<void, r104>(rs)));
+        print_epilogue_cplx("scale_cbias_real_sub", Qgemul_lower_epilogue_cplx<QgemulResult<cw>>(Dq, ThenMul<cw>(s), ThenAdd<cd, realT<r104>>(Bias), ThenSub<>(Off)));
+        print_epilogue_cplx("cbias_then_real_minus", Qgemul_lower_epilogue_cplx<QgemulResult<cw>>(Dq, ThenAdd<cw>(Bias), ThenRsub<>(rs)));
+    }
     return 0;
 }

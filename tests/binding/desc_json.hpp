@@ -31,3 +31,22 @@ inline void print_epilogue(const char* name, const qgemul_epilogue& ep)
     }
     std::printf("],\"d\":"); print_fmt(ep.d); std::printf("}\n");
 }
+
+// a complex chain (qgemul_epilogue_cplx): per stage and part what tests/golden_io.py's cplx_eltwise_epilogue builds from a
+// golden record of tests/golden/ref_cplx_eltwise_*
+inline void print_epilogue_cplx(const char* name, const qgemul_epilogue_cplx& ep)
+{
+    std::printf("{\"epilogue_cplx\":\"%s\",\"stages\":[", name);
+    for (unsigned k = 0; k < ep.part[0].n_stages; ++k) {
+        std::printf("%s{\"e_complex\":%d,\"parts\":[", k ? "," : "", ep.e_complex[k]);
+        for (int p = 0; p < 2; ++p) {
+            const qgemul_ew_stage& s = ep.part[p].stage[k];
+            std::printf("%s{\"op\":%d,\"x_first\":%d,\"scalar\":%d,\"e\":", p ? "," : "", s.op, s.x_first, s.e_scalar);
+            print_fmt(s.e); std::printf(",\"r\":"); print_fmt(s.r); std::printf(",\"t\":"); print_fmt(s.t); std::printf("}");
+        }
+        std::printf("]}");
+    }
+    std::printf("],\"n\":[%u,%u],\"d\":[", ep.part[0].n_stages, ep.part[1].n_stages);
+    print_fmt(ep.part[0].d); std::printf(","); print_fmt(ep.part[1].d); std::printf("]}\n");
+}
+

@@ -148,3 +148,11 @@ def bitstream_cases():
     for p in sorted(glob.glob(os.path.join(GOLD, "ref_bitstream_*.jsonl.gz"))):
         out.extend(_records(p))
     return out
+
+
+def cplx_bitstream_cases():
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLD, "ref_cplx_bitstream_*.jsonl.gz"))):
+        out.extend(_records(p))
+    return out
+

@@ -39,11 +39,16 @@ def test_reference_header_binding_runs_on_gpu():
         pytest.skip("oracle/_ref/ref_binding_demo was not built (needs the reference header, build container only)")
     out = subprocess.check_output([exe], text=True)
     lines = out.strip().splitlines()
-    assert _check([l for l in lines if '"epilogue"' not in l]) == 4
+    assert _check([l for l in lines if '"epilogue' not in l]) == 4
     # the Then* front-ends on the reference's own types: D of the golden element-wise record, bit for bit
     ep = [json.loads(l) for l in lines if '"epilogue"' in l]
     gold = {j["name"]: j for j in G.eltwise_cases()}
     assert len(ep) == 1 and ep[0]["D"] == gold[ep[0]["epilogue"]]["D"]
+    # ... and after a complex Qgemul (complex tensors, realT<> tag, a real operand whose imaginary part is carried over)
+    epc = [json.loads(l) for l in lines if '"epilogue_cplx"' in l]
+    cgold = {j["name"]: j for j in G.cplx_eltwise_cases()}
+    assert len(epc) == 1
+    assert epc[0]["Dre"] == cgold[epc[0]["epilogue_cplx"]]["Dre"] and epc[0]["Dim"] == cgold[epc[0]["epilogue_cplx"]]["Dim"]
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="needs AMD clang (C++23)")
@@ -73,6 +78,32 @@ def test_standalone_header_all_devices_flag(tmp_path):
     assert _check(out.strip().splitlines()) == 4
 
 
+def _check_complex_chain(r, oracle):
+    """the complex chain of tests/binding/amd_header_ep_run.cpp against oracle GEMM + the Python lowering's part-wise chains"""
+    import numpy as np
+    from qublas_amd.desc import EwC, Qcomplex, Qu, RND, SAT, Tags, TFComplexMul, lower, lower_epilogue_cplx
+    c5 = Qcomplex(Qu(6, 3, True, RND.POS_INF, SAT.TCPL), Qu(6, -3, True, RND.POS_INF, SAT.TCPL))
+    cw = Qcomplex(Qu(18, 6), Qu(18, 6))
+    cbias = Qcomplex(Qu(5, 4), Qu(3, 2))
+    cdst = Qcomplex(Qu(10, 4, True, RND.CONV, SAT.SMGN), Qu(20, 12))
+    M, N, K = r["M"], r["N"], r["K"]
+    assert r["elem_bytes"] == 16
+    d = lower(c5, c5, cw, M, N, K, mul_args=TFComplexMul())
+    epc = lower_epilogue_cplx(cw, [EwC("mul", Qu(2, 2), real_tags=Tags(18, 6), imag_tags=Tags(18, 6), scalar=True, into=cw),
+                                   EwC("add", cbias, imag_tags=Tags(intBits=19)), EwC("sub", Qu(5, 4), x_first=False)], cdst)
+    A = np.zeros(M * K, dtype=oracle.host_dtype(c5)); B = np.zeros(K * N, dtype=oracle.host_dtype(c5))
+    i = np.arange(M * K); A["re"], A["im"] = (i * 37) % 1024 - 512, (i * 11 + 3) % 16 - 8
+    i = np.arange(K * N); B["re"], B["im"] = (i * 53 + 1) % 1024 - 512, (i * 7) % 16 - 8
+    i = np.arange(M * N)
+    bias_re, bias_im, off = (i * 29) % 1024 - 512, (i * 13) % 64 - 32, (i * 41) % 1024 - 512
+    C = oracle.gemm(d, A, B, cw)
+    zero = np.zeros(1, dtype=np.int64)
+    exp_re, exp_im = oracle.eltwise_cplx(epc, cw, C["re"].astype(np.int64), C["im"].astype(np.int64),
+                                         [np.array([-7]), bias_re, off], [np.array([-7]), bias_im, zero])
+    assert r["Dre"] == exp_re.tolist() and r["Dim"] == exp_im.tolist()
+    assert len(set(r["Dre"])) > 8 and len(set(r["Dim"])) > 8
+
+
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="needs AMD clang (C++23)")
 def test_standalone_header_elementwise_chain_on_gpu(tmp_path, oracle):
     """Qgemul<…, QgemulResult<CT>>(D, A, B, ThenMul<…>(s), ThenAdd<>(Bias), ThenRsub<…>(off)) through QuBLAS_amd.h:
@@ -84,8 +115,10 @@ def test_standalone_header_elementwise_chain_on_gpu(tmp_path, oracle):
     subprocess.check_call([CLANG, "-std=c++23", "-O1", "-w", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "binding", "amd_header_ep_run.cpp"), "-o", str(exe), "-L" + lib, "-lqugemm",
                            "-Wl,-rpath," + lib])
-    r = json.loads(subprocess.check_output([str(exe)], text=True).strip().splitlines()[-1])
-    assert "error" not in r, r
+    lines = [json.loads(l) for l in subprocess.check_output([str(exe)], text=True).strip().splitlines()]
+    assert all("error" not in l for l in lines), lines
+    r = next(l for l in lines if l["name"] == "scale_bias_rsub")
+    _check_complex_chain(next(l for l in lines if l["name"] == "cplx_scale_cbias_rsub"), oracle)
     e88 = Qu(8, 8, True, TRN.TCPL, SAT.ZERO)
     ct, t1, bt, st = Qu(15, 8), Qu(16, 8), Qu(10, 6), Qu(3, 3)
     dt = Qu(12, 4, True, RND.CONV, SAT.SMGN)

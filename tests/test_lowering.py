@@ -111,13 +111,15 @@ def test_reference_binding_lowering(tmp_path):
     gold = golden_by_name()
     recs = _probe("ref_binding_probe.cpp", ["-I/root/reference/include"], tmp_path)
     eps = [r for r in recs if "epilogue" in r]
-    recs = [r for r in recs if "epilogue" not in r]
+    epcs = [r for r in recs if "epilogue_cplx" in r]
+    recs = [r for r in recs if "epilogue" not in r and "epilogue_cplx" not in r]
     assert len(recs) >= 12
     for r in recs:
         j = gold[r["name"]]
         for k in KEYS:
             assert r[k] == j[k], (r["name"], k)
     _check_epilogues(eps)
+    _check_cplx_epilogues(epcs)
 
 
 def _check_epilogues(eps):
@@ -136,16 +138,41 @@ def _check_epilogues(eps):
                 assert a["t"] == b["t"], (r["epilogue"], k)
 
 
+def _check_cplx_epilogues(eps):
+    """... and after a complex Qgemul: the two part-wise chains the headers lower to must be the ones the golden records of
+    the reference's complex tensor operators imply (tests/golden_io.py, cplx_eltwise_epilogue)"""
+    import golden_io as G
+    gold = {j["name"]: j for j in G.cplx_eltwise_cases()}
+    assert len(eps) == 6
+    tup = lambda f: [f.I, f.F, f.S, f.Q, f.O]
+    for r in eps:
+        exp, _, _, _ = G.cplx_eltwise_epilogue(gold[r["epilogue_cplx"]])
+        n = exp.part[0].n_stages
+        assert r["n"] == [n, n] and r["d"] == [tup(exp.part[0].d), tup(exp.part[1].d)]
+        for k, st in enumerate(r["stages"]):
+            assert st["e_complex"] == exp.e_complex[k]
+            for p in range(2):
+                a, b = st["parts"][p], exp.part[p].stage[k]
+                assert (a["op"], a["scalar"]) == (b.op, b.e_scalar), (r["epilogue_cplx"], k, p)
+                if b.op != 4:
+                    assert a["x_first"] == b.x_first and a["e"] == tup(b.e), (r["epilogue_cplx"], k, p)
+                assert a["r"] == tup(b.r), (r["epilogue_cplx"], k, p)
+                if k + 1 < n:
+                    assert a["t"] == tup(b.t), (r["epilogue_cplx"], k, p)
+
+
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="needs AMD clang (C++23)")
 def test_standalone_header_lowering(tmp_path):
     """include/QuBLAS_amd.h (own tag API, no reference header) lowers the same tags to the same formats."""
     gold = golden_by_name()
     recs = _probe("amd_header_probe.cpp", [], tmp_path)
     eps = [r for r in recs if "epilogue" in r]
-    recs = [r for r in recs if "epilogue" not in r]
+    epcs = [r for r in recs if "epilogue_cplx" in r]
+    recs = [r for r in recs if "epilogue" not in r and "epilogue_cplx" not in r]
     assert len(recs) >= 12
     for r in recs:
         j = gold[r["name"]]
         for k in KEYS:
             assert r[k] == j[k], (r["name"], k)
     _check_epilogues(eps)
+    _check_cplx_epilogues(epcs)
