@@ -432,7 +432,7 @@ int qoracle_bitstream(qfmt f, int64_t n, const int64_t* x, int tensor_chunk, int
 int qoracle_bitstream_cplx(qfmt fre, qfmt fim, int64_t n, const int64_t* re, const int64_t* im, int tensor_chunk, int elem_chunk, char* out)
 {
     const int wr = (int)fre.I + (int)fre.F + (fre.S ? 1 : 0), wi = (int)fim.I + (int)fim.F + (fim.S ? 1 : 0);
-    if (wr <= 0 || wr > 64 || wi <= 0 || wi > 64 || tensor_chunk < 0 || elem_chunk < 0) return -1;
+    if (wr < 0 || wr > 64 || wi < 0 || wi > 64 || tensor_chunk < 0 || elem_chunk < 0) return -1;   /* a part without bits prints as "" (substr of length 0, :2436) */
     const int w = wr + wi + 4;
     if (elem_chunk > 0 && w % elem_chunk) return -1;
     if (tensor_chunk > 0 && n % tensor_chunk) return -1;

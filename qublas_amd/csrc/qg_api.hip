@@ -925,7 +925,7 @@ int qgemul_export_bitstream(qgemul_plan* p, const void* packedC, int tensor_chun
     QG_ON_DEVICE(p->ctx);
     if (p->desc.is_complex) {
         const int wr = result_width(p, 0), wi = result_width(p, 1);
-        if (wr <= 0 || wi <= 0 || wr > 64 || wi > 64) return QG_EINVAL;
+        if (wr < 0 || wi < 0 || wr > 64 || wi > 64) return QG_EINVAL;   // (a part without bits prints as the empty string)
         QBitsCplxArgs a;
         memset(&a, 0, sizeof a);
         a.c = p->pc;
