@@ -44,7 +44,8 @@ INT8_DENSE_PEAK_OPS = 5.0e15   # MI355X dense int8 MFMA, /opt/skills/guides/MI35
 # at 8 waves per SIMD: 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / 4.3
 VALU_LANE_OPS_PEAK = 256 * 4 * 64 * 2.4e9 / 4.3
 # vector-ALU instructions per MAC of the tree kernels, from rocprofv3 SQ_INSTS_VALU (profiles/: r03d_c3T)
-VALU_PER_MAC = {"c3T": 6.7, "c2T": 6.7, "c5TF": 51.0 / 3.0}   # per real MAC (complex TF: 51 per complex MAC = 3 real MACs); c5B: not profiled
+# (c2T / c3Td: nodes and products that saturate (SAT::TCPL) clamp with one v_med3_i32: 5.3, profiles/r04c_c2T_pmc.json)
+VALU_PER_MAC = {"c3T": 6.7, "c2T": 5.3, "c3Td": 5.3, "c5TF": 51.0 / 3.0}   # per real MAC (complex TF: 51 per complex MAC = 3 real MACs); c5B: not profiled
 HBM_PEAK = 8.0e12
 
 
@@ -121,6 +122,8 @@ def workloads():
                     text="4096^3 Qgemul int<8,8> signed, linear class (MulArgs int17/frac16, AddArgs Qu<29,16>, C Qu<23,8>), 3x3 int8-limb MFMA"),
         "c3T": dict(a=e88z, b=e88z, c=e88z, mul=None, add=None, cfg="configs[2] as literally configured", ref="c3T",
                     text="4096^3 Qgemul int<8,8> signed TRN::TCPL/SAT::ZERO, default tags (tree class), exact tree on the vector ALUs"),
+        "c3Td": dict(a=Qu(8, 8), b=Qu(8, 8), c=Qu(8, 8), mul=None, add=None, cfg="configs[2] with the reference's default modes", ref=None,
+                     text="4096^3 Qgemul int<8,8> signed with the reference's default modes (TRN::TCPL / SAT::TCPL), default tags (tree class)"),
         "c2L": dict(a=e43, b=e43, c=e43, mul=Tags(9, 6), add=[Qu(19, 6)], cfg="configs[1]", ref="c2L",
                     text="1024^3 Qgemul int<4,3> signed, linear class (MulArgs int9/frac6, AddArgs Qu<19,6>), single-limb int8 MFMA"),
         "c2T": dict(a=e43, b=e43, c=e43, mul=None, add=None, cfg="configs[1], default tags", ref=None,
@@ -134,7 +137,7 @@ def workloads():
     }
 
 
-SHAPES = {"c3L": (4096, 4096, 4096), "c3T": (4096, 4096, 4096), "c2L": (1024, 1024, 1024), "c2T": (1024, 1024, 1024),
+SHAPES = {"c3L": (4096, 4096, 4096), "c3T": (4096, 4096, 4096), "c3Td": (4096, 4096, 4096), "c2L": (1024, 1024, 1024), "c2T": (1024, 1024, 1024),
           "c4L": (16384, 16384, 4096), "c5TF": (2048, 2048, 2048), "c5B": (2048, 2048, 2048)}
 
 
@@ -531,7 +534,7 @@ def main(argv=None):
             del hA, hB, hC
         except Exception as e:
             out["layout_steps"] = {"error": str(e)}
-        for name, iters in (("c3T", 10), ("c2L", 200), ("c2T", 20), ("c5TF", 10), ("c5B", 10)):
+        for name, iters in (("c3T", 10), ("c3Td", 10), ("c2L", 200), ("c2T", 20), ("c5TF", 10), ("c5B", 10)):
             if name == args.workload:
                 continue
             try:

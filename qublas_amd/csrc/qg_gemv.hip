@@ -78,7 +78,7 @@ __device__ __forceinline__ int node_fixed(int a, int b, int lo, int hi)
 {
     const int t = a + b;
     if (MODE == 1) return ((unsigned)(t - lo) > (unsigned)(hi - lo)) ? 0 : t;
-    return min(max(t, lo), hi);
+    return qg_clamp_i32(t, lo, hi);
 }
 
 template <int CNT, int MODE>

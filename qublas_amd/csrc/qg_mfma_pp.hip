@@ -334,8 +334,7 @@ __global__ __launch_bounds__(512) void k_mfma_pp(QMfmaArgs g)
             if constexpr (FAST) {
 #pragma unroll
                 for (int o = 0; o < 16; ++o) {
-                    const int32_t x = v[o] >> sh, y = x < clo ? clo : x;
-                    v[o] = y > chi ? chi : y;
+                    v[o] = qg_clamp_i32(v[o] >> sh, clo, chi);
                 }
             } else {
                 qg_step_all<int32_t, 16>(v, st);

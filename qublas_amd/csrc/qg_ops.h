@@ -98,6 +98,18 @@ QG_HD T qg_step(T x, const QStep& s)
     return qg_overflow<T>(qg_round<T>(x, s.d, s.Q), s.O, s.W, s.S, (T)s.lo, (T)s.hi);
 }
 
+// clamp to [lo, hi] (lo <= hi) in ONE VALU instruction.  hipcc forms v_med3_i32 only for compile-time bounds; with run-time
+// bounds it emits v_max_i32 + v_min_i32, and clamps are half of the tree kernels' instruction stream.
+QG_HD int qg_clamp_i32(int x, int lo, int hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_med3_i32 %0, %0, %1, %2" : "+v"(x) : "v"(lo), "v"(hi));   // in place: no copy when the value lives across a branch
+    return x;
+#else
+    return x < lo ? lo : (x > hi ? hi : x);
+#endif
+}
+
 template <class T>
 QG_HD T qg_mul(T a, T b, const QNode& n)
 {

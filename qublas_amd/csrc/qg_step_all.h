@@ -56,9 +56,12 @@ __device__ __forceinline__ void qg_overflow_all(T (&v)[N], const QStep& s)
     typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type U;
     const T lo = (T)s.lo, hi = (T)s.hi;
     switch (s.O) {
-    case QG_SAT_TCPL:   // clamp as max-then-min (lo <= hi always): two VALU instructions, no VCC round trip
+    case QG_SAT_TCPL:   // clamp (lo <= hi always): v_med3_i32 for 32-bit values, max-then-min otherwise; no VCC round trip
 #pragma unroll
-        for (int o = 0; o < N; ++o) { const T a = v[o] < lo ? lo : v[o]; v[o] = a > hi ? hi : a; }
+        for (int o = 0; o < N; ++o) {
+            if constexpr (sizeof(T) == 4) v[o] = (T)qg_clamp_i32((int)v[o], (int)lo, (int)hi);
+            else { const T a = v[o] < lo ? lo : v[o]; v[o] = a > hi ? hi : a; }
+        }
         break;
     case QG_SAT_ZERO: {
         const U span = (U)hi - (U)lo;
@@ -69,7 +72,10 @@ __device__ __forceinline__ void qg_overflow_all(T (&v)[N], const QStep& s)
     case QG_SAT_SMGN: {
         const T l2 = s.S ? (T)(-hi) : (T)0;
 #pragma unroll
-        for (int o = 0; o < N; ++o) { const T a = v[o] < l2 ? l2 : v[o]; v[o] = a > hi ? hi : a; }
+        for (int o = 0; o < N; ++o) {
+            if constexpr (sizeof(T) == 4) v[o] = (T)qg_clamp_i32((int)v[o], (int)l2, (int)hi);
+            else { const T a = v[o] < l2 ? l2 : v[o]; v[o] = a > hi ? hi : a; }
+        }
         break;
     }
     default: // WRP::TCPL

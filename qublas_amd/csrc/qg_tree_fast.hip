@@ -75,7 +75,7 @@ __device__ __forceinline__ void overflow_all(int (&v)[NOUT], const QStep& s)
     switch (s.O) {
     case QG_SAT_TCPL:
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) v[o] = min(max(v[o], lo), hi);
+        for (int o = 0; o < NOUT; ++o) v[o] = qg_clamp_i32(v[o], lo, hi);
         break;
     case QG_SAT_ZERO: {
         const unsigned span = (unsigned)(hi - lo);
@@ -86,7 +86,7 @@ __device__ __forceinline__ void overflow_all(int (&v)[NOUT], const QStep& s)
     case QG_SAT_SMGN: {
         const int l2 = s.S ? -hi : 0;
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) v[o] = min(max(v[o], l2), hi);
+        for (int o = 0; o < NOUT; ++o) v[o] = qg_clamp_i32(v[o], l2, hi);
         break;
     }
     default: // WRP::TCPL
@@ -121,7 +121,7 @@ __device__ __forceinline__ void node_fixed(int (&v)[NOUT], const int (&x)[NOUT],
         }
     } else {
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) v[o] = min(max(x[o] + v[o], flo), fhi);
+        for (int o = 0; o < NOUT; ++o) v[o] = qg_clamp_i32(x[o] + v[o], flo, fhi);
     }
 }
 
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
                                     p = (__mul24(av[i], bhv[j]) + (bias << pd)) >> pd;
                                 }
                                 if (MODE == 1) p = ((unsigned)p > span) ? bias : p;
-                                else p = min(max(p, flo), fhi);
+                                else p = qg_clamp_i32(p, flo, fhi);
                                 v[i * 2 + j] = p;
                             }
                     } else if (SPLIT) {
