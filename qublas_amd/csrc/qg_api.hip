@@ -192,6 +192,12 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
         pc->tm = pc->tn = 0;
     }
     info->kernel = kernel;
+    if (kernel == QG_KERNEL_TREE_CPLX_I32) {
+        // which form of the complex kernel's steps this descriptor gets (tests assert their coverage through it)
+        const int fx = (flags & QG_OPT_RUNTIME_MODES) ? 0 : an->cplx_fixed_ok;
+        snprintf(info->reason, sizeof info->reason, "exact tree evaluation; complex kernel steps: %s",
+                 fx == 2 ? "fixed modes, compact" : fx == 1 ? "fixed modes, table" : "run-time modes");
+    }
     info->limbs[0] = LA;
     info->limbs[1] = LB;
     info->packed_bytes[0] = (int64_t)parts * (pa->limbs ? pa->limbs : 1) * pa->rows_p * pa->K_p * pa->cbytes;

@@ -3,6 +3,7 @@
 
 #include <stdio.h>
 #include <string.h>
+#include <vector>
 
 typedef __int128 I128;
 
@@ -504,6 +505,61 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         for (int p = 0; p < 2; ++p)
             for (uint32_t l = 0; l < d->n_levels; ++l) all = all && ok(T.level_add[p][l].q) && ok(T.level_cvt[p][l]);
         out->cplx_fixed_ok = all ? 1 : 0;
+        // ... and 2 when every step also fits the branch-free forms of QFix (qg_plan.h): the values that enter a
+        // multiplication or an alignment fit 24 bits (v_mul_i32_i24 / v_mad_i32_i24), alignment and exact left shifts are
+        // folded into power-of-two factors of at most 2^22, and no tree node shifts left
+        if (all) {
+            auto b24 = [](qfmt f, int extra) { return 1 + (int)f.I + (int)f.F + extra <= 24; };
+            const bool tf = d->cmul == QG_CMUL_TF;
+            // slot -> (is a multiplication, format of its first operand x, of its second operand y)
+            struct Slot { int idx; bool mul; qfmt x, y; };
+            const qfmt a = d->a[0], b = d->a[1], cc = d->b[0], dd = d->b[1];
+            std::vector<Slot> slots;
+            if (tf) {
+                slots = {{QG_T_AB, false, a, b}, {QG_T_CD, false, cc, dd}, {QG_T_BA, false, b, a},
+                         {QG_T_A, true, d->mul[QG_T_AB], cc}, {QG_T_B, true, d->mul[QG_T_CD], b}, {QG_T_C, true, d->mul[QG_T_BA], dd},
+                         {QG_T_RE, false, d->mul[QG_T_A], d->mul[QG_T_B]}, {QG_T_IM, false, d->mul[QG_T_B], d->mul[QG_T_C]}};
+            } else {
+                slots = {{QG_B_AC, true, a, cc}, {QG_B_BD, true, b, dd}, {QG_B_AD, true, a, dd}, {QG_B_BC, true, b, cc},
+                         {QG_B_RE, false, d->mul[QG_B_AC], d->mul[QG_B_BD]}, {QG_B_IM, false, d->mul[QG_B_AD], d->mul[QG_B_BC]}};
+            }
+            auto fix_of = [](const QStep& q, QFix* f) {   // the rounding / clamp part; false when the step shifts left
+                memset(f, 0, sizeof *f);
+                f->ka = f->kb = 1;
+                if (q.identity) { f->skip = 1; f->lo = INT32_MIN; f->hi = INT32_MAX; return true; }
+                f->lo = (int32_t)q.lo;
+                f->hi = (int32_t)q.hi;
+                if (q.d < 0) return false;
+                f->d = q.d;
+                f->t = q.d > 0 ? (1 << (q.d - 1)) : 0;
+                return true;
+            };
+            bool reg = true;
+            memset(T.fmul, 0, sizeof T.fmul);
+            for (const Slot& sl : slots) {
+                const QNode& n = T.mul[sl.idx];
+                QFix& f = T.fmul[sl.idx];
+                const bool nonneg = fix_of(n.q, &f);
+                const int ls = (!n.q.identity && n.q.d < 0) ? -n.q.d : 0;   // exact left shift after the operation: folded into the factors
+                if (n.q.identity) f.skip = 0;   // (the operation itself still runs; only its rounding / clamp is the identity)
+                (void)nonneg;
+                if (sl.mul) {
+                    f.ka = 1 << ls;
+                    reg = reg && ls <= 22 && b24(sl.x, ls) && b24(sl.y, 0);
+                } else {
+                    f.ka = 1 << (n.sa + ls);
+                    f.kb = 1 << (n.sb + ls);
+                    reg = reg && n.sa + ls <= 22 && n.sb + ls <= 22 && b24(sl.x, 0) && b24(sl.y, 0);
+                }
+            }
+            for (int p = 0; p < 2 && reg; ++p)
+                for (uint32_t l = 0; l < d->n_levels && reg; ++l) {
+                    reg = reg && T.level_add[p][l].sa == 0 && T.level_add[p][l].sb == 0;
+                    reg = reg && fix_of(T.level_add[p][l].q, &T.fadd[p][l]) && fix_of(T.level_cvt[p][l], &T.fcvt[p][l]);
+                    if (T.level_add[p][l].q.identity) T.fadd[p][l].skip = 0;
+                }
+            if (reg) out->cplx_fixed_ok = 2;
+        }
     }
     if (!out->linear_ok)
         snprintf(out->reason, sizeof out->reason, "%s",

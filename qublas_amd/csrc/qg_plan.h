@@ -7,6 +7,16 @@
 #include "../../include/qgemul.h"
 #include "qg_ops.h"
 
+// One fixed-mode step of the complex kernel (qg_tree_cplx.hip, QAnalysis::cplx_fixed_ok == 2) in the form the kernel
+// executes without a branch, 8 dwords = one scalar load:
+//   add / sub slot:  v = (x * ka + t) +/- y * kb;   v >>= d;   v = clamp(v, lo, hi)       (ka, kb = 2^alignment shift)
+//   multiply slot:   v = (x * ka) * y + t;          v >>= d;   v = clamp(v, lo, hi)       (ka = 2^(left shift of an exact product))
+//   tree node:       v = x + v + t;                 v >>= d;   v = clamp(v, lo, hi)
+// t = 2^(d-1) (round half up, RND::POS_INF) or 0; an identity step is d = 0, t = 0 and the full int32 range.
+struct QFix {
+    int32_t ka, kb, t, d, lo, hi, skip, pad;
+};
+
 // everything a kernel needs about the arithmetic, laid out for device reads (plan-owned buffer)
 struct QTreeTable {
     int32_t is_complex, cmul, n_levels, parts;
@@ -15,6 +25,10 @@ struct QTreeTable {
     QStep level_cvt[2][QG_MAX_LEVELS];    // store into the level buffer (identity for real GEMMs)
     QStep leftover[2][QG_MAX_LEVELS];     // odd-leftover copy into level l's buffer
     QStep c_cvt[2];                       // root -> C, valid when the tree has all n_levels levels
+    // complex fixed-mode kernel, register-lean form (valid when QAnalysis::cplx_fixed_ok == 2)
+    QFix fmul[8];
+    QFix fadd[2][QG_MAX_LEVELS];
+    QFix fcvt[2][QG_MAX_LEVELS];
 };
 
 // epilogue of the linear class: exact dot product at frac (Fa+Fb) -> C
@@ -37,7 +51,7 @@ struct QAnalysis {
     int split_s;             // > 0: product evaluated split at its rounding shift
     int mul24_ok;            // multiplies fit v_mul_i32_i24
     int cplx_fast_ok;        // the 32-bit complex tree kernel applies
-    int cplx_fixed_ok;       // ... and every step on the path is RND::POS_INF (or exact) + SAT::TCPL: fixed-mode variant
+    int cplx_fixed_ok;       // ... and every step on the path is RND::POS_INF (or exact) + SAT::TCPL: fixed-mode variant (2: register-resident steps)
     int fast_mode;           // 0 runtime modes; 1 one format everywhere, TCPL + SAT::ZERO; 2 TCPL + SAT::TCPL
     int tree64_ok;           // the 2x2-outputs-per-lane 64-bit tree kernel applies (real, 5..16 levels)
     int gemv_ok;             // the one-column 32-bit tree kernel applies (N = 1, K = 2^p >= 16)

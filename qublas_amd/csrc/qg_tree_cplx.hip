@@ -15,6 +15,7 @@
 // depend on the A element alone and (c+d) on the B element alone, so they are formed once per
 // staged element pair, not once per output.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 
 #include "qg_kernels.h"
 #include "qg_step_all.h"
@@ -76,6 +77,113 @@ __device__ __forceinline__ void node_n(int (&v)[N], const int (&x)[N], const QTr
     step_n<FIXED, N>(v, t->level_cvt[part][l]);
 }
 
+// ---- MODE 2: the compact fixed-mode steps of qg_plan.h (QFix) --------------------------------------------------------
+// One scalar load of 8 dwords per step, no branch on the step's parameters, alignment / exact left shifts folded into
+// 24-bit multiply-adds, the rounding addend into the same instruction, saturation as one v_med3_i32 (lower bound from an
+// SGPR, upper bound moved to a VGPR once per step): 3-4 vector instructions per value and step where the table-driven form
+// above spends 5-7 (it measured 52 per complex MAC of configuration 5).
+// v_mad_i32_i24 written out (hipcc keeps a __mul24 and its addend apart): value * scalar factor + value, value * value + scalar
+__device__ __forceinline__ int mad24_vsv(int a, int k, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int mad24_vvs(int a, int b, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+
+template <int N>
+__device__ __forceinline__ void fx_finish(int (&v)[N], const QFix& f)
+{
+    if (f.d) {   // (wave-uniform; sums of equally aligned values have d == 0)
+#pragma unroll
+        for (int o = 0; o < N; ++o) v[o] >>= f.d;
+    }
+    const int hi = f.hi;
+#pragma unroll
+    for (int o = 0; o < N; ++o) asm("v_med3_i32 %0, %0, %1, %2" : "+v"(v[o]) : "s"(f.lo), "v"(hi));
+}
+// the rounding addend in a VGPR, so that it can ride in a multiply-add next to a scalar factor (one scalar operand per instruction)
+__device__ __forceinline__ int fx_vgpr(int s)
+{
+    int v;
+    asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void fx_addsub(int (&out)[N], const int (&x)[N], const int (&y)[N], const QFix& f, bool sub)
+{
+    const int kb = sub ? -f.kb : f.kb;
+    const int tv = fx_vgpr(f.t);
+#pragma unroll
+    for (int o = 0; o < N; ++o) out[o] = mad24_vsv(y[o], kb, mad24_vsv(x[o], f.ka, tv));
+    fx_finish<N>(out, f);
+}
+template <int N>
+__device__ __forceinline__ void fx_mul(int (&out)[N], const int (&x)[N], const int (&y)[N], const QFix& f)
+{
+    if (f.ka != 1) {   // an exact product that is brought to MORE fraction bits: scale one factor (wave-uniform, rare)
+#pragma unroll
+        for (int o = 0; o < N; ++o) out[o] = mad24_vvs(__mul24(x[o], f.ka), y[o], f.t);
+    } else {
+#pragma unroll
+        for (int o = 0; o < N; ++o) out[o] = mad24_vvs(x[o], y[o], f.t);
+    }
+    fx_finish<N>(out, f);
+}
+template <int N>
+__device__ __forceinline__ void fx_node(int (&v)[N], const int (&x)[N], const QFix& fa, const QFix& fc)
+{
+#pragma unroll
+    for (int o = 0; o < N; ++o) v[o] = x[o] + v[o] + fa.t;   // v_add3_u32
+    fx_finish<N>(v, fa);
+    if (!fc.skip) {   // the level buffer's conversion (identity unless the level type differs from the add's result)
+#pragma unroll
+        for (int o = 0; o < N; ++o) v[o] += fc.t;
+        fx_finish<N>(v, fc);
+    }
+}
+
+// The steps' parameters are loop-invariant; left alone, the compiler hoists all of their scalar loads out of the k loop
+// (16 steps x 8 dwords), runs out of SGPRs and spills them through VGPR lanes.  The load is therefore written out: one
+// s_load_dwordx8 from the scalar cache right where the step runs.
+typedef int fx_v8i __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ QFix fx_at(const QTreeTable* t, unsigned byte_off)
+{
+    fx_v8i r;
+    asm volatile("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(t), "s"(byte_off));
+    QFix f;
+    f.ka = r[0]; f.kb = r[1]; f.t = r[2]; f.d = r[3]; f.lo = r[4]; f.hi = r[5]; f.skip = r[6]; f.pad = 0;
+    return f;
+}
+#define FX_OFF_MUL(slot) ((unsigned)(offsetof(QTreeTable, fmul) + (slot) * sizeof(QFix)))
+#define FX_OFF_ADD(part, l) ((unsigned)(offsetof(QTreeTable, fadd) + ((part) * QG_MAX_LEVELS + (l)) * sizeof(QFix)))
+#define FX_OFF_CVT(part, l) ((unsigned)(offsetof(QTreeTable, fcvt) + ((part) * QG_MAX_LEVELS + (l)) * sizeof(QFix)))
+
+// MODE: 0 run-time modes, 1 fixed modes read from the step table, 2 fixed modes in the compact branch-free form
+template <int MODE, int N>
+__device__ __forceinline__ void op_addsub(int (&out)[N], const int (&x)[N], const int (&y)[N], const QTreeTable* __restrict__ t, int slot, bool sub)
+{
+    if constexpr (MODE == 2) fx_addsub<N>(out, x, y, fx_at(t, FX_OFF_MUL(slot)), sub);
+    else addsub_n<MODE == 1, N>(out, x, y, t->mul[slot], sub);
+}
+template <int MODE, int N>
+__device__ __forceinline__ void op_mul(int (&out)[N], const int (&x)[N], const int (&y)[N], const QTreeTable* __restrict__ t, int slot)
+{
+    if constexpr (MODE == 2) fx_mul<N>(out, x, y, fx_at(t, FX_OFF_MUL(slot)));
+    else mul_n<MODE == 1, N>(out, x, y, t->mul[slot]);
+}
+template <int MODE, int N>
+__device__ __forceinline__ void op_node(int (&v)[N], const int (&x)[N], const QTreeTable* __restrict__ t, int part, int l)
+{
+    if constexpr (MODE == 2) fx_node<N>(v, x, fx_at(t, FX_OFF_ADD(part, l)), fx_at(t, FX_OFF_CVT(part, l)));
+    else node_n<MODE == 1, N>(v, x, t, part, l);
+}
+
 struct QTreeCplxArgs {
     const QTreeTable* tab;
     const int32_t* A;  // [2][M][K]
@@ -85,7 +193,7 @@ struct QTreeCplxArgs {
     int32_t cbytes;
 };
 
-template <int MAXL, bool FIXED>
+template <int MAXL, int MODE>
 __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
 {
     __shared__ __attribute__((aligned(16))) int sA[2][TMB][PITCH];
@@ -163,27 +271,27 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
                         }
                     if (tf) {
                         int ab2[2], ba2[2], cd2[2];
-                        addsub_n<FIXED, 2>(ab2, ar, ai, tab->mul[QG_T_AB], false);  // (a+b), per A element
-                        addsub_n<FIXED, 2>(ba2, ai, ar, tab->mul[QG_T_BA], true);   // (b-a), per A element
-                        addsub_n<FIXED, 2>(cd2, br, bi, tab->mul[QG_T_CD], false);  // (c+d), per B element
+                        op_addsub<MODE, 2>(ab2, ar, ai, tab, QG_T_AB, false);  // (a+b), per A element
+                        op_addsub<MODE, 2>(ba2, ai, ar, tab, QG_T_BA, true);   // (b-a), per A element
+                        op_addsub<MODE, 2>(cd2, br, bi, tab, QG_T_CD, false);  // (c+d), per B element
                         int ab[4], ba[4], cd[4], PA[4], PB[4], PC[4];
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
 #pragma unroll
                             for (int j = 0; j < 2; ++j) { ab[i * 2 + j] = ab2[i]; ba[i * 2 + j] = ba2[i]; cd[i * 2 + j] = cd2[j]; }
-                        mul_n<FIXED, 4>(PA, ab, yr, tab->mul[QG_T_A]);
-                        mul_n<FIXED, 4>(PB, cd, xi, tab->mul[QG_T_B]);
-                        mul_n<FIXED, 4>(PC, ba, yi, tab->mul[QG_T_C]);
-                        addsub_n<FIXED, 4>(v[0], PA, PB, tab->mul[QG_T_RE], true);
-                        addsub_n<FIXED, 4>(v[1], PB, PC, tab->mul[QG_T_IM], true);
+                        op_mul<MODE, 4>(PA, ab, yr, tab, QG_T_A);
+                        op_mul<MODE, 4>(PB, cd, xi, tab, QG_T_B);
+                        op_mul<MODE, 4>(PC, ba, yi, tab, QG_T_C);
+                        op_addsub<MODE, 4>(v[0], PA, PB, tab, QG_T_RE, true);
+                        op_addsub<MODE, 4>(v[1], PB, PC, tab, QG_T_IM, true);
                     } else {
                         int ac[4], bd[4], ad[4], bc[4];
-                        mul_n<FIXED, 4>(ac, xr, yr, tab->mul[QG_B_AC]);
-                        mul_n<FIXED, 4>(bd, xi, yi, tab->mul[QG_B_BD]);
-                        mul_n<FIXED, 4>(ad, xr, yi, tab->mul[QG_B_AD]);
-                        mul_n<FIXED, 4>(bc, xi, yr, tab->mul[QG_B_BC]);
-                        addsub_n<FIXED, 4>(v[0], ac, bd, tab->mul[QG_B_RE], true);
-                        addsub_n<FIXED, 4>(v[1], ad, bc, tab->mul[QG_B_IM], false);
+                        op_mul<MODE, 4>(ac, xr, yr, tab, QG_B_AC);
+                        op_mul<MODE, 4>(bd, xi, yi, tab, QG_B_BD);
+                        op_mul<MODE, 4>(ad, xr, yi, tab, QG_B_AD);
+                        op_mul<MODE, 4>(bc, xi, yr, tab, QG_B_BC);
+                        op_addsub<MODE, 4>(v[0], ac, bd, tab, QG_B_RE, true);
+                        op_addsub<MODE, 4>(v[1], ad, bc, tab, QG_B_IM, false);
                     }
                     // ---- lower four levels (compile-time leaf index)
 #pragma unroll
@@ -192,22 +300,22 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
 #pragma unroll
                             for (int o = 0; o < 4; ++o) low[p][0][o] = v[p][o];
                         } else {
-                            node_n<FIXED, 4>(v[p], low[p][0], tab, p, 0);
+                            op_node<MODE, 4>(v[p], low[p][0], tab, p, 0);
                             if ((kk & 2) == 0) {
 #pragma unroll
                                 for (int o = 0; o < 4; ++o) low[p][1][o] = v[p][o];
                             } else {
-                                node_n<FIXED, 4>(v[p], low[p][1], tab, p, 1);
+                                op_node<MODE, 4>(v[p], low[p][1], tab, p, 1);
                                 if ((kk & 4) == 0) {
 #pragma unroll
                                     for (int o = 0; o < 4; ++o) low[p][2][o] = v[p][o];
                                 } else {
-                                    node_n<FIXED, 4>(v[p], low[p][2], tab, p, 2);
+                                    op_node<MODE, 4>(v[p], low[p][2], tab, p, 2);
                                     if ((kk & 8) == 0) {
 #pragma unroll
                                         for (int o = 0; o < 4; ++o) low[p][3][o] = v[p][o];
                                     } else {
-                                        node_n<FIXED, 4>(v[p], low[p][3], tab, p, 3);
+                                        op_node<MODE, 4>(v[p], low[p][3], tab, p, 3);
                                     }
                                 }
                             }
@@ -227,8 +335,8 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
                             for (int o = 0; o < 4; ++o) up[p][u][o] = v[p][o];
                         parked = true;
                     } else {
-                        node_n<FIXED, 4>(v[0], up[0][u], tab, 0, 4 + u);
-                        node_n<FIXED, 4>(v[1], up[1][u], tab, 1, 4 + u);
+                        op_node<MODE, 4>(v[0], up[0][u], tab, 0, 4 + u);
+                        op_node<MODE, 4>(v[1], up[1][u], tab, 1, 4 + u);
                     }
                 }
             }
@@ -266,12 +374,16 @@ hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, i
     const int64_t blocks = ((M + TMB - 1) / TMB) * ((N + TNB - 1) / TNB);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
-    if (fixed) {
-        if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((k_tree_cplx<16, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    // fixed: 0 run-time modes; 1 fixed modes, steps read from the step table; 2 fixed modes, compact branch-free steps
+    if (fixed == 2) {
+        if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_tree_cplx<16, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    } else if (fixed) {
+        if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12, 1>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_tree_cplx<16, 1>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     } else {
-        if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12, false>), dim3((unsigned)blocks), dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((k_tree_cplx<16, false>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+        if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12, 0>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_tree_cplx<16, 0>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     }
     return hipGetLastError();
 }

@@ -218,6 +218,35 @@ def test_complex_fast_kernel_tags_and_levels(oracle):
         assert fields_equal(a, b)
 
 
+def test_complex_fixed_mode_step_forms(oracle):
+    """RND::POS_INF + SAT::TCPL everywhere (BASELINE configuration 5's modes): the complex kernel runs its steps in the
+    compact branch-free form (one scalar load per step, alignment and exact left shifts folded into 24-bit multiply-adds,
+    one v_med3_i32 per value) when every step fits it, else in the table-driven fixed form; both must equal the oracle and
+    the run-time-mode kernel.  The planner reports the form in info.reason."""
+    P = lambda i, f: Qu(i, f, True, RND.POS_INF, SAT.TCPL)
+    c5 = Qcomplex(P(6, 3), P(6, -3))
+    cases = [
+        # (elements, C, lowering keywords, expected form)
+        (c5, c5, dict(mul_args=TFComplexMul()), "fixed modes, compact"),                         # configuration 5 itself
+        (c5, c5, dict(mul_args=BasicComplexMul()), "fixed modes, compact"),
+        (c5, Qcomplex(P(12, 4), P(10, 2)), dict(mul_args=TFComplexMul(abcT=Tags(9, 5), ABT=Tags(11, 2)), add_args=[Qcomplex(P(14, 0), P(12, -3))]),
+         "fixed modes, compact"),                                                                 # tags, one level type (fewer fraction bits: rounding nodes)
+        (c5, Qcomplex(P(12, 4), P(10, 2)), dict(mul_args=BasicComplexMul(), add_args=[Qcomplex(P(10, 2), P(10, 0)), Qcomplex(P(14, 5), P(12, 3))]),
+         "fixed modes, table"),                                                                   # level 1 has MORE fraction bits than level 0: a node shifts left
+        (c5, Qcomplex(P(12, 4), P(10, 2)), dict(mul_args=BasicComplexMul(acT=Tags(20, 8))), "fixed modes, table"),   # a 29-bit product format: beyond v_mad_i32_i24's operands
+    ]
+    for K in (64, 250):
+        for e, ec, kw, form in cases:
+            M, N = 45, 38
+            d = lower(e, e, ec, M, N, K, **kw)
+            info = capi.classify(d)
+            assert capi.KERNEL_NAMES[info.kernel] == "tree_cplx_i32" and info.reason.decode().endswith(form), (info.reason, form)
+            assert capi.classify(d, capi.OPT_RUNTIME_MODES).reason.decode().endswith("run-time modes")
+            a = _vs_oracle(oracle, e, e, ec, M, N, K, expect_kernel="tree_cplx_i32", **kw)
+            b = _vs_oracle(oracle, e, e, ec, M, N, K, flags=capi.OPT_RUNTIME_MODES, expect_kernel="tree_cplx_i32", **kw)
+            assert fields_equal(a, b)
+
+
 def test_leading_dimensions(oracle):
     M, N, K = 70, 50, 96
     ea = eb = E43
