@@ -505,10 +505,20 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         for (int p = 0; p < 2; ++p)
             for (uint32_t l = 0; l < d->n_levels; ++l) all = all && ok(T.level_add[p][l].q) && ok(T.level_cvt[p][l]);
         out->cplx_fixed_ok = all ? 1 : 0;
-        // ... and 2 when every step also fits the branch-free forms of QFix (qg_plan.h): the values that enter a
-        // multiplication or an alignment fit 24 bits (v_mul_i32_i24 / v_mad_i32_i24), alignment and exact left shifts are
-        // folded into power-of-two factors of at most 2^22, and no tree node shifts left
-        if (all) {
+        // ... and 2 when every step fits the branch-free forms of QFix (qg_plan.h): a rounding that is "add a constant, shift
+        // right" — TRN::TCPL (+0; the reference's default QuMode), RND::POS_INF (+2^(d-1)), RND::NEG_INF (+2^(d-1) - 1) — and an
+        // overflow that is one clamp — SAT::TCPL (the reference's default OfMode) or SAT::SMGN ([-hi, hi]); the values that
+        // enter a multiplication or an alignment fit 24 bits (v_mad_i32_i24), alignment and exact left shifts are folded
+        // into power-of-two factors of at most 2^22
+        auto ok2 = [](const QStep& q) {
+            return q.identity || (q.d >= -22 && q.d <= 29 && (q.O == QG_SAT_TCPL || q.O == QG_SAT_SMGN) &&
+                                  (q.d <= 0 || q.Q == QG_RND_POS_INF || q.Q == QG_TRN_TCPL || q.Q == QG_RND_NEG_INF));
+        };
+        bool all2 = true;
+        for (int i = 0; i < ns; ++i) all2 = all2 && ok2(T.mul[i].q);
+        for (int p = 0; p < 2; ++p)
+            for (uint32_t l = 0; l < d->n_levels; ++l) all2 = all2 && ok2(T.level_add[p][l].q) && ok2(T.level_cvt[p][l]);
+        if (all2) {
             auto b24 = [](qfmt f, int extra) { return 1 + (int)f.I + (int)f.F + extra <= 24; };
             const bool tf = d->cmul == QG_CMUL_TF;
             // slot -> (is a multiplication, format of its first operand x, of its second operand y)
@@ -527,11 +537,11 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                 memset(f, 0, sizeof *f);
                 f->ka = f->kb = 1;
                 if (q.identity) { f->skip = 1; f->lo = INT32_MIN; f->hi = INT32_MAX; return true; }
-                f->lo = (int32_t)q.lo;
+                f->lo = q.O == QG_SAT_SMGN ? (q.S ? -(int32_t)q.hi : 0) : (int32_t)q.lo;
                 f->hi = (int32_t)q.hi;
-                if (q.d < 0) return false;
+                if (q.d < 0) { f->ls = -q.d; return false; }
                 f->d = q.d;
-                f->t = q.d > 0 ? (1 << (q.d - 1)) : 0;
+                f->t = q.d == 0 ? 0 : q.Q == QG_RND_POS_INF ? (1 << (q.d - 1)) : q.Q == QG_RND_NEG_INF ? (1 << (q.d - 1)) - 1 : 0;
                 return true;
             };
             bool reg = true;
@@ -555,7 +565,8 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
             for (int p = 0; p < 2 && reg; ++p)
                 for (uint32_t l = 0; l < d->n_levels && reg; ++l) {
                     reg = reg && T.level_add[p][l].sa == 0 && T.level_add[p][l].sb == 0;
-                    reg = reg && fix_of(T.level_add[p][l].q, &T.fadd[p][l]) && fix_of(T.level_cvt[p][l], &T.fcvt[p][l]);
+                    fix_of(T.level_add[p][l].q, &T.fadd[p][l]);   // (a left shift at a node is QFix::ls)
+                    fix_of(T.level_cvt[p][l], &T.fcvt[p][l]);
                     if (T.level_add[p][l].q.identity) T.fadd[p][l].skip = 0;
                 }
             if (reg) out->cplx_fixed_ok = 2;

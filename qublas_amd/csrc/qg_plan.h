@@ -11,10 +11,11 @@
 // executes without a branch, 8 dwords = one scalar load:
 //   add / sub slot:  v = (x * ka + t) +/- y * kb;   v >>= d;   v = clamp(v, lo, hi)       (ka, kb = 2^alignment shift)
 //   multiply slot:   v = (x * ka) * y + t;          v >>= d;   v = clamp(v, lo, hi)       (ka = 2^(left shift of an exact product))
-//   tree node:       v = x + v + t;                 v >>= d;   v = clamp(v, lo, hi)
-// t = 2^(d-1) (round half up, RND::POS_INF) or 0; an identity step is d = 0, t = 0 and the full int32 range.
+//   tree node:       v = x + v + t;   v <<= ls;     v >>= d;   v = clamp(v, lo, hi)       (ls: a level type with MORE fraction bits)
+// t = the rounding mode's addend (TRN::TCPL 0, RND::POS_INF 2^(d-1), RND::NEG_INF 2^(d-1) - 1); an identity step is d = 0,
+// t = 0 and the full int32 range.
 struct QFix {
-    int32_t ka, kb, t, d, lo, hi, skip, pad;
+    int32_t ka, kb, t, d, lo, hi, skip, ls;
 };
 
 // everything a kernel needs about the arithmetic, laid out for device reads (plan-owned buffer)

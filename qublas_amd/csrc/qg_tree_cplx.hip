@@ -140,10 +140,19 @@ __device__ __forceinline__ void fx_node(int (&v)[N], const int (&x)[N], const QF
 {
 #pragma unroll
     for (int o = 0; o < N; ++o) v[o] = x[o] + v[o] + fa.t;   // v_add3_u32
+    if (fa.ls) {      // (wave-uniform, rare: the add's result type has more fraction bits than its operands)
+#pragma unroll
+        for (int o = 0; o < N; ++o) v[o] = (int)((unsigned)v[o] << fa.ls);
+    }
     fx_finish<N>(v, fa);
     if (!fc.skip) {   // the level buffer's conversion (identity unless the level type differs from the add's result)
+        if (fc.ls) {
 #pragma unroll
-        for (int o = 0; o < N; ++o) v[o] += fc.t;
+            for (int o = 0; o < N; ++o) v[o] = (int)((unsigned)v[o] << fc.ls);
+        } else {
+#pragma unroll
+            for (int o = 0; o < N; ++o) v[o] += fc.t;
+        }
         fx_finish<N>(v, fc);
     }
 }
@@ -157,7 +166,7 @@ __device__ __forceinline__ QFix fx_at(const QTreeTable* t, unsigned byte_off)
     fx_v8i r;
     asm volatile("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(t), "s"(byte_off));
     QFix f;
-    f.ka = r[0]; f.kb = r[1]; f.t = r[2]; f.d = r[3]; f.lo = r[4]; f.hi = r[5]; f.skip = r[6]; f.pad = 0;
+    f.ka = r[0]; f.kb = r[1]; f.t = r[2]; f.d = r[3]; f.lo = r[4]; f.hi = r[5]; f.skip = r[6]; f.ls = r[7];
     return f;
 }
 #define FX_OFF_MUL(slot) ((unsigned)(offsetof(QTreeTable, fmul) + (slot) * sizeof(QFix)))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Opt-in fuzz of the complex tree kernel's FIXED-mode step forms on an MI355X (not collected by pytest): complex descriptors
-whose every step is RND::POS_INF (or exact) + SAT::TCPL — random part formats (negative fracBits included), Basic / TF with
+whose every step rounds by "add a constant, shift right" (TRN::TCPL, RND::POS_INF, RND::NEG_INF) and overflows by one clamp
+(SAT::TCPL, SAT::SMGN) — random part formats (negative fracBits included), Basic / TF with
 random sub-operation tags, 0..2 level types, any K >= 17 — so that the planner picks the compact branch-free steps, or the
 table-driven fixed steps where a condition of the compact form fails (left shifts at tree nodes, per-level formats).  Each
 case: GPU against the oracle, and against the same plan with run-time modes (QG_OPT_RUNTIME_MODES).
@@ -17,7 +18,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import qoracle as oracle  # noqa: E402
 from qublas_amd import capi  # noqa: E402
-from qublas_amd.desc import BasicComplexMul, Qcomplex, Qu, RND, SAT, Tags, TFComplexMul, lower  # noqa: E402
+from qublas_amd.desc import BasicComplexMul, Qcomplex, Qu, RND, SAT, TRN, Tags, TFComplexMul, lower  # noqa: E402
 
 
 def rq(rng, bits):
@@ -27,7 +28,9 @@ def rq(rng, bits):
     if rng.random() < 0.25:
         shift = rng.randint(1, 3)
         i, f = i + shift, f - shift          # negative or smaller fracBits at the same width
-    return Qu(i, f, rng.random() < 0.85, RND.POS_INF, SAT.TCPL)
+    # modes the compact steps cover: "add a constant, shift right" roundings and one-clamp overflows (mixed modes between
+    # two operands merge to the reference's defaults TRN::TCPL / SAT::TCPL, which are among them)
+    return Qu(i, f, rng.random() < 0.85, rng.choice([RND.POS_INF, RND.POS_INF, TRN.TCPL, TRN.TCPL, RND.NEG_INF]), rng.choice([SAT.TCPL, SAT.TCPL, SAT.SMGN]))
 
 
 def rtag(rng, like):

@@ -232,8 +232,13 @@ def test_complex_fixed_mode_step_forms(oracle):
         (c5, Qcomplex(P(12, 4), P(10, 2)), dict(mul_args=TFComplexMul(abcT=Tags(9, 5), ABT=Tags(11, 2)), add_args=[Qcomplex(P(14, 0), P(12, -3))]),
          "fixed modes, compact"),                                                                 # tags, one level type (fewer fraction bits: rounding nodes)
         (c5, Qcomplex(P(12, 4), P(10, 2)), dict(mul_args=BasicComplexMul(), add_args=[Qcomplex(P(10, 2), P(10, 0)), Qcomplex(P(14, 5), P(12, 3))]),
-         "fixed modes, table"),                                                                   # level 1 has MORE fraction bits than level 0: a node shifts left
+         "fixed modes, compact"),                                                                 # level 1 has MORE fraction bits than level 0: a node shifts left
         (c5, Qcomplex(P(12, 4), P(10, 2)), dict(mul_args=BasicComplexMul(acT=Tags(20, 8))), "fixed modes, table"),   # a 29-bit product format: beyond v_mad_i32_i24's operands
+        # the reference's DEFAULT modes (TRN::TCPL / SAT::TCPL), RND::NEG_INF and SAT::SMGN are compact too; RND::CONV is not fixed at all
+        (Qcomplex(Qu(6, 3), Qu(6, -3)), Qcomplex(Qu(9, 3), Qu(9, 1)), dict(mul_args=TFComplexMul()), "fixed modes, compact"),
+        (Qcomplex(Qu(5, 4, True, RND.NEG_INF, SAT.SMGN), Qu(6, 2, True, RND.NEG_INF, SAT.SMGN)), Qcomplex(Qu(8, 2, True, RND.NEG_INF, SAT.SMGN), Qu(8, 2, True, TRN.TCPL, SAT.TCPL)),
+         dict(mul_args=BasicComplexMul(), add_args=[Qcomplex(Qu(12, 3, True, RND.NEG_INF, SAT.SMGN), Qu(12, 1, True, RND.NEG_INF, SAT.SMGN))]), "fixed modes, compact"),
+        (Qcomplex(Qu(6, 3, True, RND.CONV), Qu(6, 3, True, RND.CONV)), Qcomplex(Qu(9, 3), Qu(9, 1)), dict(mul_args=TFComplexMul()), "run-time modes"),
     ]
     for K in (64, 250):
         for e, ec, kw, form in cases:
