@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["qg_api.hip", "qg_pack.hip", "qg_eltwise.hip", "qg_tree.hip", "qg_tree_fast.hip", "qg_tree64.hip", "qg_tree_cplx.hip", "qg_gemv.hip", "qg_mfma.hip", "qg_mfma_pp.hip", "qg_mfma_ppl.hip", "qg_plan.cpp"]
-HEADERS = ["qg_ops.h", "qg_plan.h", "qg_kernels.h", "qg_step_all.h", "qg_eltwise.h", "qg_eltwise_args.h", os.path.join("..", "..", "include", "qgemul.h")]
+HEADERS = ["qg_ops.h", "qg_plan.h", "qg_kernels.h", "qg_step_all.h", "qg_eltwise.h", "qg_eltwise_args.h", "qg_fix.h", os.path.join("..", "..", "include", "qgemul.h")]
 LIB = os.path.join(HERE, "libqugemm.so")
 # the same sources with -DQG_DIAG: environment A/B switches and the ablation kernel variants (results may be WRONG by
 # construction there).  Loaded only by tools/ (QUBLAS_AMD_DIAG=1, qublas_amd/capi.py); the product library has neither.

@@ -1,0 +1,87 @@
+// qg_fix.h — the compact fixed-mode steps of qg_plan.h (QFix) on the device: shared by the complex and the real 32-bit tree kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+#include "qg_plan.h"
+
+// One scalar load of 8 dwords per step, no branch on the step's mode, alignment / exact left shifts folded into 24-bit
+// multiply-adds, the rounding addend into the same instruction, saturation as one v_med3_i32 (lower bound from an SGPR,
+// upper bound moved to a VGPR once per step): 2-4 vector instructions per value and step where the table-driven run-time
+// forms spend 5-7 and a scalar branch ladder (52 -> 31 instructions per complex MAC of configuration 5; the real kernel's
+// run-time-mode form is 4.3x slower than this one at 2048^3).
+// v_mad_i32_i24 written out (hipcc keeps a __mul24 and its addend apart): value * scalar factor + value, value * value + scalar
+__device__ __forceinline__ int mad24_vsv(int a, int k, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int mad24_vvs(int a, int b, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+
+template <int N>
+__device__ __forceinline__ void fx_finish(int (&v)[N], const QFix& f)
+{
+    if (f.d) {   // (wave-uniform; sums of equally aligned values have d == 0)
+#pragma unroll
+        for (int o = 0; o < N; ++o) v[o] >>= f.d;
+    }
+    const int hi = f.hi;
+#pragma unroll
+    for (int o = 0; o < N; ++o) asm("v_med3_i32 %0, %0, %1, %2" : "+v"(v[o]) : "s"(f.lo), "v"(hi));
+}
+// the same with the overflow kind of the record (QFix::kb of a product / node record of the REAL kernel, which has no second
+// factor): 0 one clamp (SAT::TCPL, SAT::SMGN), 1 out of range -> 0 (SAT::ZERO), 2 wrap, signed (WRP::TCPL: keep the low
+// W + 1 bits, sign-extended; hi = 2^W - 1), 3 wrap, unsigned (v & hi).  Wave-uniform.
+template <int N>
+__device__ __forceinline__ void fx_finish_any(int (&v)[N], const QFix& f)
+{
+    if (f.d) {
+#pragma unroll
+        for (int o = 0; o < N; ++o) v[o] >>= f.d;
+    }
+    if (f.kb == 0) {
+        const int hi = f.hi;
+#pragma unroll
+        for (int o = 0; o < N; ++o) asm("v_med3_i32 %0, %0, %1, %2" : "+v"(v[o]) : "s"(f.lo), "v"(hi));
+    } else if (f.kb == 1) {
+        const unsigned span = (unsigned)f.hi - (unsigned)f.lo;
+#pragma unroll
+        for (int o = 0; o < N; ++o) v[o] = ((unsigned)v[o] - (unsigned)f.lo > span) ? 0 : v[o];
+    } else if (f.kb == 2) {
+        const int sh = __builtin_clz((unsigned)f.hi) - 1;   // 31 - (W + 1) for hi = 2^W - 1
+#pragma unroll
+        for (int o = 0; o < N; ++o) v[o] = (int)((unsigned)v[o] << sh) >> sh;
+    } else {
+#pragma unroll
+        for (int o = 0; o < N; ++o) v[o] &= f.hi;
+    }
+}
+// the rounding addend in a VGPR, so that it can ride in a multiply-add next to a scalar factor (one scalar operand per instruction)
+__device__ __forceinline__ int fx_vgpr(int s)
+{
+    int v;
+    asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
+// The steps' parameters are loop-invariant; left alone, the compiler hoists all of their scalar loads out of the k loop
+// (16 steps x 8 dwords), runs out of SGPRs and spills them through VGPR lanes.  The load is therefore written out: one
+// s_load_dwordx8 from the scalar cache right where the step runs.
+typedef int fx_v8i __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ QFix fx_at(const QTreeTable* t, unsigned byte_off)
+{
+    fx_v8i r;
+    asm volatile("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(t), "s"(byte_off));
+    QFix f;
+    f.ka = r[0]; f.kb = r[1]; f.t = r[2]; f.d = r[3]; f.lo = r[4]; f.hi = r[5]; f.skip = r[6]; f.ls = r[7];
+    return f;
+}
+#define FX_OFF_MUL(slot) ((unsigned)(offsetof(QTreeTable, fmul) + (slot) * sizeof(QFix)))
+#define FX_OFF_ADD(part, l) ((unsigned)(offsetof(QTreeTable, fadd) + ((part) * QG_MAX_LEVELS + (l)) * sizeof(QFix)))
+#define FX_OFF_CVT(part, l) ((unsigned)(offsetof(QTreeTable, fcvt) + ((part) * QG_MAX_LEVELS + (l)) * sizeof(QFix)))
+

@@ -477,6 +477,41 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         const int W = (int)pf.I + (int)pf.F;
         if (one && W + 1 + T.mul[0].q.d <= 30) out->fast_mode = pf.O == QG_SAT_ZERO ? 1 : 2;
     }
+    // fast_mode 3: per-level formats, but every step "add a constant, shift right, clamp" (QFix, qg_plan.h): TRN::TCPL /
+    // RND::POS_INF / RND::NEG_INF rounding; SAT::TCPL / SAT::SMGN (one clamp), SAT::ZERO (range test + select) or WRP::TCPL
+    // (sign extension / mask) overflow — e.g. default modes with a wider level type in QgemulAddArgs, which used to take the
+    // run-time-mode form (4.3x slower at 2048^3)
+    if (out->tree_fast_ok && out->mul24_ok && out->fast_mode == 0) {
+        auto okq = [](const QStep& q) {
+            return q.identity || (q.d >= -22 && q.d <= 29 && (q.O == QG_SAT_TCPL || q.O == QG_SAT_SMGN || q.O == QG_SAT_ZERO || (q.O == QG_WRP_TCPL && q.W >= 1)) &&
+                                  (q.d <= 0 || q.Q == QG_RND_POS_INF || q.Q == QG_TRN_TCPL || q.Q == QG_RND_NEG_INF));
+        };
+        auto fix_of = [](const QStep& q, QFix* f) {
+            memset(f, 0, sizeof *f);
+            f->ka = 1;
+            if (q.identity) { f->lo = INT32_MIN; f->hi = INT32_MAX; return; }
+            f->kb = q.O == QG_SAT_ZERO ? 1 : q.O == QG_WRP_TCPL ? (q.S ? 2 : 3) : 0;   // overflow kind (qg_plan.h)
+            f->lo = q.O == QG_SAT_SMGN ? (q.S ? -(int32_t)q.hi : 0) : (int32_t)q.lo;
+            f->hi = (int32_t)q.hi;
+            if (q.d < 0) { f->ls = -q.d; return; }
+            f->d = q.d;
+            f->t = q.d == 0 ? 0 : q.Q == QG_RND_POS_INF ? (1 << (q.d - 1)) : q.Q == QG_RND_NEG_INF ? (1 << (q.d - 1)) - 1 : 0;
+        };
+        const QStep& pq = T.mul[0].q;
+        // (the split product is rounded inside its low half: its shift is the split, never a left shift)
+        bool ok3 = okq(pq) && (out->split_s == 0 || (!pq.identity && pq.d == out->split_s));
+        for (uint32_t l = 0; l < d->n_levels && ok3; ++l)
+            ok3 = okq(T.level_add[0][l].q) && T.level_cvt[0][l].identity && T.level_add[0][l].sa == 0 && T.level_add[0][l].sb == 0;
+        if (ok3) {
+            fix_of(pq, &T.fmul[0]);
+            bool clamps = T.fmul[0].kb == 0;
+            for (uint32_t l = 0; l < d->n_levels; ++l) {
+                fix_of(T.level_add[0][l].q, &T.fadd[0][l]);
+                clamps = clamps && T.fadd[0][l].kb == 0;
+            }
+            out->fast_mode = clamps ? 3 : 4;   // 3: every step clamps (one v_med3 per value, no branch on the overflow kind)
+        }
+    }
     out->tree64_ok = (!cx && d->n_levels >= 5 && d->n_levels <= 16) ? 1 : 0;   // (max_bits <= 62 was checked above)
     // one-column kernel (qg_gemv.hip): products are formed in 64 bits, everything else in 32
     out->gemv_ok = (!cx && d->N == 1 && d->n_levels >= 4 && d->n_levels <= 30 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;

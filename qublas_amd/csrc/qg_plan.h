@@ -14,6 +14,8 @@
 //   tree node:       v = x + v + t;   v <<= ls;     v >>= d;   v = clamp(v, lo, hi)       (ls: a level type with MORE fraction bits)
 // t = the rounding mode's addend (TRN::TCPL 0, RND::POS_INF 2^(d-1), RND::NEG_INF 2^(d-1) - 1); an identity step is d = 0,
 // t = 0 and the full int32 range.
+// Records of the REAL kernel (product, nodes) have no second factor; their kb holds the overflow kind instead: 0 one clamp
+// (SAT::TCPL, SAT::SMGN), 1 out of range -> 0 (SAT::ZERO), 2 wrap signed, 3 wrap unsigned (WRP::TCPL).
 struct QFix {
     int32_t ka, kb, t, d, lo, hi, skip, ls;
 };
@@ -53,7 +55,7 @@ struct QAnalysis {
     int mul24_ok;            // multiplies fit v_mul_i32_i24
     int cplx_fast_ok;        // the 32-bit complex tree kernel applies
     int cplx_fixed_ok;       // ... and every step on the path is RND::POS_INF (or exact) + SAT::TCPL: fixed-mode variant (2: register-resident steps)
-    int fast_mode;           // 0 runtime modes; 1 one format everywhere, TCPL + SAT::ZERO; 2 TCPL + SAT::TCPL
+    int fast_mode;           // 0 runtime modes; 1 one format everywhere, TCPL + SAT::ZERO; 2 TCPL + SAT::TCPL; 3 / 4 per-level formats, compact steps (QFix; 3: every step clamps)
     int tree64_ok;           // the 2x2-outputs-per-lane 64-bit tree kernel applies (real, 5..16 levels)
     int gemv_ok;             // the one-column 32-bit tree kernel applies (N = 1, K = 2^p >= 16)
     int gemv_fixed;          // 1 / 2: every tree level has one format, no rounding shift, SAT::ZERO / SAT::TCPL (fixed-mode nodes)

@@ -17,6 +17,7 @@
 //     whose K is a power of two >= 32.
 #include <hip/hip_runtime.h>
 
+#include "qg_fix.h"
 #include "qg_kernels.h"
 
 namespace {
@@ -125,6 +126,20 @@ __device__ __forceinline__ void node_fixed(int (&v)[NOUT], const int (&x)[NOUT],
     }
 }
 
+template <bool ANY>   // ANY: the record's overflow kind decides (clamp / range test / wrap); else every step of the descriptor clamps
+__device__ __forceinline__ void node_fx(int (&v)[NOUT], const int (&x)[NOUT], const QTreeTable* __restrict__ t, int l)
+{
+    const QFix f = fx_at(t, FX_OFF_ADD(0, l));
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) v[o] = x[o] + v[o] + f.t;   // v_add3_u32
+    if (f.ls) {   // (wave-uniform, rare: the level type has MORE fraction bits than its operands)
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) v[o] = (int)((unsigned)v[o] << f.ls);
+    }
+    if (ANY) fx_finish_any<NOUT>(v, f);
+    else fx_finish<NOUT>(v, f);
+}
+
 __device__ __forceinline__ void node_all(int (&v)[NOUT], const int (&x)[NOUT], const QTreeTable* __restrict__ t, int l)
 {
 #pragma unroll
@@ -181,9 +196,14 @@ struct QTreeFastArgs {
 //   SAT::ZERO (1) or SAT::TCPL (2) — the default-tag shapes (configurations 1 and 3 as literally configured).  Then
 //   a node is 3 (ZERO, on values biased by -lo so that the range test is one unsigned compare) or 2 (TCPL:
 //   v_add + v_med3) VALU instructions and the leaf needs no separate rounding step.
+// MODE 3 / 4: per-level formats, every step in the compact form of qg_fix.h (QAnalysis::fast_mode): the node's record is one
+//   scalar load, the node itself v_add3 (+ the rounding addend), a shift where the level has fewer fraction bits, and one
+//   v_med3 (3: every step of the descriptor clamps) or what the record's overflow kind asks for (4: SAT::ZERO / WRP::TCPL
+//   steps exist; kept apart because the extra wave-uniform branches cost the clamp-only form a third of its speed).
 #define NODE(X, L)                                                         \
     do {                                                                   \
-        if (MODE != 0) node_fixed<MODE>(v, X, flo, fhi, bias, span);       \
+        if (MODE >= 3) node_fx<MODE == 4>(v, X, tab, L);                   \
+        else if (MODE != 0) node_fixed<MODE>(v, X, flo, fhi, bias, span);  \
         else node_all(v, X, tab, L);                                       \
     } while (0)
 
@@ -217,6 +237,9 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
     const int bias = MODE == 1 ? -flo : 0;
     const unsigned span = (unsigned)(fhi - flo);
     const int pd = pstep.d > 0 ? pstep.d : 0;  // DIRECT: TCPL shift of the product
+    // MODE 3: the product's own compact step (rounding addend, shift, clamp; the upper bound lives in a VGPR for v_med3_i32)
+    const QFix fp = tab->fmul[0];
+    const int phi_v = MODE >= 3 ? fx_vgpr(fp.hi) : 0;
 
     int low[4][NOUT];
     int up[MAXL - 4][NOUT];
@@ -273,7 +296,37 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
                         if (SPLIT) blv[j] = e == 0 ? bl4[j].x : e == 1 ? bl4[j].y : e == 2 ? bl4[j].z : bl4[j].w;
                     }
                     // ---- leaves: 8 quantised products
-                    if (MODE != 0) {
+                    if (MODE >= 3) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                if (SPLIT) {
+                                    // floor((a*b + t) / 2^s) = a*bh + ((a*bl + t) >> s): the rounding addend rides in the low half
+                                    const int t = mad24_vvs(av[i], blv[j], fp.t);
+                                    v[i * 2 + j] = __mul24(av[i], bhv[j]) + (t >> s);
+                                } else {
+                                    v[i * 2 + j] = mad24_vvs(av[i], bhv[j], fp.t);
+                                }
+                            }
+                        if (!SPLIT) {
+                            if (fp.d) {
+#pragma unroll
+                                for (int o = 0; o < NOUT; ++o) v[o] >>= fp.d;
+                            } else if (fp.ls) {
+#pragma unroll
+                                for (int o = 0; o < NOUT; ++o) v[o] = (int)((unsigned)v[o] << fp.ls);
+                            }
+                        }
+                        if (MODE == 3 || fp.kb == 0) {
+#pragma unroll
+                            for (int o = 0; o < NOUT; ++o) asm("v_med3_i32 %0, %0, %1, %2" : "+v"(v[o]) : "s"(fp.lo), "v"(phi_v));
+                        } else {
+                            QFix f0 = fp;
+                            f0.d = 0;   // (the shift is done)
+                            fx_finish_any<NOUT>(v, f0);
+                        }
+                    } else if (MODE != 0) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -400,11 +453,15 @@ hipError_t qg_launch_tree_fast(const QTreeTable* dev_table, int n_levels, int sp
     if (split_s > 0) {
         if (mode == 1) launch_tf<true, true, 1>(n_levels, grid, st, g);
         else if (mode == 2) launch_tf<true, true, 2>(n_levels, grid, st, g);
+        else if (mode == 3) launch_tf<true, true, 3>(n_levels, grid, st, g);
+        else if (mode == 4) launch_tf<true, true, 4>(n_levels, grid, st, g);
         else if (mul24) launch_tf<true, true, 0>(n_levels, grid, st, g);
         else launch_tf<true, false, 0>(n_levels, grid, st, g);
     } else {
         if (mode == 1) launch_tf<false, true, 1>(n_levels, grid, st, g);
         else if (mode == 2) launch_tf<false, true, 2>(n_levels, grid, st, g);
+        else if (mode == 3) launch_tf<false, true, 3>(n_levels, grid, st, g);
+        else if (mode == 4) launch_tf<false, true, 4>(n_levels, grid, st, g);
         else if (mul24) launch_tf<false, true, 0>(n_levels, grid, st, g);
         else launch_tf<false, false, 0>(n_levels, grid, st, g);
     }

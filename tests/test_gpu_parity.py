@@ -218,6 +218,37 @@ def test_complex_fast_kernel_tags_and_levels(oracle):
         assert fields_equal(a, b)
 
 
+def test_real_tree_kernel_step_forms(oracle):
+    """The 32-bit tree kernel's step forms (the planner reports the form in info.reason): one format everywhere (default
+    tags), per-level formats in the compact form of qg_fix.h — roundings that add a constant and shift (TRN::TCPL,
+    RND::POS_INF, RND::NEG_INF), overflows that clamp (SAT::TCPL, SAT::SMGN), test the range (SAT::ZERO) or wrap (WRP::TCPL),
+    split and direct products, level types with fewer and with more fraction bits — and run-time modes for the rest
+    (RND::CONV here).  Every form must equal the oracle and the run-time-mode kernel."""
+    e88 = Qu(8, 8)
+    e88z = Qu(8, 8, True, TRN.TCPL, SAT.ZERO)
+    cases = [
+        (e88, e88, dict(), "one format, SAT::TCPL"),
+        (e88z, e88z, dict(), "one format, SAT::ZERO"),
+        (e88, Qu(12, 8), dict(add_args=[Qu(12, 8)]), "per-level formats, compact (clamps)"),                          # a wider level type (split product)
+        (e88z, Qu(12, 6, True, TRN.TCPL, SAT.ZERO), dict(add_args=[Qu(10, 8, True, TRN.TCPL, SAT.ZERO), Qu(12, 6, True, TRN.TCPL, SAT.ZERO)]),
+         "per-level formats, compact"),                                                                               # SAT::ZERO with per-level formats
+        (Qu(4, 3), Qu(9, 2, True, RND.NEG_INF, SAT.SMGN), dict(mul_args=Qu(6, 5, True, RND.POS_INF, SAT.TCPL),
+                                                                add_args=[Qu(8, 3, True, RND.POS_INF, SAT.TCPL), Qu(9, 2, True, RND.NEG_INF, SAT.SMGN)]),
+         "per-level formats, compact (clamps)"),                                                                      # direct product, rounding nodes
+        (Qu(4, 3), Qu(8, 7), dict(mul_args=Tags(6, 7), add_args=[Qu(7, 7), Qu(8, 9, True, TRN.TCPL, WRP.TCPL)]), "per-level formats, compact"),   # left shifts, a wrapping level
+        (e88, Qu(12, 8), dict(add_args=[Qu(12, 8, True, RND.CONV)], mul_args=Qu(10, 6, True, RND.CONV)), "run-time modes"),
+    ]
+    for K in (64, 300):
+        for e, ec, kw, form in cases:
+            M, N = 70, 41
+            d = lower(e, e, ec, M, N, K, **kw)
+            info = capi.classify(d)
+            assert capi.KERNEL_NAMES[info.kernel] == "tree_i32" and info.reason.decode().endswith(form), (info.reason, form)
+            a = _vs_oracle(oracle, e, e, ec, M, N, K, expect_kernel="tree_i32", **kw)
+            b = _vs_oracle(oracle, e, e, ec, M, N, K, flags=capi.OPT_RUNTIME_MODES, expect_kernel="tree_i32", **kw)
+            assert np.array_equal(a, b)
+
+
 def test_complex_fixed_mode_step_forms(oracle):
     """RND::POS_INF + SAT::TCPL everywhere (BASELINE configuration 5's modes): the complex kernel runs its steps in the
     compact branch-free form (one scalar load per step, alignment and exact left shifts folded into 24-bit multiply-adds,

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Kernel time of the 32-bit tree kernels' step forms at 2048^3 (one format / compact per-level records / run-time modes),
+real and complex; one JSON line per case."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from qublas_amd import capi  # noqa: E402
+from qublas_amd.desc import Qcomplex, Qu, RND, SAT, TRN, TFComplexMul, lower  # noqa: E402
+
+E = Qu(8, 8)
+EZ = Qu(8, 8, True, TRN.TCPL, SAT.ZERO)
+S = 2048
+CD = Qcomplex(Qu(6, 3), Qu(6, -3))     # configuration 5's widths with the reference's default modes
+CASES = [
+    ("int<8,8> default tags (one format, SAT::TCPL)", lower(E, E, E, S, S, S), 0),
+    ("same, run-time modes forced", lower(E, E, E, S, S, S), capi.OPT_RUNTIME_MODES),
+    ("int<8,8>, level type Qu<12,8> (QgemulAddArgs)", lower(E, E, Qu(12, 8), S, S, S, add_args=[Qu(12, 8)]), 0),
+    ("same, run-time modes forced", lower(E, E, Qu(12, 8), S, S, S, add_args=[Qu(12, 8)]), capi.OPT_RUNTIME_MODES),
+    ("int<8,8> SAT::ZERO, level types Qu<10,8>, Qu<12,6> SAT::ZERO", lower(EZ, EZ, Qu(12, 6, True, TRN.TCPL, SAT.ZERO), S, S, S,
+                                                                          add_args=[Qu(10, 8, True, TRN.TCPL, SAT.ZERO), Qu(12, 6, True, TRN.TCPL, SAT.ZERO)]), 0),
+    ("product Qu<10,6> RND::POS_INF, levels Qu<12,6>, Qu<16,4>", lower(E, E, Qu(16, 4), S, S, S, mul_args=Qu(10, 6, True, RND.POS_INF, SAT.TCPL),
+                                                                      add_args=[Qu(12, 6), Qu(16, 4)]), 0),
+    ("complex int<6,3>/int<6,-3> DEFAULT modes, TFComplexMul", lower(CD, CD, CD, S, S, S, mul_args=TFComplexMul()), 0),
+    ("same, run-time modes forced", lower(CD, CD, CD, S, S, S, mul_args=TFComplexMul()), capi.OPT_RUNTIME_MODES),
+]
+
+
+def main():
+    with capi.Context(0) as ctx:
+        for name, d, fl in CASES:
+            plan = capi.Plan(ctx, d, fl)
+            pb = plan.info.packed_bytes
+            pA, pB, pC = ctx.alloc(pb[0]), ctx.alloc(pb[1]), ctx.alloc(pb[2])
+            plan.fill(capi.OPERAND_A, 1, 0, pA)
+            plan.fill(capi.OPERAND_B, 2, 0, pB)
+            ms = plan.time_execute(pC, pA, pB, 2, 5)
+            print(json.dumps({"case": name, "kernel": capi.KERNEL_NAMES[plan.info.kernel], "steps": plan.info.reason.decode().split("steps: ")[-1], "ms": ms}), flush=True)
+            for p in (pA, pB, pC):
+                ctx.free(p)
+            plan.close()
+
+
+if __name__ == "__main__":
+    main()
