@@ -195,7 +195,7 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     if (kernel == QG_KERNEL_TREE_I32) {
         const int fm = (flags & QG_OPT_RUNTIME_MODES) ? 0 : an->fast_mode;
         snprintf(info->reason, sizeof info->reason, "exact tree evaluation; tree kernel steps: %s",
-                 fm == 1 ? "one format, SAT::ZERO" : fm == 2 ? "one format, SAT::TCPL" : fm == 3 ? "per-level formats, compact (clamps)" : fm == 4 ? "per-level formats, compact" : "run-time modes");
+                 fm == 1 ? "one format, SAT::ZERO" : fm == 2 ? "one format, SAT::TCPL" : fm == 3 ? "per-level formats, compact (clamps)" : fm == 4 ? "per-level formats, compact" : fm == 5 ? "per-level formats, compact (unbiased)" : "run-time modes");
     }
     if (kernel == QG_KERNEL_TREE_CPLX_I32) {
         // which form of the complex kernel's steps this descriptor gets (tests assert their coverage through it)

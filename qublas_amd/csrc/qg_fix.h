@@ -35,8 +35,28 @@ __device__ __forceinline__ void fx_finish(int (&v)[N], const QFix& f)
 #pragma unroll
     for (int o = 0; o < N; ++o) asm("v_med3_i32 %0, %0, %1, %2" : "+v"(v[o]) : "s"(f.lo), "v"(hi));
 }
-// the same with the overflow kind of the record (QFix::kb of a product / node record of the REAL kernel, which has no second
-// factor): 0 one clamp (SAT::TCPL, SAT::SMGN), 1 out of range -> 0 (SAT::ZERO), 2 wrap, signed (WRP::TCPL: keep the low
+// BIASED records (the real kernel's fast_mode 4, qg_plan.cpp): the value is u = v - lo >= 0 of its own format; after the shift
+// the overflow kind of the record (QFix::kb) acts on u with span = hi - lo (QFix::hi) and the biased zero B = -lo (QFix::lo):
+// 0 clamp = med3(u, 0, span); 1 SAT::ZERO = one unsigned compare + select; 2 WRP::TCPL = u & span; 4 none.  Wave-uniform.
+template <int N>
+__device__ __forceinline__ void fx_finish_biased(int (&v)[N], const QFix& f)
+{
+    if (f.d) {
+#pragma unroll
+        for (int o = 0; o < N; ++o) v[o] >>= f.d;
+    }
+    if (f.kb == 1) {
+#pragma unroll
+        for (int o = 0; o < N; ++o) v[o] = ((unsigned)v[o] > (unsigned)f.hi) ? f.lo : v[o];
+    } else if (f.kb == 0) {
+#pragma unroll
+        for (int o = 0; o < N; ++o) asm("v_med3_i32 %0, %0, 0, %1" : "+v"(v[o]) : "s"(f.hi));
+    } else if (f.kb == 2) {
+#pragma unroll
+        for (int o = 0; o < N; ++o) v[o] &= f.hi;
+    }
+}
+// UNBIASED records with an overflow kind (the real kernel's fast_mode 5: formats too wide for the biased form), QFix::kb: 0 one clamp (SAT::TCPL, SAT::SMGN), 1 out of range -> 0 (SAT::ZERO), 2 wrap, signed (WRP::TCPL: keep the low
 // W + 1 bits, sign-extended; hi = 2^W - 1), 3 wrap, unsigned (v & hi).  Wave-uniform.
 template <int N>
 __device__ __forceinline__ void fx_finish_any(int (&v)[N], const QFix& f)

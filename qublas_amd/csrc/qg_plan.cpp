@@ -509,7 +509,59 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                 fix_of(T.level_add[0][l].q, &T.fadd[0][l]);
                 clamps = clamps && T.fadd[0][l].kb == 0;
             }
-            out->fast_mode = clamps ? 3 : 4;   // 3: every step clamps (one v_med3 per value, no branch on the overflow kind)
+            out->fast_mode = clamps ? 3 : 5;   // 3: every step clamps (one v_med3 per value, no branch on the overflow kind);
+                                               // 5: the records' overflow kinds on unbiased values (any format the kernel admits)
+            if (!clamps) {
+                QFix keep_mul = T.fmul[0];
+                std::vector<QFix> keep_add(T.fadd[0], T.fadd[0] + d->n_levels);
+                // 4: some step tests the range (SAT::ZERO) or wraps.  The running value is then kept BIASED by -lo of its own
+                // format, u = v - lo >= 0 (as the one-format SAT::ZERO form does): the range test is ONE unsigned compare
+                // against span = hi - lo with the biased zero as the select's other operand, a clamp is med3(u, 0, span) with
+                // no register for a bound, a wrap is u & span; the change of bias from level to level, the rounding addend and
+                // the new bias (scaled by 2^d: subtracting a multiple of 2^d before a right shift by d is exact) are ONE
+                // constant of the node's v_add3.  Record fields (QFix): t = that constant, d, ls, kb = overflow kind
+                // (0 clamp, 1 zero, 2 wrap, 4 none), hi = span, lo = the bias B = -lo (also the biased zero).
+                struct L { int kind; int64_t B, span; };
+                auto lv = [](const QStep& q) {
+                    L r{4, 0, 0};
+                    if (q.identity) return r;
+                    const int64_t lo = q.O == QG_SAT_SMGN ? (q.S ? -q.hi : 0) : q.lo;
+                    r.kind = q.O == QG_SAT_ZERO ? 1 : q.O == QG_WRP_TCPL ? 2 : 0;
+                    r.B = -lo;
+                    r.span = q.hi - lo;
+                    return r;
+                };
+                bool fits = c.max_bits_np <= 30;   // (the raw product is never formed: split, or bitsA + bitsB <= 31)
+                auto put = [&](const QStep& q, const L& me, int64_t bias_in2, QFix* f) {   // bias_in2: the bias the inputs carry, summed
+                    const QFix u = *f;                                                    // (the unbiased record: t, d, ls)
+                    memset(f, 0, sizeof *f);
+                    f->ka = 1;
+                    f->d = u.d;
+                    f->ls = u.ls;
+                    f->kb = me.kind;
+                    f->hi = (int32_t)me.span;
+                    f->lo = (int32_t)me.B;
+                    const int64_t cst = u.ls ? -bias_in2 : (int64_t)u.t - bias_in2 + (me.B << u.d);   // (left shift: B is added after it)
+                    fits = fits && me.span < (1ll << 30) && (me.B << u.d) < (1ll << 29) && cst > -(1ll << 30) && cst < (1ll << 30) &&
+                           (me.B << u.ls) < (1ll << 30);
+                    f->t = (int32_t)cst;
+                    (void)q;
+                };
+                L cur = lv(pq);
+                put(pq, cur, 0, &T.fmul[0]);
+                for (uint32_t l = 0; l < d->n_levels; ++l) {
+                    const L me = lv(T.level_add[0][l].q);
+                    put(T.level_add[0][l].q, me, 2 * cur.B, &T.fadd[0][l]);
+                    cur = me;
+                }
+                T.fmul[0].ka = (int32_t)cur.B;   // the root's bias, removed once per output
+                if (fits) {
+                    out->fast_mode = 4;
+                } else {   // too wide for the bias arithmetic: the unbiased records stand
+                    T.fmul[0] = keep_mul;
+                    for (uint32_t l = 0; l < d->n_levels; ++l) T.fadd[0][l] = keep_add[l];
+                }
+            }
         }
     }
     out->tree64_ok = (!cx && d->n_levels >= 5 && d->n_levels <= 16) ? 1 : 0;   // (max_bits <= 62 was checked above)

@@ -14,8 +14,11 @@
 //   tree node:       v = x + v + t;   v <<= ls;     v >>= d;   v = clamp(v, lo, hi)       (ls: a level type with MORE fraction bits)
 // t = the rounding mode's addend (TRN::TCPL 0, RND::POS_INF 2^(d-1), RND::NEG_INF 2^(d-1) - 1); an identity step is d = 0,
 // t = 0 and the full int32 range.
-// Records of the REAL kernel (product, nodes) have no second factor; their kb holds the overflow kind instead: 0 one clamp
-// (SAT::TCPL, SAT::SMGN), 1 out of range -> 0 (SAT::ZERO), 2 wrap signed, 3 wrap unsigned (WRP::TCPL).
+// Records of the REAL kernel (product, nodes) have no factors.  fast_mode 3 (every step clamps): as above.  fast_mode 4 (a step
+// tests the range or wraps): the value is kept biased by -lo of its format, and the fields mean: t = the node's one constant
+// (rounding addend, change of bias), kb = overflow kind (0 clamp, 1 SAT::ZERO, 2 WRP::TCPL, 4 none), hi = span = hi - lo,
+// lo = the bias B = -lo (the biased zero); fmul[0].ka = the root's bias (qg_plan.cpp).  fast_mode 5 (a format too wide for that):
+// unbiased values, lo / hi = the bounds, kb = 0 clamp, 1 SAT::ZERO, 2 / 3 WRP::TCPL signed / unsigned.
 struct QFix {
     int32_t ka, kb, t, d, lo, hi, skip, ls;
 };
@@ -55,7 +58,7 @@ struct QAnalysis {
     int mul24_ok;            // multiplies fit v_mul_i32_i24
     int cplx_fast_ok;        // the 32-bit complex tree kernel applies
     int cplx_fixed_ok;       // ... and every step on the path is RND::POS_INF (or exact) + SAT::TCPL: fixed-mode variant (2: register-resident steps)
-    int fast_mode;           // 0 runtime modes; 1 one format everywhere, TCPL + SAT::ZERO; 2 TCPL + SAT::TCPL; 3 / 4 per-level formats, compact steps (QFix; 3: every step clamps)
+    int fast_mode;           // 0 runtime modes; 1 one format everywhere, TCPL + SAT::ZERO; 2 TCPL + SAT::TCPL; 3 / 4 / 5 per-level formats, compact steps (QFix; 3: every step clamps, 4: biased values, 5: unbiased)
     int tree64_ok;           // the 2x2-outputs-per-lane 64-bit tree kernel applies (real, 5..16 levels)
     int gemv_ok;             // the one-column 32-bit tree kernel applies (N = 1, K = 2^p >= 16)
     int gemv_fixed;          // 1 / 2: every tree level has one format, no rounding shift, SAT::ZERO / SAT::TCPL (fixed-mode nodes)

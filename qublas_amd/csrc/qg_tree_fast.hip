@@ -126,17 +126,18 @@ __device__ __forceinline__ void node_fixed(int (&v)[NOUT], const int (&x)[NOUT],
     }
 }
 
-template <bool ANY>   // ANY: the record's overflow kind decides (clamp / range test / wrap); else every step of the descriptor clamps
+template <int FORM>   // 3: every step clamps; 4: values biased by -lo, the record's overflow kind decides; 5: the same on unbiased values
 __device__ __forceinline__ void node_fx(int (&v)[NOUT], const int (&x)[NOUT], const QTreeTable* __restrict__ t, int l)
 {
     const QFix f = fx_at(t, FX_OFF_ADD(0, l));
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o) v[o] = x[o] + v[o] + f.t;   // v_add3_u32
+    for (int o = 0; o < NOUT; ++o) v[o] = x[o] + v[o] + f.t;   // v_add3_u32 (BIASED: t also carries the change of bias)
     if (f.ls) {   // (wave-uniform, rare: the level type has MORE fraction bits than its operands)
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) v[o] = (int)((unsigned)v[o] << f.ls);
+        for (int o = 0; o < NOUT; ++o) v[o] = (int)((unsigned)v[o] << f.ls) + (FORM == 4 ? f.lo : 0);
     }
-    if (ANY) fx_finish_any<NOUT>(v, f);
+    if (FORM == 4) fx_finish_biased<NOUT>(v, f);
+    else if (FORM == 5) fx_finish_any<NOUT>(v, f);
     else fx_finish<NOUT>(v, f);
 }
 
@@ -198,11 +199,12 @@ struct QTreeFastArgs {
 //   v_add + v_med3) VALU instructions and the leaf needs no separate rounding step.
 // MODE 3 / 4: per-level formats, every step in the compact form of qg_fix.h (QAnalysis::fast_mode): the node's record is one
 //   scalar load, the node itself v_add3 (+ the rounding addend), a shift where the level has fewer fraction bits, and one
-//   v_med3 (3: every step of the descriptor clamps) or what the record's overflow kind asks for (4: SAT::ZERO / WRP::TCPL
-//   steps exist; kept apart because the extra wave-uniform branches cost the clamp-only form a third of its speed).
+//   v_med3 (3: every step of the descriptor clamps), or — 4: SAT::ZERO / WRP::TCPL steps exist — values biased by -lo of their
+//   format and the overflow by the record's kind: one unsigned compare + select, med3(u, 0, span), or u & span (qg_fix.h);
+//   5: the same kinds on unbiased values (a subtraction more per range test) where a format is too wide for the biased form.
 #define NODE(X, L)                                                         \
     do {                                                                   \
-        if (MODE >= 3) node_fx<MODE == 4>(v, X, tab, L);                   \
+        if (MODE >= 3) node_fx<MODE>(v, X, tab, L);                        \
         else if (MODE != 0) node_fixed<MODE>(v, X, flo, fhi, bias, span);  \
         else node_all(v, X, tab, L);                                       \
     } while (0)
@@ -315,16 +317,17 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
                                 for (int o = 0; o < NOUT; ++o) v[o] >>= fp.d;
                             } else if (fp.ls) {
 #pragma unroll
-                                for (int o = 0; o < NOUT; ++o) v[o] = (int)((unsigned)v[o] << fp.ls);
+                                for (int o = 0; o < NOUT; ++o) v[o] = (int)((unsigned)v[o] << fp.ls) + (MODE == 4 ? fp.lo : 0);
                             }
                         }
-                        if (MODE == 3 || fp.kb == 0) {
+                        if (MODE == 3) {
 #pragma unroll
                             for (int o = 0; o < NOUT; ++o) asm("v_med3_i32 %0, %0, %1, %2" : "+v"(v[o]) : "s"(fp.lo), "v"(phi_v));
                         } else {
                             QFix f0 = fp;
                             f0.d = 0;   // (the shift is done)
-                            fx_finish_any<NOUT>(v, f0);
+                            if (MODE == 4) fx_finish_biased<NOUT>(v, f0);
+                            else fx_finish_any<NOUT>(v, f0);
                         }
                     } else if (MODE != 0) {
 #pragma unroll
@@ -412,6 +415,10 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) v[o] -= bias;
     }
+    if (MODE == 4) {   // the root's bias
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) v[o] -= fp.ka;
+    }
     step_all(v, tab->c_cvt[0]);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -455,6 +462,7 @@ hipError_t qg_launch_tree_fast(const QTreeTable* dev_table, int n_levels, int sp
         else if (mode == 2) launch_tf<true, true, 2>(n_levels, grid, st, g);
         else if (mode == 3) launch_tf<true, true, 3>(n_levels, grid, st, g);
         else if (mode == 4) launch_tf<true, true, 4>(n_levels, grid, st, g);
+        else if (mode == 5) launch_tf<true, true, 5>(n_levels, grid, st, g);
         else if (mul24) launch_tf<true, true, 0>(n_levels, grid, st, g);
         else launch_tf<true, false, 0>(n_levels, grid, st, g);
     } else {
@@ -462,6 +470,7 @@ hipError_t qg_launch_tree_fast(const QTreeTable* dev_table, int n_levels, int sp
         else if (mode == 2) launch_tf<false, true, 2>(n_levels, grid, st, g);
         else if (mode == 3) launch_tf<false, true, 3>(n_levels, grid, st, g);
         else if (mode == 4) launch_tf<false, true, 4>(n_levels, grid, st, g);
+        else if (mode == 5) launch_tf<false, true, 5>(n_levels, grid, st, g);
         else if (mul24) launch_tf<false, true, 0>(n_levels, grid, st, g);
         else launch_tf<false, false, 0>(n_levels, grid, st, g);
     }

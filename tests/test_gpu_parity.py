@@ -236,6 +236,10 @@ def test_real_tree_kernel_step_forms(oracle):
                                                                 add_args=[Qu(8, 3, True, RND.POS_INF, SAT.TCPL), Qu(9, 2, True, RND.NEG_INF, SAT.SMGN)]),
          "per-level formats, compact (clamps)"),                                                                      # direct product, rounding nodes
         (Qu(4, 3), Qu(8, 7), dict(mul_args=Tags(6, 7), add_args=[Qu(7, 7), Qu(8, 9, True, TRN.TCPL, WRP.TCPL)]), "per-level formats, compact"),   # left shifts, a wrapping level
+        (e88z, Qu(20, 9, True, TRN.TCPL, SAT.ZERO), dict(add_args=[Qu(20, 9, True, TRN.TCPL, SAT.ZERO)]), "per-level formats, compact (unbiased)"),   # 30 bits: too wide to bias
+        # the README's own call (readme.md:28-36, :84-87): product and level 0 int<6,3> SAT::ZERO, later levels int<6,-3> with default modes
+        (Qu(6, 3, True, TRN.TCPL, SAT.ZERO), Qu(6, 3, True, TRN.TCPL, SAT.ZERO),
+         dict(mul_args=Qu(6, 3, True, TRN.TCPL, SAT.ZERO), add_args=[Qu(6, 3, True, TRN.TCPL, SAT.ZERO), Qu(6, -3)], transposed_a=True), "per-level formats, compact"),
         (e88, Qu(12, 8), dict(add_args=[Qu(12, 8, True, RND.CONV)], mul_args=Qu(10, 6, True, RND.CONV)), "run-time modes"),
     ]
     for K in (64, 300):

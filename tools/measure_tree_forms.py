@@ -23,6 +23,13 @@ CASES = [
                                                                           add_args=[Qu(10, 8, True, TRN.TCPL, SAT.ZERO), Qu(12, 6, True, TRN.TCPL, SAT.ZERO)]), 0),
     ("product Qu<10,6> RND::POS_INF, levels Qu<12,6>, Qu<16,4>", lower(E, E, Qu(16, 4), S, S, S, mul_args=Qu(10, 6, True, RND.POS_INF, SAT.TCPL),
                                                                       add_args=[Qu(12, 6), Qu(16, 4)]), 0),
+    # the README's own Qgemul call (readme.md:28-36, :84-87): type1 = int<6,3> SAT::ZERO, type2 = int<6,-3>, AddArgs<TypeList<type1, type2>>, MulArgs<type1>
+    ("README example types at 2048^3 (product and level 0 SAT::ZERO, levels >= 1 int<6,-3> default modes)",
+     lower(Qu(6, 3, True, TRN.TCPL, SAT.ZERO), Qu(6, 3, True, TRN.TCPL, SAT.ZERO), Qu(6, 3, True, TRN.TCPL, SAT.ZERO), S, S, S,
+           mul_args=Qu(6, 3, True, TRN.TCPL, SAT.ZERO), add_args=[Qu(6, 3, True, TRN.TCPL, SAT.ZERO), Qu(6, -3)], transposed_a=True), 0),
+    ("same, run-time modes forced",
+     lower(Qu(6, 3, True, TRN.TCPL, SAT.ZERO), Qu(6, 3, True, TRN.TCPL, SAT.ZERO), Qu(6, 3, True, TRN.TCPL, SAT.ZERO), S, S, S,
+           mul_args=Qu(6, 3, True, TRN.TCPL, SAT.ZERO), add_args=[Qu(6, 3, True, TRN.TCPL, SAT.ZERO), Qu(6, -3)], transposed_a=True), capi.OPT_RUNTIME_MODES),
     ("complex int<6,3>/int<6,-3> DEFAULT modes, TFComplexMul", lower(CD, CD, CD, S, S, S, mul_args=TFComplexMul()), 0),
     ("same, run-time modes forced", lower(CD, CD, CD, S, S, S, mul_args=TFComplexMul()), capi.OPT_RUNTIME_MODES),
 ]
