@@ -127,9 +127,8 @@ __device__ __forceinline__ void node_fixed(int (&v)[NOUT], const int (&x)[NOUT],
 }
 
 template <int FORM>   // 3: every step clamps; 4: values biased by -lo, the record's overflow kind decides; 5: the same on unbiased values
-__device__ __forceinline__ void node_fx(int (&v)[NOUT], const int (&x)[NOUT], const QTreeTable* __restrict__ t, int l)
+__device__ __forceinline__ void node_fx_rec(int (&v)[NOUT], const int (&x)[NOUT], const QFix& f)
 {
-    const QFix f = fx_at(t, FX_OFF_ADD(0, l));
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) v[o] = x[o] + v[o] + f.t;   // v_add3_u32 (BIASED: t also carries the change of bias)
     if (f.ls) {   // (wave-uniform, rare: the level type has MORE fraction bits than its operands)
@@ -139,6 +138,11 @@ __device__ __forceinline__ void node_fx(int (&v)[NOUT], const int (&x)[NOUT], co
     if (FORM == 4) fx_finish_biased<NOUT>(v, f);
     else if (FORM == 5) fx_finish_any<NOUT>(v, f);
     else fx_finish<NOUT>(v, f);
+}
+template <int FORM>
+__device__ __forceinline__ void node_fx(int (&v)[NOUT], const int (&x)[NOUT], const QTreeTable* __restrict__ t, int l)
+{
+    node_fx_rec<FORM>(v, x, fx_at(t, FX_OFF_ADD(0, l)));
 }
 
 __device__ __forceinline__ void node_all(int (&v)[NOUT], const int (&x)[NOUT], const QTreeTable* __restrict__ t, int l)
@@ -204,7 +208,7 @@ struct QTreeFastArgs {
 //   5: the same kinds on unbiased values (a subtraction more per range test) where a format is too wide for the biased form.
 #define NODE(X, L)                                                         \
     do {                                                                   \
-        if (MODE >= 3) node_fx<MODE>(v, X, tab, L);                        \
+        if (MODE >= 3) { if ((L) < 4) node_fx_rec<MODE>(v, X, flow[(L) < 4 ? (L) : 0]); else node_fx<MODE>(v, X, tab, L); } \
         else if (MODE != 0) node_fixed<MODE>(v, X, flo, fhi, bias, span);  \
         else node_all(v, X, tab, L);                                       \
     } while (0)
@@ -242,6 +246,10 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
     // MODE 3: the product's own compact step (rounding addend, shift, clamp; the upper bound lives in a VGPR for v_med3_i32)
     const QFix fp = tab->fmul[0];
     const int phi_v = MODE >= 3 ? fx_vgpr(fp.hi) : 0;
+    // ... and the records of the four lowest levels (15 of 16 nodes) stay in registers; the upper levels load theirs per node
+    QFix flow[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) flow[l] = tab->fadd[0][l];
 
     int low[4][NOUT];
     int up[MAXL - 4][NOUT];
