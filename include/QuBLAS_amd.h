@@ -655,7 +655,8 @@ void Qgemul(TD& D, const TA& A, const TB& B, const S0& s0, const Stages&... st)
 // ------------------------------------------------------------------ Qreduce (SURVEY.md §8-f "next" #1)
 // The reference's tree reduction of a tensor, Qreduce<L…>(v) (QuBLAS.h:4960-4990, :5014-5018), on the
 // same engine path: C[1 x 1] = A[1 x len] * ones[len x 1] with the product format equal to the element
-// format (Qmul(a, 1) into a's own format is the identity) and the level list L.  The result type is
+// format (Qmul(a, 1) into a's own format is the identity — except for the raw value -2^W of a signed SAT::SMGN
+// element type, which that conversion clamps to -(2^W - 1)) and the level list L.  The result type is
 // the reducer's: the last level type used, or the element type when there are no levels / one element.
 namespace detail {
 template <class Elem, size_t Len, class List> struct reduce_result { using type = Elem; };

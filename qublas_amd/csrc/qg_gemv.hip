@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "qg_kernels.h"
+#include "qg_fix.h"
 #include "qg_step_all.h"
 
 namespace {
@@ -81,6 +82,23 @@ __device__ __forceinline__ int node_fixed(int a, int b, int lo, int hi)
     return qg_clamp_i32(t, lo, hi);
 }
 
+// MODE 3 / 5: per-level formats in the compact records of qg_plan.h (QFix; QAnalysis::gemv_fixed): acc = acc + x + the rounding
+// addend, a left shift where the level has more fraction bits, then a right shift and one clamp (3: every level clamps) or what
+// the record's overflow kind asks for (5: SAT::ZERO / WRP::TCPL levels exist) — no mode ladder, one scalar load per level.
+template <int MODE, int N>
+__device__ __forceinline__ void node_rec(int (&acc)[N], const int (&x)[N], const QTreeTable* t, int level)
+{
+    const QFix f = fx_at(t, FX_OFF_ADD(0, level));
+#pragma unroll
+    for (int o = 0; o < N; ++o) acc[o] = acc[o] + x[o] + f.t;
+    if (f.ls) {
+#pragma unroll
+        for (int o = 0; o < N; ++o) acc[o] = (int)((unsigned)acc[o] << f.ls);
+    }
+    if (MODE == 5) fx_finish_any<N>(acc, f);
+    else fx_finish<N>(acc, f);
+}
+
 template <int CNT, int MODE>
 __device__ __forceinline__ int lane_tree(int (&v)[CNT], CTab tab, int level, int lo, int hi)
 {
@@ -92,6 +110,11 @@ __device__ __forceinline__ int lane_tree(int (&v)[CNT], CTab tab, int level, int
 #pragma unroll
             for (int o = 0; o < CNT / 2; ++o) h[o] = v[2 * o] + v[2 * o + 1];   // left child + right child, in the tree's order
             qg_step_all<int, CNT / 2>(h, load_step(&tab->level_add[0][level].q));
+        } else if constexpr (MODE >= 3) {
+            int r[CNT / 2];
+#pragma unroll
+            for (int o = 0; o < CNT / 2; ++o) { h[o] = v[2 * o]; r[o] = v[2 * o + 1]; }
+            node_rec<MODE, CNT / 2>(h, r, (const QTreeTable*)tab, level);
         } else {
 #pragma unroll
             for (int o = 0; o < CNT / 2; ++o) h[o] = node_fixed<MODE>(v[2 * o], v[2 * o + 1], lo, hi);
@@ -190,6 +213,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
             for (int i = 0; i < 6; ++i) {
                 int y[1] = {__shfl_down(x[0], 1 << i)};
                 if constexpr (MODE == 0) node_all<1>(x, y, tab, Q + i);
+                else if constexpr (MODE >= 3) node_rec<MODE, 1>(x, y, g.tab, Q + i);
                 else x[0] = node_fixed<MODE>(x[0], y[0], flo, fhi);
             }
             // x[0] in lane 0 = the segment's node of level Q + 6; carry it into the counter
@@ -201,6 +225,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
                 else if (MODE == 0) {
                     int l[1] = {up[u]};
                     node_all<1>(l, x, tab, base + u);
+                    x[0] = l[0];
+                } else if (MODE >= 3) {
+                    int l[1] = {up[u]};
+                    node_rec<MODE, 1>(l, x, g.tab, base + u);
                     x[0] = l[0];
                 } else {
                     x[0] = node_fixed<MODE>(up[u], x[0], flo, fhi);
@@ -266,13 +294,27 @@ __global__ __launch_bounds__(256) void k_gemv_short(QGemvArgs g)
 #pragma unroll
                 for (int o = 0; o < 4 * U; ++o) p[o] = (int)w[o];
             }
+            if constexpr (MODE >= 3) {
+                int r0[2 * U];
 #pragma unroll
-            for (int o = 0; o < 2 * U; ++o) l0[o] = MODE == 0 ? p[2 * o] + p[2 * o + 1] : node_fixed<MODE == 0 ? 1 : MODE>(p[2 * o], p[2 * o + 1], flo, fhi);
+                for (int o = 0; o < 2 * U; ++o) { l0[o] = p[2 * o]; r0[o] = p[2 * o + 1]; }
+                node_rec<MODE, 2 * U>(l0, r0, g.tab, 0);
+            } else {
+#pragma unroll
+                for (int o = 0; o < 2 * U; ++o) l0[o] = MODE == 0 ? p[2 * o] + p[2 * o + 1] : node_fixed<(MODE == 1 || MODE == 2) ? MODE : 1>(p[2 * o], p[2 * o + 1], flo, fhi);
+            }
         }
         if constexpr (MODE == 0) qg_step_all<int, 2 * U>(l0, load_step(&tab->level_add[0][0].q));
         int x[U];
+        if constexpr (MODE >= 3) {
+            int r1[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = MODE == 0 ? l0[2 * u] + l0[2 * u + 1] : node_fixed<MODE == 0 ? 1 : MODE>(l0[2 * u], l0[2 * u + 1], flo, fhi);
+            for (int u = 0; u < U; ++u) { x[u] = l0[2 * u]; r1[u] = l0[2 * u + 1]; }
+            node_rec<MODE, U>(x, r1, g.tab, 1);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = MODE == 0 ? l0[2 * u] + l0[2 * u + 1] : node_fixed<(MODE == 1 || MODE == 2) ? MODE : 1>(l0[2 * u], l0[2 * u + 1], flo, fhi);
+        }
         if constexpr (MODE == 0) qg_step_all<int, U>(x, load_step(&tab->level_add[0][1].q));
 #pragma unroll
         for (int i = 0; i < XL; ++i) {
@@ -280,9 +322,10 @@ __global__ __launch_bounds__(256) void k_gemv_short(QGemvArgs g)
 #pragma unroll
             for (int u = 0; u < U; ++u) y[u] = __shfl_down(x[u], 1 << i);
             if constexpr (MODE == 0) node_all<U>(x, y, tab, 2 + i);
+            else if constexpr (MODE >= 3) node_rec<MODE, U>(x, y, g.tab, 2 + i);
             else {
 #pragma unroll
-                for (int u = 0; u < U; ++u) x[u] = node_fixed<MODE == 0 ? 1 : MODE>(x[u], y[u], flo, fhi);
+                for (int u = 0; u < U; ++u) x[u] = node_fixed<(MODE == 1 || MODE == 2) ? MODE : 1>(x[u], y[u], flo, fhi);
             }
         }
         qg_step_all<int, U>(x, c_cvt);
@@ -309,6 +352,8 @@ hipError_t launch_gemv_short(const QGemvArgs& g, hipStream_t st)
     if constexpr (MODE == 0) {
         if (g.pad_ == 1) return launch_gemv_short<KK, 1>(g, st);
         if (g.pad_ == 2) return launch_gemv_short<KK, 2>(g, st);
+        if (g.pad_ == 3) return launch_gemv_short<KK, 3>(g, st);
+        if (g.pad_ == 5) return launch_gemv_short<KK, 5>(g, st);
     }
     constexpr int RPL = 64 / (KK / 4);
     const int64_t groups = (g.M + RPL - 1) / RPL;
@@ -324,6 +369,8 @@ hipError_t launch_gemv(const QGemvArgs& g, hipStream_t st)
     if constexpr (MODE == 0) {
         if (g.pad_ == 1) return launch_gemv<CH, 1>(g, st);
         if (g.pad_ == 2) return launch_gemv<CH, 2>(g, st);
+        if (g.pad_ == 3) return launch_gemv<CH, 3>(g, st);
+        if (g.pad_ == 5) return launch_gemv<CH, 5>(g, st);
     }
     constexpr int IMG = 64 * (CH * 4 + 16);
     const int64_t nseg = g.K / (64 * CH);

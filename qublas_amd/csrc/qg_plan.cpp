@@ -477,11 +477,15 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         const int W = (int)pf.I + (int)pf.F;
         if (one && W + 1 + T.mul[0].q.d <= 30) out->fast_mode = pf.O == QG_SAT_ZERO ? 1 : 2;
     }
+    // one-column kernel (qg_gemv.hip): products are formed in 64 bits, everything else in 32
+    out->gemv_ok = (!cx && d->N == 1 && d->n_levels >= 4 && d->n_levels <= 30 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     // fast_mode 3: per-level formats, but every step "add a constant, shift right, clamp" (QFix, qg_plan.h): TRN::TCPL /
     // RND::POS_INF / RND::NEG_INF rounding; SAT::TCPL / SAT::SMGN (one clamp), SAT::ZERO (range test + select) or WRP::TCPL
     // (sign extension / mask) overflow — e.g. default modes with a wider level type in QgemulAddArgs, which used to take the
     // run-time-mode form (4.3x slower at 2048^3)
-    if (out->tree_fast_ok && out->mul24_ok && out->fast_mode == 0) {
+    int rec_form = 0;   // 3 / 5: the unbiased records are valid (every level clamps / overflow kinds), for the one-column kernel
+    if (((out->tree_fast_ok && out->mul24_ok && out->fast_mode == 0) || out->gemv_ok)) {
+        const bool for_tree = out->tree_fast_ok && out->mul24_ok && out->fast_mode == 0 && !out->gemv_ok;
         auto okq = [](const QStep& q) {
             return q.identity || (q.d >= -22 && q.d <= 29 && (q.O == QG_SAT_TCPL || q.O == QG_SAT_SMGN || q.O == QG_SAT_ZERO || (q.O == QG_WRP_TCPL && q.W >= 1)) &&
                                   (q.d <= 0 || q.Q == QG_RND_POS_INF || q.Q == QG_TRN_TCPL || q.Q == QG_RND_NEG_INF));
@@ -499,19 +503,21 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         };
         const QStep& pq = T.mul[0].q;
         // (the split product is rounded inside its low half: its shift is the split, never a left shift)
-        bool ok3 = okq(pq) && (out->split_s == 0 || (!pq.identity && pq.d == out->split_s));
+        // (the one-column kernel forms its products itself: only the levels' records matter there)
+        bool ok3 = out->gemv_ok || (okq(pq) && (out->split_s == 0 || (!pq.identity && pq.d == out->split_s)));
         for (uint32_t l = 0; l < d->n_levels && ok3; ++l)
             ok3 = okq(T.level_add[0][l].q) && T.level_cvt[0][l].identity && T.level_add[0][l].sa == 0 && T.level_add[0][l].sb == 0;
         if (ok3) {
-            fix_of(pq, &T.fmul[0]);
-            bool clamps = T.fmul[0].kb == 0;
+            if (okq(pq)) fix_of(pq, &T.fmul[0]);
+            bool clamps = out->gemv_ok || T.fmul[0].kb == 0;
             for (uint32_t l = 0; l < d->n_levels; ++l) {
                 fix_of(T.level_add[0][l].q, &T.fadd[0][l]);
                 clamps = clamps && T.fadd[0][l].kb == 0;
             }
-            out->fast_mode = clamps ? 3 : 5;   // 3: every step clamps (one v_med3 per value, no branch on the overflow kind);
-                                               // 5: the records' overflow kinds on unbiased values (any format the kernel admits)
-            if (!clamps) {
+            rec_form = clamps ? 3 : 5;
+            if (for_tree) out->fast_mode = rec_form;   // 3: every step clamps (one v_med3 per value, no branch on the overflow kind);
+                                                       // 5: the records' overflow kinds on unbiased values (any format the kernel admits)
+            if (!clamps && for_tree) {
                 QFix keep_mul = T.fmul[0];
                 std::vector<QFix> keep_add(T.fadd[0], T.fadd[0] + d->n_levels);
                 // 4: some step tests the range (SAT::ZERO) or wraps.  The running value is then kept BIASED by -lo of its own
@@ -565,9 +571,10 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         }
     }
     out->tree64_ok = (!cx && d->n_levels >= 5 && d->n_levels <= 16) ? 1 : 0;   // (max_bits <= 62 was checked above)
-    // one-column kernel (qg_gemv.hip): products are formed in 64 bits, everything else in 32
-    out->gemv_ok = (!cx && d->N == 1 && d->n_levels >= 4 && d->n_levels <= 30 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
-    out->gemv_b_bit = (out->gemv_ok && d->b[0].I == 1 && d->b[0].F == 0 && !d->b[0].S && same(d->mul[0], d->a[0])) ? 1 : 0;
+    // (the Qreduce lowering: a * 1 into a's own format.  That is the identity for every raw value EXCEPT -2^W of a signed
+    // SAT::SMGN format, which the conversion clamps to -(2^W - 1): such element types take the ordinary product path)
+    out->gemv_b_bit = (out->gemv_ok && d->b[0].I == 1 && d->b[0].F == 0 && !d->b[0].S && same(d->mul[0], d->a[0]) &&
+                       !(d->a[0].S && d->a[0].O == QG_SAT_SMGN)) ? 1 : 0;
     out->gemv_fixed = 0;
     if (out->gemv_ok) {
         // all levels one format (the product's), exact alignment (d == 0), SAT::ZERO or SAT::TCPL
@@ -576,6 +583,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         for (uint32_t l = 0; l < d->n_levels && one; ++l)
             one = same(d->level_add[0][l], lf) && same(d->level[0][l], lf) && T.level_add[0][l].q.d == 0;
         if (one) out->gemv_fixed = lf.O == QG_SAT_ZERO ? 1 : 2;
+        else if (rec_form) out->gemv_fixed = rec_form;   // per-level formats in compact records (3: every level clamps, 5: kinds)
     }
     out->cplx_fast_ok = (cx && d->n_levels >= 5 && d->n_levels <= 16 && c.max_bits <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     // fixed-mode variant of the complex kernel (BASELINE configuration 5's "RND + SAT"): every sub-operation and every tree

@@ -390,7 +390,10 @@ def host_layout(e: Elem) -> Tuple[int, int, Tuple[int, int]]:
 # Qreduce<L...>(v) (/root/reference/include/QuBLAS.h:4960-4990, :5014-5018), expressed on the SAME engine path:
 # a batch of `rows` vectors of length `length` is the Qgemul  C[rows x 1] = A[rows x length] * ones[length x 1]
 # whose product format is the element's own format (Qmul(a, 1) into a's format is the identity: no
-# rounding shift, value in range) and whose level list is L.  The result type is the reducer's
+# rounding shift, value in range — with ONE exception: the raw value -2^W of a signed SAT::SMGN element
+# type, which the reference's fill() can produce but symmetric-saturation arithmetic never does; the
+# product's conversion clamps it to -(2^W - 1), where the reference's Qreduce would add it as it is)
+# and whose level list is L.  The result type is the reducer's
 # result type: the last level type, or the element type without levels (len 1: the element itself).
 ONE = Qu(1, 0, False)   # the constant 1 as an unsigned 1-bit integer
 

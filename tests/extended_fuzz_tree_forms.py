@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import qoracle as oracle  # noqa: E402
 from qublas_amd import capi  # noqa: E402
-from qublas_amd.desc import Qu, RND, SAT, TRN, WRP, Tags, lower  # noqa: E402
+from qublas_amd.desc import ONE, Qu, RND, SAT, TRN, WRP, Tags, lower, lower_reduce, reduce_result_type  # noqa: E402
 
 QM = [TRN.TCPL, TRN.TCPL, RND.POS_INF, RND.NEG_INF]
 OM = [SAT.TCPL, SAT.TCPL, SAT.SMGN, SAT.ZERO, SAT.ZERO, WRP.TCPL]
@@ -47,8 +47,17 @@ def main():
         ec = rq(rng, rng.choice([7, 12, 16, 24]))
         M, N = rng.randint(1, 130), rng.randint(1, 130)
         K = rng.choice([17, 32, 33, 64, 100, 128, 250, 256, 512, 1000, 2048])
+        reduce_form = False
+        if rng.random() < 0.3:           # one output column: the batched Qreduce / GEMV kernel (K a power of two >= 16)
+            N, K = 1, rng.choice([16, 32, 64, 128, 256, 1024, 4096])
+            M = rng.randint(1, 700)
+            reduce_form = rng.random() < 0.5
         try:
-            d = lower(ea, eb, ec, M, N, K, mul_args=mul, add_args=levels or None, transposed_a=rng.random() < 0.5)
+            if reduce_form:              # the Qreduce lowering: B is the 0/1 vector, the product is the element itself
+                eb, ec = ONE, reduce_result_type(ea, levels, K)
+                d = lower_reduce(ea, M, K, levels or None)
+            else:
+                d = lower(ea, eb, ec, M, N, K, mul_args=mul, add_args=levels or None, transposed_a=rng.random() < 0.5)
         except ValueError:
             skipped += 1
             continue
@@ -57,16 +66,16 @@ def main():
             skipped += 1
             continue
         k = capi.KERNEL_NAMES[info.kernel]
-        form = info.reason.decode().split("steps: ")[-1] if k == "tree_i32" else k
+        form = (("one column: " if k == "gemv_i32" else "") + info.reason.decode().split("steps: ")[-1]) if k in ("tree_i32", "gemv_i32") else k
         forms[form] = forms.get(form, 0) + 1
         dist = rng.randint(0, 1)
         A = oracle.fill(ea, M * K, rng.randint(1, 1 << 30), dist)
-        B = oracle.fill(eb, K * N, rng.randint(1, 1 << 30), dist)
+        B = np.ones(K, dtype=np.int32) if reduce_form else oracle.fill(eb, K * N, rng.randint(1, 1 << 30), dist)
         out = np.zeros(M * N, dtype=oracle.host_dtype(ec))
         capi.run(d, out, A, B)
         exp = oracle.gemm(d, A, B, ec, nthreads=8)
         ok = np.array_equal(out, exp)
-        if ok and k == "tree_i32":
+        if ok and k in ("tree_i32", "gemv_i32"):
             rt = np.zeros(M * N, dtype=oracle.host_dtype(ec))
             capi.run(d, rt, A, B, flags=capi.OPT_RUNTIME_MODES)
             ok = np.array_equal(rt, exp)

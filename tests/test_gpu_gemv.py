@@ -106,3 +106,33 @@ def test_fixed_mode_nodes_equal_runtime_mode_nodes(oracle, K):
         a = _check(oracle, d, e, e, e, ones=ones)
         b = _check(oracle, d, e, e, e, ones=ones, flags=capi.OPT_RUNTIME_MODES)
         assert np.array_equal(a, b)
+
+
+def test_one_column_step_forms_and_the_smgn_minimum(oracle):
+    """Per-level formats on the one-column kernels (the README's Qreduce<list>): compact records, against the oracle and the
+    run-time-mode kernel, long and short rows.  And the one raw value for which `a * 1 into a's own format` is NOT the
+    identity: -2^W of a signed SAT::SMGN element type (the conversion clamps it to -(2^W - 1)); found by
+    tests/extended_fuzz_tree_forms.py — the 0/1-vector shortcut must not be taken for such element types."""
+    from qublas_amd.desc import SAT, TRN, WRP, RND, lower_reduce, reduce_result_type
+    t1 = Qu(6, 3, True, TRN.TCPL, SAT.ZERO)
+    cases = [
+        (t1, [t1, Qu(6, -3)], "per-level formats, compact"),                                   # the README's level list
+        (Qu(8, 8), [Qu(10, 8), Qu(12, 8)], "per-level formats, compact (clamps)"),
+        (Qu(4, 3), [Qu(6, 5, True, RND.POS_INF, SAT.SMGN), Qu(9, 2, True, RND.NEG_INF, WRP.TCPL)], "per-level formats, compact"),
+        (Qu(3, 4, True, TRN.TCPL, SAT.SMGN), [Qu(4, 6, True, TRN.TCPL, SAT.ZERO)], "per-level formats, compact"),   # SMGN elements, a level with more fraction bits
+    ]
+    for e, levels, form in cases:
+        for rows, K in ((700, 64), (37, 1024), (5, 4096)):
+            d = lower_reduce(e, rows, K, levels)
+            info = capi.classify(d)
+            assert capi.KERNEL_NAMES[info.kernel] == "gemv_i32" and info.reason.decode().endswith(form), (info.reason, form)
+            ec = reduce_result_type(e, levels, K)
+            A = oracle.fill(e, rows * K, 11, 0)
+            A[:3] = e.raw_min                        # the format's raw minimum is present
+            B = np.ones(K, dtype=np.int32)
+            exp = oracle.gemm(d, A, B, ec)
+            for flags in (0, capi.OPT_RUNTIME_MODES):
+                out = np.zeros(rows, dtype=oracle.host_dtype(ec))
+                capi.run(d, out, A, B, flags=flags)
+                assert np.array_equal(out, exp), (str(e), K, flags)
+
