@@ -655,8 +655,9 @@ void Qgemul(TD& D, const TA& A, const TB& B, const S0& s0, const Stages&... st)
 // ------------------------------------------------------------------ Qreduce (SURVEY.md §8-f "next" #1)
 // The reference's tree reduction of a tensor, Qreduce<L…>(v) (QuBLAS.h:4960-4990, :5014-5018), on the
 // same engine path: C[1 x 1] = A[1 x len] * ones[len x 1] with the product format equal to the element
-// format (Qmul(a, 1) into a's own format is the identity — except for the raw value -2^W of a signed SAT::SMGN
-// element type, which that conversion clamps to -(2^W - 1)) and the level list L.  The result type is
+// format (Qmul(a, 1) into a's own format is the identity; for a signed SAT::SMGN element type, whose conversion would clamp
+// the raw minimum -2^W that the reference's Qreduce adds as it is, the leaf format is the element's with SAT::TCPL and the
+// default level type — the element type — is named explicitly) and the level list L.  The result type is
 // the reducer's: the last level type used, or the element type when there are no levels / one element.
 namespace detail {
 template <class Elem, size_t Len, class List> struct reduce_result { using type = Elem; };
@@ -684,11 +685,16 @@ auto Qreduce(const Qu_s<dim<D...>, Elem>& v)
     a.data = v.data;
     Qu_s<dim<len, 1>, one_t> ones;
     for (auto& o : ones.data) o.data = 1;
-    Qu_s<dim<1, 1>, res_t> c;
+    constexpr bool smgn = Elem::isS && Elem::OfM == QG_SAT_SMGN;
+    using leaf_t = std::conditional_t<smgn, scalar_of<Fmt{Elem::intB, Elem::fracB, Elem::isS, Elem::QuM, int(QG_SAT_TCPL)}>, Elem>;
+    using lv_t = std::conditional_t<(smgn && std::is_same_v<list, TypeList<>>), TypeList<Elem>, list>;
+    Qu_s<dim<1, 1>, std::conditional_t<(smgn && len <= 1), leaf_t, res_t>> c;
     [&]<class... Ls>(TypeList<Ls...>) {
-        Qgemul<QgemulAddArgs<Ls...>, QgemulMulArgs<Elem>, QgemulTransposedA<true>>(c, a, ones);
-    }(list{});
-    return c.data[0];
+        Qgemul<QgemulAddArgs<Ls...>, QgemulMulArgs<leaf_t>, QgemulTransposedA<true>>(c, a, ones);
+    }(lv_t{});
+    res_t r;
+    r.data = typename res_t::raw_t(c.data[0].data);
+    return r;
 }
 
 } // namespace QuBLAS_amd

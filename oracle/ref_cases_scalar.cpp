@@ -121,6 +121,29 @@ static void reduce_table(FILE* out, const char* name)
     std::fprintf(out, "]}\n");
 }
 
+// the same with the format's raw minimum -2^W forced into two elements: a signed SAT::SMGN element type holds it (fill() can
+// produce it) although symmetric-saturation arithmetic never does; Qreduce adds it as it is
+template <class T, size_t LEN, class... Levels>
+static void reduce_min_table(FILE* out, const char* name)
+{
+    std::string lv = "[";
+    ((lv += (lv.size() > 1 ? "," : "") + fmt_json<Levels>()), ...);
+    lv += "]";
+    constexpr int64_t rmin = T::isS ? -(int64_t(1) << (T::intB + T::fracB)) : 0;
+    std::fprintf(out, "{\"kind\":\"reduce\",\"name\":\"%s\",\"fin\":%s,\"levels\":%s,\"len\":%zu,\"dist\":0,\"seeds\":[1,2,3,4,5,6,7,8],\"min_at\":[0,%zu],\"y\":[", name,
+                 fmt_json<T>().c_str(), lv.c_str(), LEN, LEN / 2);
+    for (uint64_t seed = 1; seed <= 8; ++seed) {
+        Qu_s<dim<LEN>, T> v;
+        for (size_t i = 0; i < LEN; ++i) v[i].data.data = synth<T>(seed, 0, i, 0);
+        v[0].data.data = rmin;
+        v[LEN / 2].data.data = rmin;
+        auto r = Qreduce<Levels...>(v);
+        using R = decltype(r);
+        std::fprintf(out, "%s[%lld,%s]", seed > 1 ? "," : "", (long long)r.data.data, fmt_json<R>().c_str());
+    }
+    std::fprintf(out, "]}\n");
+}
+
 // Qu_s(double): loadFromDouble into a 2400-bit buffer, then the type's own fracConvert / intConvert
 // (QuBLAS.h:2387-2393, :663-749).  Doubles are printed as hex-float so the table is exact.
 template <class T>
@@ -264,6 +287,27 @@ int main(int argc, char** argv)
         cvt_table<s400, u33w>(out, lo, hi, step);
         cvt_table<s400, s31w>(out, lo, hi, step);
         cvt_table<s400, s30w>(out, lo, hi, step);
+        break;
+    }
+    case 7: {
+        // Qreduce on a signed SAT::SMGN element type whose raw minimum is present (and, for comparison, the same on TCPL / ZERO types)
+        using sm = Qu<intBits<3>, fracBits<4>, OfMode<SAT::SMGN>>;
+        using st = Qu<intBits<3>, fracBits<4>>;
+        using sz = Qu<intBits<3>, fracBits<4>, OfMode<SAT::ZERO>>;
+        using lz = Qu<intBits<4>, fracBits<6>, OfMode<SAT::ZERO>>;
+        using lw = Qu<intBits<9>, fracBits<4>>;
+        using lsm = Qu<intBits<5>, fracBits<3>, QuMode<RND::POS_INF>, OfMode<SAT::SMGN>>;
+        reduce_min_table<sm, 2>(out, "smgn_min_len2_default");
+        reduce_min_table<sm, 5>(out, "smgn_min_len5_default");
+        reduce_min_table<sm, 16>(out, "smgn_min_len16_default");
+        reduce_min_table<sm, 64>(out, "smgn_min_len64_default");
+        reduce_min_table<sm, 16, lz>(out, "smgn_min_len16_lz");
+        reduce_min_table<sm, 64, lw>(out, "smgn_min_len64_lw");
+        reduce_min_table<sm, 64, lsm, lw>(out, "smgn_min_len64_lsm_lw");
+        reduce_min_table<sm, 512, lw>(out, "smgn_min_len512_lw");
+        reduce_min_table<sm, 1000, lsm, lw>(out, "smgn_min_len1000_lsm_lw");
+        reduce_min_table<st, 64>(out, "tcpl_min_len64_default");
+        reduce_min_table<sz, 64, lz>(out, "zero_min_len64_lz");
         break;
     }
     default:

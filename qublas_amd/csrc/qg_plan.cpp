@@ -572,9 +572,14 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     }
     out->tree64_ok = (!cx && d->n_levels >= 5 && d->n_levels <= 16) ? 1 : 0;   // (max_bits <= 62 was checked above)
     // (the Qreduce lowering: a * 1 into a's own format.  That is the identity for every raw value EXCEPT -2^W of a signed
-    // SAT::SMGN format, which the conversion clamps to -(2^W - 1): such element types take the ordinary product path)
-    out->gemv_b_bit = (out->gemv_ok && d->b[0].I == 1 && d->b[0].F == 0 && !d->b[0].S && same(d->mul[0], d->a[0]) &&
-                       !(d->a[0].S && d->a[0].O == QG_SAT_SMGN)) ? 1 : 0;
+    // SAT::SMGN format, which the conversion clamps to -(2^W - 1); the lowerings therefore name a's format with SAT::TCPL
+    // as the leaf format of such element types, and only that form takes the shortcut)
+    {
+        qfmt leaf = d->a[0];
+        const bool smgn = leaf.S && leaf.O == QG_SAT_SMGN;
+        if (smgn) leaf.O = QG_SAT_TCPL;
+        out->gemv_b_bit = (out->gemv_ok && d->b[0].I == 1 && d->b[0].F == 0 && !d->b[0].S && same(d->mul[0], leaf)) ? 1 : 0;
+    }
     out->gemv_fixed = 0;
     if (out->gemv_ok) {
         // all levels one format (the product's), exact alignment (d == 0), SAT::ZERO or SAT::TCPL

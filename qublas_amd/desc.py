@@ -390,10 +390,8 @@ def host_layout(e: Elem) -> Tuple[int, int, Tuple[int, int]]:
 # Qreduce<L...>(v) (/root/reference/include/QuBLAS.h:4960-4990, :5014-5018), expressed on the SAME engine path:
 # a batch of `rows` vectors of length `length` is the Qgemul  C[rows x 1] = A[rows x length] * ones[length x 1]
 # whose product format is the element's own format (Qmul(a, 1) into a's format is the identity: no
-# rounding shift, value in range — with ONE exception: the raw value -2^W of a signed SAT::SMGN element
-# type, which the reference's fill() can produce but symmetric-saturation arithmetic never does; the
-# product's conversion clamps it to -(2^W - 1), where the reference's Qreduce would add it as it is)
-# and whose level list is L.  The result type is the reducer's
+# rounding shift, value in range; for a signed SAT::SMGN element type the leaf format is the element's
+# with SAT::TCPL, see lower_reduce) and whose level list is L.  The result type is the reducer's
 # result type: the last level type, or the element type without levels (len 1: the element itself).
 ONE = Qu(1, 0, False)   # the constant 1 as an unsigned 1-bit integer
 
@@ -408,8 +406,15 @@ def lower_reduce(e: Qu, rows: int, length: int, levels=None) -> qgemul_desc:
     if isinstance(e, Qcomplex):
         raise ValueError("complex Qreduce is not lowered yet")
     levels = list(levels) if levels else []
-    return lower(e, ONE, reduce_result_type(e, levels, length), rows, 1, length, add_args=levels, mul_args=e,
-                 transposed_a=True)
+    ec = reduce_result_type(e, levels, length)
+    if e.isSigned and e.OfMode == SAT.SMGN:
+        # the one element type for which Qmul(a, 1) into a's own format is not the identity: symmetric saturation clamps the raw
+        # minimum -2^W, which the reference's Qreduce adds as it is (tests/golden/ref_scalar_7).  The leaf conversion
+        # therefore targets a's format with SAT::TCPL (the identity on every raw value), and the default level type — the
+        # merge of two elements, i.e. the element type itself (AddMerger, QuBLAS.h:3125-3139) — is named explicitly.
+        leaf = Qu(e.intBits, e.fracBits, e.isSigned, e.QuMode, SAT.TCPL)
+        return lower(e, ONE, leaf if length <= 1 else ec, rows, 1, length, add_args=levels or [e], mul_args=leaf, transposed_a=True)
+    return lower(e, ONE, ec, rows, 1, length, add_args=levels, mul_args=e, transposed_a=True)
 
 
 # ---- element-wise epilogue: the lazy tensor operators after a Qgemul ----

@@ -10,7 +10,8 @@ from qublas_amd.desc import ONE, Qu, lower_reduce, reduce_result_type
 
 
 def _tables():
-    return [t for t in G.scalar_tables(4) if t["kind"] == "reduce"]
+    # part 4: the reduce tables; part 7: signed SAT::SMGN (and TCPL / ZERO) element types with the raw minimum -2^W present
+    return [t for part in (4, 7) for t in G.scalar_tables(part) if t["kind"] == "reduce"]
 
 
 def _batch(oracle, t):
@@ -22,6 +23,9 @@ def _batch(oracle, t):
     A = np.zeros(n * rows, dtype=np.int32)
     for r, seed in enumerate(t["seeds"]):
         A[r * n:(r + 1) * n] = [L.qoracle_synth(fin.c(), seed, t["dist"], i, 0) for i in range(n)]
+    for r in range(rows):
+        for i in t.get("min_at", []):
+            A[r * n + i] = fin.raw_min
     ec = reduce_result_type(fin, levels, n)
     return fin, levels, ec, A, np.ones(n, dtype=np.int32), rows
 
