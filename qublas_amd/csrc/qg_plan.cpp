@@ -653,13 +653,14 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                 const int ls = (!n.q.identity && n.q.d < 0) ? -n.q.d : 0;   // exact left shift after the operation: folded into the factors
                 if (n.q.identity) f.skip = 0;   // (the operation itself still runs; only its rounding / clamp is the identity)
                 (void)nonneg;
+                auto pow2 = [](int sh) { return sh >= 0 && sh <= 22 ? (int32_t)1 << sh : 0; };   // (0: out of the form's range, see reg)
                 if (sl.mul) {
-                    f.ka = 1 << ls;
+                    f.ka = pow2(ls);
                     reg = reg && ls <= 22 && b24(sl.x, ls) && b24(sl.y, 0);
                 } else {
-                    f.ka = 1 << (n.sa + ls);
-                    f.kb = 1 << (n.sb + ls);
-                    reg = reg && n.sa + ls <= 22 && n.sb + ls <= 22 && b24(sl.x, 0) && b24(sl.y, 0);
+                    f.ka = pow2(n.sa + ls);
+                    f.kb = pow2(n.sb + ls);
+                    reg = reg && n.sa >= 0 && n.sb >= 0 && n.sa + ls <= 22 && n.sb + ls <= 22 && b24(sl.x, 0) && b24(sl.y, 0);
                 }
             }
             for (int p = 0; p < 2 && reg; ++p)

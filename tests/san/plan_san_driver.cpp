@@ -31,7 +31,8 @@ int main()
             char why[96];
             ep_st = qg_analyze_ep(d.c[0], &ep, &t, &ep_bits, why, sizeof why);
         }
-        printf("%zu %d %d %d %d %d %d\n", count, an->status, an->cls, an->max_bits, an->linear_ok ? 1 : 0, an->tree_fast_ok ? 1 : 0, ep_st);
+        printf("%zu %d %d %d %d %d %d %d %d %d\n", count, an->status, an->cls, an->max_bits, an->linear_ok ? 1 : 0, an->tree_fast_ok ? 1 : 0, ep_st,
+               an->status == QG_OK ? an->fast_mode : -1, an->status == QG_OK ? an->cplx_fixed_ok : -1, an->status == QG_OK ? an->gemv_fixed : -1);
         delete an;
     }
     fprintf(stderr, "analysed %zu descriptors\n", count);

@@ -57,9 +57,42 @@ def random_descs(n, seed):
     return out
 
 
+def compact_form_descs(n, seed):
+    """descriptors whose roundings add a constant and whose overflows clamp / test / wrap: the planner's compact step records
+    (QFix: fast_mode 3 / 4 / 5, cplx_fixed_ok 2, gemv_fixed 3 / 5) are built for most of them"""
+    from qublas_amd.desc import BasicComplexMul, Qcomplex, TFComplexMul, lower_reduce
+    rng = random.Random(seed)
+    QM, OM = [5, 0, 1], [0, 0, 2, 1, 3]     # TRN::TCPL, RND::POS_INF, RND::NEG_INF; SAT::TCPL, SAT::SMGN, SAT::ZERO, WRP::TCPL
+
+    def rq(bits, om=OM):
+        i = rng.randint(0, bits)
+        return Qu(i + rng.choice([0, 0, 2]), bits - i - rng.choice([0, 0, 3]), rng.random() < 0.85, rng.choice(QM), rng.choice(om))
+    out = []
+    while len(out) < n:
+        kind = rng.random()
+        K = rng.choice([16, 17, 64, 100, 1024, 4096])
+        try:
+            if kind < 0.4:          # real, per-level formats
+                ea = rq(rng.choice([4, 8, 12, 16]))
+                d = lower(ea, ea, rq(12), rng.choice([1, 70]), rng.choice([1, 33]), K, mul_args=rq(rng.choice([8, 12, 20])) if rng.random() < 0.6 else None,
+                          add_args=[rq(rng.choice([10, 18, 26, 30])) for _ in range(rng.randint(0, 3))] or None)
+            elif kind < 0.55:       # Qreduce lowering (incl. signed SAT::SMGN element types)
+                d = lower_reduce(rq(rng.choice([4, 8, 12])), rng.choice([1, 9]), rng.choice([1, 2, 16, 64, 4096]), [rq(rng.choice([10, 18])) for _ in range(rng.randint(0, 2))] or None)
+            else:                   # complex, clamping modes
+                c = lambda b: Qcomplex(rq(b, [0, 0, 2]), rq(b, [0, 0, 2]))
+                ea = c(rng.choice([5, 8, 11]))
+                mul = TFComplexMul(abcT=Tags(rng.randint(4, 12), rng.randint(-2, 8)), ABT=rq(rng.choice([8, 14, 29]), [0, 2]) if rng.random() < 0.3 else None) if rng.random() < 0.5 \
+                    else BasicComplexMul(acT=Tags(rng.randint(4, 24), rng.randint(-2, 10)) if rng.random() < 0.5 else None)
+                d = lower(ea, ea, c(12), 9, 7, K, mul_args=mul, add_args=[c(rng.choice([10, 16, 24])) for _ in range(rng.randint(0, 2))] or None)
+        except (ValueError, OverflowError):
+            continue
+        out.append(d)
+    return out
+
+
 def test_planner_under_asan_ubsan(tmp_path):
     exe = build_driver(str(tmp_path))
-    descs = [desc_from_dict(j) for j in G.gemm_cases("real") + G.gemm_cases("cplx")] + random_descs(3000, 5)
+    descs = [desc_from_dict(j) for j in G.gemm_cases("real") + G.gemm_cases("cplx")] + random_descs(3000, 5) + compact_form_descs(1500, 6)
     blob = bytearray()
     ep0 = qgemul_epilogue()
     for d in descs:
@@ -73,11 +106,15 @@ def test_planner_under_asan_ubsan(tmp_path):
     # same verdicts as the product library (the same source compiled by hipcc)
     L = capi.lib()
     n_ok = 0
+    forms = {"fast": set(), "cplx": set(), "gemv": set()}
     for ln, d in zip(lines, descs):
-        _, st, cls, bits, *_ = ln.split()
+        _, st, cls, bits, _, _, _, fm, cf, gf = ln.split()
+        forms["fast"].add(int(fm)); forms["cplx"].add(int(cf)); forms["gemv"].add(int(gf))
         info = capi.qgemul_info()
         assert L.qgemul_classify(C.byref(d), 0, C.byref(info)) == int(st)
         if int(st) == 0:
             assert info.cls == int(cls) and info.max_bits == int(bits)
             n_ok += 1
     assert n_ok > 500
+    # the record-building code ran under the sanitizers for every form
+    assert {1, 2, 3, 4, 5} <= forms["fast"] and {1, 2} <= forms["cplx"] and {1, 2, 3, 5} <= forms["gemv"], forms
