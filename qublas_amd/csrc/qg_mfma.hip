@@ -76,8 +76,11 @@ __device__ __forceinline__ void interleave_hint(std::integer_sequence<int, M...>
 // out with the operands' row sums: sum ab = sum a'b' - biasB rsA[i] - biasA rsB[j] + K biasA biasB.  Exact: every P is an
 // int32 as long as K * 126^2 < 2^31 (planner).  (The 3 x 3-digit form needs 6 accumulator sets — 384 registers for a
 // 64 x 64 wave tile — which hipcc cannot allocate without spilling)
-template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE, int ABL, bool EP, int SA = LA, int SB = LB, bool KARA = false>   // EP: fused element-wise epilogue
-__global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
+// KS > 1 (small problems): KS wave groups of WGM x WGN waves split the k-tiles of ONE output tile among them — each group has its
+// own LDS ring and walks nk / KS consecutive k-tiles, twice the LDS-DMA transfers in flight and half the k-loop per wave —
+// and the groups' accumulators are summed through LDS before the one epilogue (no atomics, no memset, no second launch).
+template <int LA, int LB, int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE, int ABL, bool EP, int SA = LA, int SB = LB, bool KARA = false, int KS = 1>   // EP: fused element-wise epilogue
+__global__ __launch_bounds__(64 * WGM * WGN * KS) void k_mfma(QMfmaArgs g)
 {
     if constexpr (SA == 3 && SB == 3 && ABL == 0) {
         const unsigned ma = qg_plane_mask(g.maskA);
@@ -95,10 +98,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
     constexpr int KSTEPS = BK / 32;            // MFMA k-steps per tile
     static_assert(PIECES % NWAVES == 0, "every wave issues the same number of LDS-DMA pieces");
     static_assert(NSTAGE >= 2 && (NSTAGE - 2) * PPW < 64, "vmcnt is a 6-bit counter");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
 
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kg = KS > 1 ? wave_all / NWAVES : 0;          // k group of this wave (wave-uniform)
+    const int wave = KS > 1 ? wave_all % NWAVES : wave_all;
+    char* smem = smem_all + kg * (NSTAGE * STAGE);           // the group's own ring
     const int wm = wave / WGN, wn = wave % WGN;
 
     // XCD-aware tile order: consecutive block ids go to different XCDs, so give each XCD a
@@ -119,12 +125,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
 
     // operands are pre-tiled: block (row tile, k tile) of A is LA*TM*BK contiguous bytes that are
     // already the swizzled LDS image; same for B.  A stage is two linear copies.
-    const int nk = (int)(g.Kp / BK);
+    const int nk_all = (int)(g.Kp / BK);
+    const int nk = nk_all / KS;                                         // k-tiles of this group (the launcher checks divisibility)
     constexpr int A_BYTES = LA * TM * BK, B_BYTES = LB * TN * BK;       // copied per stage (the first LA / LB planes)
     constexpr int A_STORED = SA * TM * BK, B_STORED = SB * TN * BK;     // stride of a (row tile, k tile) block in memory
     constexpr int A_PIECES = A_BYTES / 1024;
-    const int8_t* Ag = g.A + (int64_t)tile_m * nk * A_STORED + lane * 16;
-    const int8_t* Bg = g.B + (int64_t)tile_n * nk * B_STORED + lane * 16;
+    const int8_t* Ag = g.A + ((int64_t)tile_m * nk_all + (int64_t)kg * nk) * A_STORED + lane * 16;
+    const int8_t* Bg = g.B + ((int64_t)tile_n * nk_all + (int64_t)kg * nk) * B_STORED + lane * 16;
 
     auto issue = [&](int stage, int kt) {
         char* sbase = smem + stage * STAGE;
@@ -267,6 +274,31 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma(QMfmaArgs g)
     // the branch-free refill leaves LDS-DMA transfers of the clamped tile in flight: they must have landed before this
     // workgroup can end and its LDS be handed to another one
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    if constexpr (KS > 1) {
+        // sum the groups' accumulators: groups 1 .. KS-1 park theirs in LDS (the rings are free now), group 0 adds them
+        static_assert(KS == 1 || (NW == 1 && !KARA && !EP), "k split: single-limb kernels");
+        __syncthreads();
+        int* red = (int*)smem_all;   // [KS - 1][NWAVES][TI * TJ][16][64]
+        if (kg > 0) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) red[((((kg - 1) * NWAVES + wave) * (TI * TJ) + i * TJ + j) * 16 + e) * 64 + lane] = acc[0][i][j][e];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int q = 0; q < KS - 1; ++q)
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[0][i][j][e] += red[(((q * NWAVES + wave) * (TI * TJ) + i * TJ + j) * 16 + e) * 64 + lane];
+    }
 
     // epilogue: recombine limb weights, ONE round + overflow into C, store.
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5),
@@ -742,6 +774,23 @@ hipError_t launch(const QMfmaArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
+// single limb, KS k groups per workgroup (see k_mfma)
+template <int BK, int WGM, int WGN, int TI, int TJ, int NSTAGE, int KS>
+hipError_t launch_ksplit(const QMfmaArgs& a, hipStream_t st)
+{
+    constexpr int TM = WGM * TI * 32, TN = WGN * TJ * 32;
+    constexpr int STAGE = (TM + TN) * BK;
+    constexpr int RED = (KS - 1) * WGM * WGN * TI * TJ * 16 * 64 * 4;
+    const int lds = KS * NSTAGE * STAGE > RED ? KS * NSTAGE * STAGE : RED;
+    static std::atomic<uint64_t> attr_done{0};
+    if (hipError_t e = qg_lds_attr((const void*)k_mfma<1, 1, BK, WGM, WGN, TI, TJ, NSTAGE, 0, false, 1, 1, false, KS>, lds, attr_done); e != hipSuccess) return e;
+    const int64_t blocks = (a.Mp / TM) * (a.Np / TN);
+    if (blocks <= 0) return hipSuccess;
+    if (blocks > 0x7fffffffll || a.Kp % (BK * KS) || a.Mp % TM || a.Np % TN || a.has_ep || a.kara) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_mfma<1, 1, BK, WGM, WGN, TI, TJ, NSTAGE, 0, false, 1, 1, false, KS>), dim3((unsigned)blocks), dim3(64 * WGM * WGN * KS), lds, st, a);
+    return hipGetLastError();
+}
+
 } // namespace
 
 QMfmaCfg qg_mfma_pick(int LA, int LB, int64_t M, int64_t N, uint32_t opt_flags)
@@ -832,7 +881,16 @@ hipError_t qg_launch_mfma(int LA, int LB, const QMfmaArgs& a_in, hipStream_t st)
         // (0.283 vs 0.308 ms at 8192x8192x4096, profiles/r01n_ablation_mfma_shape.log); QG_ABLATE=32 keeps the other
         if (a.variant == 9) return a.has_ep ? hipErrorInvalidValue : qg_launch_mfma_pp(a, st);
         if (a.variant == 5) return launch<1, 1, 64, 2, 2, 1, 1, 3>(a, st);   // 64x64 tiles, one 32x32 MFMA tile per wave
-        if (a.variant == 7) return launch<1, 1, 128, 2, 2, 1, 1, 3>(a, st);   // the same on 128-byte k-tiles
+        if (a.variant == 7) {   // the same on 128-byte k-tiles
+            // ... with two k groups per workgroup for long-k problems of at most one workgroup per CU (diag: QG_NO_KSPLIT for A/B).
+            // Measured (us, split / not split): 512^2 x 4096 9.30 / 10.20, 256^2 x 4096 9.16 / 10.03 — but 1024^3 (8 k-tiles)
+            // 5.50 / 5.30, and with more than 256 workgroups the 8-wave, 96 KB workgroups no longer share a CU: 1536 x 1024^2
+            // 9.34 / 6.01, 2048 x 1024 x 512 8.17 / 5.02 (profiles/r04_small_ksplit.jsonl).
+            static const bool no_ks = QG_DIAG_ENV("QG_NO_KSPLIT");
+            if (!no_ks && !a.has_ep && (a.Kp / 128) % 2 == 0 && a.Kp / 128 >= 16 && (a.Mp / 64) * (a.Np / 64) <= 256)
+                return launch_ksplit<128, 2, 2, 1, 1, 3, 2>(a, st);
+            return launch<1, 1, 128, 2, 2, 1, 1, 3>(a, st);
+        }
         if (a.variant == 8) return launch<1, 1, 128, 2, 2, 2, 2, 3>(a, st);   // 128x128 tiles on 128-byte k-tiles
 #ifdef QG_DIAG
         if (ablation() == 32) return a.variant == 2 ? launch<1, 1, 64, 2, 4, 4, 2, 3>(a, st) : launch<1, 1, 64, 2, 2, 2, 2, 3>(a, st);

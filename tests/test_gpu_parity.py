@@ -79,6 +79,17 @@ def test_mfma_i8_vs_oracle(oracle, shape, ta):
     assert saturated_fraction(c, W16) < 0.5  # the comparison is not hidden by saturation
 
 
+@pytest.mark.parametrize("shape", [(512, 512, 4096), (256, 256, 2048), (500, 130, 4096), (64, 1000, 8192), (512, 512, 1920), (1024, 1024, 2048)])
+def test_small_single_limb_long_k(oracle, shape):
+    """Long-k single-limb problems of at most one 64 x 64 tile per CU run with TWO k groups per workgroup (each its own LDS ring
+    and half of the k-tiles, accumulators summed through LDS before the epilogue); 15 k-tiles (K = 1920) and 1024^2 (one
+    workgroup per CU, but the 128-tile form) keep one group.  All against the oracle, narrow and wide C."""
+    M, N, K = shape
+    for ec in (W16, Qu(6, 1, True, RND.CONV, SAT.SMGN)):
+        c = _vs_oracle(oracle, E43, E43, ec, M, N, K, dist=1, mul_args=Tags(9, 6), add_args=[Qu(22, 6)], expect_kernel="mfma_i8")
+    assert len(np.unique(c)) > 8
+
+
 @pytest.mark.parametrize("qm", [RND.POS_INF, RND.NEG_INF, RND.ZERO, RND.INF, RND.CONV, TRN.TCPL, TRN.SMGN])
 @pytest.mark.parametrize("om", [SAT.TCPL, SAT.ZERO, SAT.SMGN, WRP.TCPL])
 def test_mfma_epilogue_modes(oracle, qm, om):
