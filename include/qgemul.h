@@ -155,7 +155,7 @@ enum {
 enum {
     QG_OK = 0,
     QG_EINVAL = -1,       /* malformed descriptor / null pointer / bad size */
-    QG_EUNSUPPORTED = -2, /* e.g. WRP::TCPL_SAT, an intermediate wider than 62 bits */
+    QG_EUNSUPPORTED = -2, /* e.g. WRP::TCPL_SAT, an intermediate wider than 62 bits (the unrounded product of two operands: 64) */
     QG_EHIP = -3,         /* a HIP runtime call failed; qgemul_last_hip_error() has the code */
     QG_ERCCL = -4,
     QG_ERANGE = -5,       /* QG_OPT_CHECK_RANGE: an input raw value is outside its format */

@@ -443,7 +443,10 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     out->max_bits = c.max_bits;
     out->max_bits_np = c.max_bits_np;
     c.max_fmt_bits = g_fmt_bits_seen; // the int32 kernels keep every format's bounds in 32-bit registers
-    if (c.max_bits > 62) { c.fail(QG_EUNSUPPORTED, "an intermediate needs more than 62 bits"); return; }
+    // 64-bit kernels: every value within 62 bits, so that sums, alignment shifts and rounding addends stay inside int64 — except
+    // the unrounded product of two operands, which is formed exactly by one 64-bit multiply and goes straight into its rounding
+    // shift: it may use all of int64 (two signed 32-bit words: |a * b| <= 2^62).  32-bit fixed-point words therefore run.
+    if (c.max_bits_np > 62 || c.max_bits > 64) { c.fail(QG_EUNSUPPORTED, "an intermediate needs more than 62 bits"); return; }
     out->linear_ok = c.exact ? 1 : 0;
     out->cls = out->linear_ok ? QG_CLASS_LINEAR : QG_CLASS_TREE;
     // 32-bit tree kernel (qg_tree_fast.hip): real, K a power of two >= 32, every value except the

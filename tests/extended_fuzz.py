@@ -26,10 +26,12 @@ def main():
     for it in range(cases):
         cx = rng.random() < 0.15
         wide = rng.random() < 0.3
-        mw = 22 if wide else 12
+        words = rng.random() < 0.12          # operands of up to 32 storage bits: the unrounded product uses all of an int64
+        mw = rng.choice([26, 28, 30, 31]) if words else 22 if wide else 12
         if cx:
-            ea = Qcomplex(rand_qu(rng, 9), rand_qu(rng, 9))
-            eb = ea if rng.random() < 0.5 else Qcomplex(rand_qu(rng, 9), rand_qu(rng, 9))
+            pw = rng.choice([24, 28, 31]) if words else 9
+            ea = Qcomplex(rand_qu(rng, pw), rand_qu(rng, pw))
+            eb = ea if rng.random() < 0.5 else Qcomplex(rand_qu(rng, pw), rand_qu(rng, pw))
             ec = Qcomplex(rand_qu(rng, 16), rand_qu(rng, 16))
             sub = lambda: rand_qu(rng, 14) if rng.random() < 0.5 else None  # noqa: E731
             m = (TFComplexMul(abT=sub(), cdT=sub(), baT=sub(), abcT=sub(), cdbT=sub(), badT=sub(), ABT=sub(), BCT=sub()) if rng.random() < 0.5
@@ -44,7 +46,7 @@ def main():
                 pf = Qu(ea.intBits + eb.intBits + 1, ea.fracBits + eb.fracBits, ea.isSigned or eb.isSigned)
                 kw = dict(mul_args=pf, add_args=[Qu(pf.intBits + 12, pf.fracBits, pf.isSigned)])
             else:
-                lv = [rand_qu(rng, 40 if wide else 14) for _ in range(rng.randint(0, 3))]
+                lv = [rand_qu(rng, 40 if (wide or words) else 14) for _ in range(rng.randint(0, 3))]
                 kw = dict(mul_args=rand_tags(rng, ea), add_args=lv or None)
             ec = rand_qu(rng, rng.choice([30, 36, 44]) if wide else rng.choice([16, 16, 34]))
         M = rng.randint(1, 150)

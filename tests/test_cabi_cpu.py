@@ -110,6 +110,13 @@ def test_rejections():
     d = lower(Qu(30, 30), Qu(30, 30), Qu(8, 8), 4, 4, 4, mul_args=Qu(60, 60))
     st, _ = capi.classify_status(d)
     assert st == capi.QG_EUNSUPPORTED
+    # ... but the UNROUNDED product of two operands may use all of an int64: signed 32-bit words (Q15.16) are admitted, two
+    # unsigned 32-bit words (a 64-bit magnitude) and a 33-bit pair are not
+    q = Qu(15, 16)
+    st, info = capi.classify_status(lower(q, q, q, 4, 4, 64))
+    assert st == capi.QG_OK and info.max_bits == 64, info.reason
+    for a, b in ((Qu(16, 16, False), Qu(16, 16, False)), (Qu(16, 16), Qu(15, 16))):
+        assert capi.classify_status(lower(a, b, q, 4, 4, 64))[0] == capi.QG_EUNSUPPORTED
     d = lower(e, e, e, 4, 4, 4)
     d.n_levels = 5
     st, _ = capi.classify_status(d)

@@ -229,6 +229,39 @@ def test_complex_fast_kernel_tags_and_levels(oracle):
         assert fields_equal(a, b)
 
 
+def test_32_bit_fixed_point_words(oracle):
+    """Operands of 32 storage bits (Q15.16 and friends): the unrounded product of two of them needs all 64 bits of an int64
+    (|a * b| <= 2^62), which the planner admits for the ONE exact 64-bit multiply that feeds its rounding shift, while every
+    other intermediate stays within 62 bits.  Real (64-bit tree kernel), one column, complex (general kernel), full-range
+    operands incl. the raw minimum, several modes."""
+    q = Qu(15, 16)
+    cases = [
+        (q, q, q, dict(), "tree_i64"),                                                                     # default tags: every product and node saturates
+        (q, q, Qu(24, 16, True, RND.CONV, SAT.SMGN), dict(add_args=[Qu(24, 16), Qu(28, 12, True, RND.ZERO, SAT.ZERO)]), "tree_i64"),
+        (Qu(20, 11, True, TRN.SMGN, WRP.TCPL), Qu(3, 28), Qu(20, 11), dict(mul_args=Tags(20, 11)), "tree_i64"),
+        (q, Qu(15, 16, False), Qu(18, 13), dict(), "tree_i64"),                                          # signed 32 x unsigned 31 bits
+    ]
+    for ea, eb, ec, kw, kern in cases:
+        for M, N, K, ta in ((37, 29, 64, False), (16, 40, 300, True), (50, 1, 1024, False)):
+            d = lower(ea, eb, ec, M, N, K, transposed_a=ta, **kw)
+            assert capi.KERNEL_NAMES[capi.classify(d).kernel] == kern
+            A, B = oracle.fill(ea, M * K, 3, 0), oracle.fill(eb, K * N, 4, 0)
+            A[:2] = ea.raw_min
+            B[:2] = eb.raw_min                                                                            # (-2^31) * (-2^31) = 2^62 is present
+            got = run_gpu(d, A, B, ec, oracle)
+            assert fields_equal(got, oracle.gemm(d, A, B, ec, nthreads=8)), (str(ea), str(eb), M, N, K)
+    cq = Qcomplex(q, q)
+    for mul in (BasicComplexMul(), TFComplexMul()):
+        d = lower(cq, cq, cq, 21, 17, 64, mul_args=mul)
+        assert capi.KERNEL_NAMES[capi.classify(d).kernel] == "tree_cplx"
+        A, B = oracle.fill(cq, 21 * 64, 5, 0), oracle.fill(cq, 64 * 17, 6, 0)
+        assert fields_equal(run_gpu(d, A, B, cq, oracle), oracle.gemm(d, A, B, cq, nthreads=8))
+    # two UNSIGNED 32-bit words: the product needs 64 magnitude bits and is still refused
+    u = Qu(16, 16, False)
+    st, info = capi.classify_status(lower(u, u, u, 8, 8, 64))
+    assert st == capi.QG_EUNSUPPORTED and b"62 bits" in info.reason
+
+
 def test_real_tree_kernel_step_forms(oracle):
     """The 32-bit tree kernel's step forms (the planner reports the form in info.reason): one format everywhere (default
     tags), per-level formats in the compact form of qg_fix.h — roundings that add a constant and shift (TRN::TCPL,
