@@ -36,6 +36,16 @@ int main()
         Qu<dim<4>, e43> v = {1.0, 2.0, 3.0, 4.0};
         auto r = Qreduce<Qu<intBits<8>, fracBits<3>>>(v);
         std::printf("{\"name\":\"qreduce\",\"C\":[%lld]}\n", (long long)r.data);
+        // a signed SAT::SMGN element type whose raw minimum -2^W is present: the reference's Qreduce adds it as it is (the leaf
+        // format of the lowering is the element's with SAT::TCPL; tests/golden/ref_scalar_7)
+        using sm = Qu<intBits<3>, fracBits<4>, OfMode<SAT::SMGN>>;
+        Qu<dim<16>, sm> w;
+        for (size_t i = 0; i < 16; ++i) w[i].fill(int64_t((i * 37) % 256) - 128);
+        w[0].fill(-128);
+        w[8].fill(-128);
+        auto r1 = Qreduce<Qu<intBits<4>, fracBits<6>, OfMode<SAT::ZERO>>>(w);
+        auto r2 = Qreduce<>(w);
+        std::printf("{\"name\":\"qreduce_smgn\",\"C\":[%lld,%lld]}\n", (long long)r1.data, (long long)r2.data);
     } catch (const std::exception& e) {
         std::printf("{\"error\":\"%s\"}\n", e.what());
         return 3;

@@ -63,6 +63,20 @@ def test_standalone_header_runs_on_gpu(tmp_path):
     assert _check(lines) == 4
     q = [json.loads(l) for l in lines if '"qreduce"' in l]
     assert q and q[0]["C"] == [80]
+    # Qreduce on signed SAT::SMGN elements with the raw minimum present: the header's lowering against the Python one (which
+    # the reference's own tables pin, tests/test_reduce.py)
+    import numpy as np
+    from oracle import qoracle as oracle
+    from qublas_amd.desc import Qu, SAT, TRN, lower_reduce, reduce_result_type
+    sm = Qu(3, 4, True, TRN.TCPL, SAT.SMGN)
+    w = np.array([(i * 37) % 256 - 128 for i in range(16)], dtype=np.int32)
+    w[0] = w[8] = -128
+    exp = []
+    for levels in ([Qu(4, 6, True, TRN.TCPL, SAT.ZERO)], None):
+        ec = reduce_result_type(sm, levels or [], 16)
+        exp.append(int(oracle.gemm(lower_reduce(sm, 1, 16, levels), w, np.ones(16, dtype=np.int32), ec)[0]))
+    qs = [json.loads(l) for l in lines if '"qreduce_smgn"' in l]
+    assert qs and qs[0]["C"] == exp
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="needs AMD clang (C++23)")
