@@ -192,7 +192,8 @@ enum {
     QG_KERNEL_TREE_CPLX = 5,    /* class T, complex, any descriptor (64-bit) */
     QG_KERNEL_TREE_CPLX_I32 = 6,/* class T, complex, K = 2^p and 32-bit intermediates */
     QG_KERNEL_MFMA_CPLX = 7,    /* class L, complex: four real int8-limb dot products on MFMA + one combine pass */
-    QG_KERNEL_GEMV_I32 = 8      /* class T, N = 1 (batched Qreduce / GEMV), K = 2^p >= 16, 32-bit values: one wave per row (or per 256/K rows) */
+    QG_KERNEL_GEMV_I32 = 8,     /* class T, N = 1 (batched Qreduce / GEMV), K = 2^p >= 16, 32-bit values: one wave per row (or per 256/K rows) */
+    QG_KERNEL_GEMV_I64 = 9      /* the same with 64-bit tree values on elements of at most 32 storage bits (32-bit words, wide level types) */
 };
 
 /* ---- descriptor analysis: pure host code, works without a GPU ---- */

@@ -26,7 +26,7 @@ OPT_FORCE_TREE, OPT_CHECK_RANGE, OPT_GENERIC_TREE, OPT_RUNTIME_MODES, OPT_FUSED_
 OPT_GENERIC_LAYOUT, OPT_LOCKSTEP_TILES, OPT_ARITHMETIC_CONV, OPT_ALL_DEVICES = 64, 128, 256, 512
 OPERAND_A, OPERAND_B, OPERAND_C = 0, 1, 2
 BITS_ASCII, BITS_PACKED = 0, 1
-KERNEL_NAMES = {0: "none", 1: "mfma_i8", 2: "mfma_i8_limb", 3: "tree_i32", 4: "tree_i64", 5: "tree_cplx", 6: "tree_cplx_i32", 7: "mfma_cplx", 8: "gemv_i32"}
+KERNEL_NAMES = {0: "none", 1: "mfma_i8", 2: "mfma_i8_limb", 3: "tree_i32", 4: "tree_i64", 5: "tree_cplx", 6: "tree_cplx_i32", 7: "mfma_cplx", 8: "gemv_i32", 9: "gemv_i64"}
 
 EXPORTS = [
     "qgemul_classify", "qgemul_strerror", "qgemul_abi_version", "qgemul_last_hip_error", "qgemul_run",

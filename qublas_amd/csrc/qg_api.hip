@@ -179,11 +179,12 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     } else {
         const bool fast = !(flags & QG_OPT_GENERIC_TREE);
         kernel = d->is_complex ? ((an->cplx_fast_ok && fast) ? QG_KERNEL_TREE_CPLX_I32 : QG_KERNEL_TREE_CPLX)
-                               : ((an->gemv_ok && fast) ? QG_KERNEL_GEMV_I32 : (an->tree_fast_ok && fast) ? QG_KERNEL_TREE_I32 : QG_KERNEL_TREE_I64);
+                               : ((an->gemv_ok && fast) ? QG_KERNEL_GEMV_I32 : (an->gemv_wide_ok && fast) ? QG_KERNEL_GEMV_I64
+                                  : (an->tree_fast_ok && fast) ? QG_KERNEL_TREE_I32 : QG_KERNEL_TREE_I64);
         // the 32-bit tree kernels walk a perfect binary tree: their operands are zero-padded along K to 2^n_levels leaves
         // (a node whose right child is a zero leaf / zero subtree is the reference's converting copy of an odd leftover)
         const bool t64 = kernel == QG_KERNEL_TREE_I64 && an->tree64_ok && fast;   // the 2x2-per-lane 64-bit kernel, not the general one
-        const int64_t Kt = (kernel == QG_KERNEL_TREE_I32 || kernel == QG_KERNEL_TREE_CPLX_I32 || kernel == QG_KERNEL_GEMV_I32 || t64)
+        const int64_t Kt = (kernel == QG_KERNEL_TREE_I32 || kernel == QG_KERNEL_TREE_CPLX_I32 || kernel == QG_KERNEL_GEMV_I32 || kernel == QG_KERNEL_GEMV_I64 || t64)
                                ? ((int64_t)1 << d->n_levels) : d->K;
         *pa = QPackedGeom{d->M, Kt, info->in_bits[0] <= 32 ? 4 : 8, 0, 0, 0};
         *pb = QPackedGeom{d->N, Kt, info->in_bits[1] <= 32 ? 4 : 8, 0, 0, 0};
@@ -197,6 +198,8 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
         snprintf(info->reason, sizeof info->reason, "exact tree evaluation; tree kernel steps: %s",
                  fm == 1 ? "one format, SAT::ZERO" : fm == 2 ? "one format, SAT::TCPL" : fm == 3 ? "per-level formats, compact (clamps)" : fm == 4 ? "per-level formats, compact" : fm == 5 ? "per-level formats, compact (unbiased)" : "run-time modes");
     }
+    if (kernel == QG_KERNEL_GEMV_I64)
+        snprintf(info->reason, sizeof info->reason, "exact tree evaluation; one-column kernel steps: run-time modes, 64-bit values");
     if (kernel == QG_KERNEL_GEMV_I32) {
         const int fm = (flags & QG_OPT_RUNTIME_MODES) ? 0 : an->gemv_fixed;
         snprintf(info->reason, sizeof info->reason, "exact tree evaluation; one-column kernel steps: %s",
@@ -887,6 +890,10 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
         QG_HIP(qg_launch_tree_fast(p->dev_table, (int)p->desc.n_levels, p->an.split_s, p->an.mul24_ok,
                                    (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : p->an.fast_mode, packedA, packedB, packedC,
                                    p->desc.M, p->desc.N, p->pa.K_p, pcg.cbytes, st));
+        return QG_OK;
+    case QG_KERNEL_GEMV_I64:
+        QG_HIP(qg_launch_gemv(p->dev_table, (int)p->desc.n_levels, p->an.gemv_b_bit, 0, packedA, packedB, packedC, p->desc.M, p->pa.K_p,
+                              pcg.cbytes, st, 1));
         return QG_OK;
     case QG_KERNEL_GEMV_I32:
         QG_HIP(qg_launch_gemv(p->dev_table, (int)p->desc.n_levels, p->an.gemv_b_bit, (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : p->an.gemv_fixed,

@@ -61,12 +61,12 @@ constexpr int MAXUP = 20;   // levels above a segment (K < 2^31)
 
 // node of level l: acc (LEFT child) + x, quantised by the level's add format, then stored into the level buffer's type
 // (children share one format: no alignment shift in a real GEMM tree)
-template <int N>
-__device__ __forceinline__ void node_all(int (&acc)[N], const int (&x)[N], CTab tab, int level)
+template <int N, class T = int>
+__device__ __forceinline__ void node_all(T (&acc)[N], const T (&x)[N], CTab tab, int level)
 {
 #pragma unroll
     for (int o = 0; o < N; ++o) acc[o] += x[o];
-    qg_step_all<int, N>(acc, load_step(&tab->level_add[0][level].q));   // (level_cvt is the identity in a real GEMM tree)
+    qg_step_all<T, N>(acc, load_step(&tab->level_add[0][level].q));   // (level_cvt is the identity in a real GEMM tree)
 }
 
 // in-lane levels: v[0..CNT) -> v[0..CNT/2) ... -> v[0]
@@ -99,17 +99,17 @@ __device__ __forceinline__ void node_rec(int (&acc)[N], const int (&x)[N], const
     else fx_finish<N>(acc, f);
 }
 
-template <int CNT, int MODE>
-__device__ __forceinline__ int lane_tree(int (&v)[CNT], CTab tab, int level, int lo, int hi)
+template <int CNT, int MODE, class T = int>
+__device__ __forceinline__ T lane_tree(T (&v)[CNT], CTab tab, int level, int lo, int hi)
 {
     if constexpr (CNT == 1) {
         return v[0];
     } else {
-        int h[CNT / 2];   // (arrays of exact size, indexed only by unrolled loops: registers, never scratch)
+        T h[CNT / 2];   // (arrays of exact size, indexed only by unrolled loops: registers, never scratch)
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int o = 0; o < CNT / 2; ++o) h[o] = v[2 * o] + v[2 * o + 1];   // left child + right child, in the tree's order
-            qg_step_all<int, CNT / 2>(h, load_step(&tab->level_add[0][level].q));
+            qg_step_all<T, CNT / 2>(h, load_step(&tab->level_add[0][level].q));
         } else if constexpr (MODE >= 3) {
             int r[CNT / 2];
 #pragma unroll
@@ -119,13 +119,17 @@ __device__ __forceinline__ int lane_tree(int (&v)[CNT], CTab tab, int level, int
 #pragma unroll
             for (int o = 0; o < CNT / 2; ++o) h[o] = node_fixed<MODE>(v[2 * o], v[2 * o + 1], lo, hi);
         }
-        return lane_tree<CNT / 2, MODE>(h, tab, level + 1, lo, hi);
+        return lane_tree<CNT / 2, MODE, T>(h, tab, level + 1, lo, hi);
     }
 }
 
-template <int CH, int MODE>   // leaves per lane and segment; MODE: 0 run-time modes, 1 / 2 fixed (see node_fixed)
+// T = int64_t (MODE 0 only): the tree's values need more than 31 bits — sums of 32-bit words, wide level types — while the
+// elements still come in 4-byte containers; the same streaming structure on 64-bit nodes (still HBM-bound by far: the general
+// 64-bit tree kernel, built for square output tiles, ran a 65 536 x 4096 reduction of Q15.16 at 140 GB/s).
+template <int CH, int MODE, class T = int>   // leaves per lane and segment; MODE: 0 run-time modes, 1 / 2 fixed (see node_fixed)
 __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
 {
+    static_assert(sizeof(T) == 4 || MODE == 0, "64-bit values: run-time modes");
     constexpr int Q = CH == 32 ? 5 : CH == 16 ? 4 : CH == 8 ? 3 : 2;
     static_assert(CH <= 32 && CH >= 4, "leaves per lane");
     constexpr int SEG = 64 * CH;                 // leaves per segment
@@ -154,8 +158,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
 
     // binary counter over the levels above a segment (only vectors longer than one segment use it): per wave in LDS, so
     // that it can be indexed at run time; lane 0 holds the real partial results and is the only writer
-    __shared__ int upbuf[WAVES][MAXUP];
-    int* up = &upbuf[wave][0];
+    __shared__ T upbuf[WAVES][MAXUP];
+    T* up = &upbuf[wave][0];
     const int64_t wstride = (int64_t)gridDim.x * WAVES;
     int64_t row = (int64_t)blockIdx.x * WAVES + wave;
     v4i nxt[LOADS];
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
     const QStep c_cvt = load_step(&tab->c_cvt[0]);
     const int flo = (int)tab->level_add[0][0].q.lo, fhi = (int)tab->level_add[0][0].q.hi;   // MODE 1 / 2: the one level format
     for (; row < g.M; row += wstride) {
-        int root = 0;
+        T root = 0;
         for (int64_t s = 0; s < nseg; ++s) {
             // publish the prefetched segment in the wave's image, start fetching the next one
 #pragma unroll
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
                 if (ns == nseg) { ns = 0; nr = row + wstride; }
                 if (nr < g.M) fetch(nr, ns);
             }
-            int v[CH];
+            T v[CH];
             if (g.b_is_bit) {
 #pragma unroll
                 for (int t = 0; t < LOADS; ++t) {
@@ -204,15 +208,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
                     for (int e = 0; e < 4; ++e) p[e] = (int64_t)a[e] * (int64_t)b[e];
                     qg_step_all<int64_t, 4>(p, pnode.q);                          // Qmul: round + overflow into the product format
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * t + e] = (int)p[e];
+                    for (int e = 0; e < 4; ++e) v[4 * t + e] = (T)p[e];
                 }
             }
             // across the lanes: level Q + i pairs lane j (left) with lane j + 2^i
-            int x[1] = {lane_tree<CH, MODE>(v, tab, 0, flo, fhi)};
+            T x[1] = {lane_tree<CH, MODE, T>(v, tab, 0, flo, fhi)};
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                int y[1] = {__shfl_down(x[0], 1 << i)};
-                if constexpr (MODE == 0) node_all<1>(x, y, tab, Q + i);
+                T y[1] = {__shfl_down(x[0], 1 << i)};
+                if constexpr (MODE == 0) node_all<1, T>(x, y, tab, Q + i);
                 else if constexpr (MODE >= 3) node_rec<MODE, 1>(x, y, g.tab, Q + i);
                 else x[0] = node_fixed<MODE>(x[0], y[0], flo, fhi);
             }
@@ -222,11 +226,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
             for (int u = 0; u < MAXUP && !parked; ++u) {
                 if (base + u >= g.n_levels) { root = x[0]; parked = true; }
                 else if (((s >> u) & 1) == 0) { if (lane == 0) up[u] = x[0]; parked = true; }
-                else if (MODE == 0) {
-                    int l[1] = {up[u]};
-                    node_all<1>(l, x, tab, base + u);
+                else if constexpr (MODE == 0) {
+                    T l[1] = {up[u]};
+                    node_all<1, T>(l, x, tab, base + u);
                     x[0] = l[0];
-                } else if (MODE >= 3) {
+                } else if constexpr (MODE >= 3) {
                     int l[1] = {up[u]};
                     node_rec<MODE, 1>(l, x, g.tab, base + u);
                     x[0] = l[0];
@@ -235,8 +239,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
                 }
             }
         }
-        int r[1] = {root};
-        qg_step_all<int, 1>(r, c_cvt);
+        T r[1] = {root};
+        qg_step_all<T, 1>(r, c_cvt);
         if (lane == 0) {
             switch (g.cbytes) {
             case 1: ((int8_t*)g.C)[row] = (int8_t)r[0]; break;
@@ -251,9 +255,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
 // Short rows (K = 16 .. 128): a row is K/4 lanes wide, so one 16-byte load per lane covers 256/K whole rows and the lane's
 // four values are already consecutive leaves — no LDS.  Two levels inside the lane, log2(K) - 2 across the lanes of the
 // row's group; U row groups are processed together so that the (wave-uniform) mode switches are paid once per U values.
-template <int KK, int MODE>   // MODE: see node_fixed
+template <int KK, int MODE, class T = int>   // MODE: see node_fixed; T = int64_t (MODE 0): see k_gemv
 __global__ __launch_bounds__(256) void k_gemv_short(QGemvArgs g)
 {
+    static_assert(sizeof(T) == 4 || MODE == 0, "64-bit values: run-time modes");
     constexpr int LPR = KK / 4;        // lanes per row
     constexpr int RPL = 64 / LPR;      // rows per wave-wide load
     constexpr int U = 4;               // loads in flight per lane
@@ -276,9 +281,9 @@ __global__ __launch_bounds__(256) void k_gemv_short(QGemvArgs g)
             const int64_t row = (g0 + u) * RPL + rl;
             a[u] = row < g.M ? *(const v4i*)(g.A + row * KK + sub * 4) : v4i{0, 0, 0, 0};
         }
-        int l0[2 * U];   // level-0 inputs pairwise: (p0 + p1), (p2 + p3) per load
+        T l0[2 * U];   // level-0 inputs pairwise: (p0 + p1), (p2 + p3) per load
         {
-            int p[4 * U];
+            T p[4 * U];
             if (g.b_is_bit) {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(256) void k_gemv_short(QGemvArgs g)
                     for (int e = 0; e < 4; ++e) w[4 * u + e] = (int64_t)a[u][e] * (int64_t)b[e];
                 qg_step_all<int64_t, 4 * U>(w, pnode.q);
 #pragma unroll
-                for (int o = 0; o < 4 * U; ++o) p[o] = (int)w[o];
+                for (int o = 0; o < 4 * U; ++o) p[o] = (T)w[o];
             }
             if constexpr (MODE >= 3) {
                 int r0[2 * U];
@@ -301,11 +306,14 @@ __global__ __launch_bounds__(256) void k_gemv_short(QGemvArgs g)
                 node_rec<MODE, 2 * U>(l0, r0, g.tab, 0);
             } else {
 #pragma unroll
-                for (int o = 0; o < 2 * U; ++o) l0[o] = MODE == 0 ? p[2 * o] + p[2 * o + 1] : node_fixed<(MODE == 1 || MODE == 2) ? MODE : 1>(p[2 * o], p[2 * o + 1], flo, fhi);
+                for (int o = 0; o < 2 * U; ++o) {
+                    if constexpr (MODE == 0) l0[o] = p[2 * o] + p[2 * o + 1];
+                    else l0[o] = node_fixed<(MODE == 1 || MODE == 2) ? MODE : 1>(p[2 * o], p[2 * o + 1], flo, fhi);
+                }
             }
         }
-        if constexpr (MODE == 0) qg_step_all<int, 2 * U>(l0, load_step(&tab->level_add[0][0].q));
-        int x[U];
+        if constexpr (MODE == 0) qg_step_all<T, 2 * U>(l0, load_step(&tab->level_add[0][0].q));
+        T x[U];
         if constexpr (MODE >= 3) {
             int r1[U];
 #pragma unroll
@@ -313,22 +321,25 @@ __global__ __launch_bounds__(256) void k_gemv_short(QGemvArgs g)
             node_rec<MODE, U>(x, r1, g.tab, 1);
         } else {
 #pragma unroll
-            for (int u = 0; u < U; ++u) x[u] = MODE == 0 ? l0[2 * u] + l0[2 * u + 1] : node_fixed<(MODE == 1 || MODE == 2) ? MODE : 1>(l0[2 * u], l0[2 * u + 1], flo, fhi);
+            for (int u = 0; u < U; ++u) {
+                if constexpr (MODE == 0) x[u] = l0[2 * u] + l0[2 * u + 1];
+                else x[u] = node_fixed<(MODE == 1 || MODE == 2) ? MODE : 1>(l0[2 * u], l0[2 * u + 1], flo, fhi);
+            }
         }
-        if constexpr (MODE == 0) qg_step_all<int, U>(x, load_step(&tab->level_add[0][1].q));
+        if constexpr (MODE == 0) qg_step_all<T, U>(x, load_step(&tab->level_add[0][1].q));
 #pragma unroll
         for (int i = 0; i < XL; ++i) {
-            int y[U];
+            T y[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) y[u] = __shfl_down(x[u], 1 << i);
-            if constexpr (MODE == 0) node_all<U>(x, y, tab, 2 + i);
+            if constexpr (MODE == 0) node_all<U, T>(x, y, tab, 2 + i);
             else if constexpr (MODE >= 3) node_rec<MODE, U>(x, y, g.tab, 2 + i);
             else {
 #pragma unroll
                 for (int u = 0; u < U; ++u) x[u] = node_fixed<(MODE == 1 || MODE == 2) ? MODE : 1>(x[u], y[u], flo, fhi);
             }
         }
-        qg_step_all<int, U>(x, c_cvt);
+        qg_step_all<T, U>(x, c_cvt);
         if (sub == 0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -363,6 +374,31 @@ hipError_t launch_gemv_short(const QGemvArgs& g, hipStream_t st)
     return hipGetLastError();
 }
 
+template <int KK>
+hipError_t launch_gemv_short_wide(const QGemvArgs& g, hipStream_t st)   // 64-bit values (k_gemv_short<KK, 0, int64_t>)
+{
+    constexpr int RPL = 64 / (KK / 4);
+    const int64_t groups = (g.M + RPL - 1) / RPL;
+    int64_t blocks = (groups + 15) / 16;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL((k_gemv_short<KK, 0, int64_t>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    return hipGetLastError();
+}
+
+template <int CH>
+hipError_t launch_gemv_wide(const QGemvArgs& g, hipStream_t st)   // 64-bit values (k_gemv<CH, 0, int64_t>)
+{
+    constexpr int IMG = 64 * (CH * 4 + 16);
+    const int64_t nseg = g.K / (64 * CH);
+    const int lds = IMG * ((nseg == 1 ? 1 : 0) + WAVES);
+    static std::atomic<uint64_t> attr_done{0};
+    if (hipError_t e = qg_lds_attr((const void*)k_gemv<CH, 0, int64_t>, IMG * (1 + WAVES), attr_done); e != hipSuccess) return e;
+    int64_t blocks = (g.M + WAVES - 1) / WAVES;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL((k_gemv<CH, 0, int64_t>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, st, g);
+    return hipGetLastError();
+}
+
 template <int CH, int MODE = 0>
 hipError_t launch_gemv(const QGemvArgs& g, hipStream_t st)
 {
@@ -386,11 +422,22 @@ hipError_t launch_gemv(const QGemvArgs& g, hipStream_t st)
 } // namespace
 
 hipError_t qg_launch_gemv(const QTreeTable* dev_table, int n_levels, int b_is_bit, int fixed_mode, const void* A, const void* B, void* C,
-                          int64_t M, int64_t K, int cbytes, hipStream_t st)
+                          int64_t M, int64_t K, int cbytes, hipStream_t st, int wide)
 {
     if (M <= 0) return hipSuccess;
     if (K < 16 || (K & (K - 1)) || n_levels < 4 || n_levels > 10 + MAXUP) return hipErrorInvalidValue;
-    QGemvArgs g{dev_table, (const int32_t*)A, (const int32_t*)B, (char*)C, M, K, cbytes, n_levels, b_is_bit, fixed_mode};
+    QGemvArgs g{dev_table, (const int32_t*)A, (const int32_t*)B, (char*)C, M, K, cbytes, n_levels, b_is_bit, wide ? 0 : fixed_mode};
+    if (wide) {   // 64-bit tree values on 4-byte elements: 8 leaves per lane and segment (16 would hold 64 registers of values alone)
+        if (K >= 1024) return launch_gemv_wide<16>(g, st);
+        if (K >= 512) return launch_gemv_wide<8>(g, st);
+        if (K >= 256) return launch_gemv_wide<4>(g, st);
+        switch (K) {
+        case 16: return launch_gemv_short_wide<16>(g, st);
+        case 32: return launch_gemv_short_wide<32>(g, st);
+        case 64: return launch_gemv_short_wide<64>(g, st);
+        default: return launch_gemv_short_wide<128>(g, st);
+        }
+    }
     switch (K) {
     case 16: return launch_gemv_short<16>(g, st);
     case 32: return launch_gemv_short<32>(g, st);

@@ -110,7 +110,7 @@ hipError_t qg_launch_tree64(const QTreeTable* dev_table, int n_levels, const voi
 
 // exact tree evaluation of ONE output column (batched Qreduce / GEMV): A [M][K] int32, B [K] int32
 hipError_t qg_launch_gemv(const QTreeTable* dev_table, int n_levels, int b_is_bit, int fixed_mode, const void* A, const void* B, void* C,
-                          int64_t M, int64_t K, int cbytes, hipStream_t st);
+                          int64_t M, int64_t K, int cbytes, hipStream_t st, int wide = 0);   // wide: 64-bit tree values (4-byte elements)
 
 // exact tree evaluation, complex descriptors with K = 2^p >= 32 and 32-bit intermediates
 hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, int fixed_modes, const void* A, const void* B, void* C,

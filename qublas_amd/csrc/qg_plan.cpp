@@ -482,6 +482,9 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     }
     // one-column kernel (qg_gemv.hip): products are formed in 64 bits, everything else in 32
     out->gemv_ok = (!cx && d->N == 1 && d->n_levels >= 4 && d->n_levels <= 30 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
+    // ... with 64-bit tree values when only the ELEMENTS fit 32 storage bits (sums of 32-bit words, wide level types)
+    out->gemv_wide_ok = (!cx && !out->gemv_ok && d->N == 1 && d->n_levels >= 4 && d->n_levels <= 30 &&
+                         1 + (int)d->a[0].I + (int)d->a[0].F <= 32 && 1 + (int)d->b[0].I + (int)d->b[0].F <= 32) ? 1 : 0;
     // fast_mode 3: per-level formats, but every step "add a constant, shift right, clamp" (QFix, qg_plan.h): TRN::TCPL /
     // RND::POS_INF / RND::NEG_INF rounding; SAT::TCPL / SAT::SMGN (one clamp), SAT::ZERO (range test + select) or WRP::TCPL
     // (sign extension / mask) overflow — e.g. default modes with a wider level type in QgemulAddArgs, which used to take the
@@ -581,7 +584,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         qfmt leaf = d->a[0];
         const bool smgn = leaf.S && leaf.O == QG_SAT_SMGN;
         if (smgn) leaf.O = QG_SAT_TCPL;
-        out->gemv_b_bit = (out->gemv_ok && d->b[0].I == 1 && d->b[0].F == 0 && !d->b[0].S && same(d->mul[0], leaf)) ? 1 : 0;
+        out->gemv_b_bit = ((out->gemv_ok || out->gemv_wide_ok) && d->b[0].I == 1 && d->b[0].F == 0 && !d->b[0].S && same(d->mul[0], leaf)) ? 1 : 0;
     }
     out->gemv_fixed = 0;
     if (out->gemv_ok) {

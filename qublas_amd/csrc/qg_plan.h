@@ -61,6 +61,7 @@ struct QAnalysis {
     int fast_mode;           // 0 runtime modes; 1 one format everywhere, TCPL + SAT::ZERO; 2 TCPL + SAT::TCPL; 3 / 4 / 5 per-level formats, compact steps (QFix; 3: every step clamps, 4: biased values, 5: unbiased)
     int tree64_ok;           // the 2x2-outputs-per-lane 64-bit tree kernel applies (real, 5..16 levels)
     int gemv_ok;             // the one-column 32-bit tree kernel applies (N = 1, K = 2^p >= 16)
+    int gemv_wide_ok;        // ... or its 64-bit-value form: elements of at most 32 storage bits, wider sums / level types
     int gemv_fixed;          // 1 / 2: every tree level has one format, no rounding shift, SAT::ZERO / SAT::TCPL (fixed-mode nodes); 3 / 5: per-level formats in compact records
     int gemv_b_bit;          // ... and B is a 0/1 vector whose product with a is a itself (the Qreduce lowering)
     char reason[96];

@@ -138,3 +138,36 @@ def test_one_column_step_forms_and_the_smgn_minimum(oracle):
                 capi.run(d, out, A, B, flags=flags)
                 assert np.array_equal(out, exp), (str(e), K, flags)
 
+
+def test_one_column_64_bit_values(oracle):
+    """Elements of at most 32 storage bits whose sums or level types need more than 31 bits (Q15.16, 24-bit elements under
+    40-bit levels ...): the one-column kernels with 64-bit tree values (gemv_i64) instead of the general 64-bit tree kernel,
+    which is built for square tiles.  Qreduce lowerings and GEMVs, long and short rows, several modes, against the oracle."""
+    from qublas_amd.desc import SAT, TRN, WRP, RND, lower_reduce, reduce_result_type
+    q = Qu(15, 16)
+    cases = [
+        (q, [Qu(24, 16)]),
+        (q, None),                                                       # every node saturates at 32 bits
+        (q, [Qu(20, 12, True, RND.CONV, SAT.SMGN), Qu(30, 8, True, RND.ZERO, SAT.ZERO)]),
+        (Qu(12, 11), [Qu(28, 11), Qu(34, 6, True, TRN.SMGN, WRP.TCPL)]),
+        (Qu(15, 16, False), [Qu(30, 16, False)]),                        # unsigned elements of 32 storage bits
+    ]
+    for e, levels in cases:
+        for rows, K in ((300, 16), (37, 64), (700, 128), (9, 256), (41, 1024), (5, 8192)):
+            d = lower_reduce(e, rows, K, levels)
+            info = capi.classify(d)
+            assert capi.KERNEL_NAMES[info.kernel] == "gemv_i64", (str(e), K, info.reason)
+            ec = reduce_result_type(e, levels or [], K)
+            A = oracle.fill(e, rows * K, 21, 0)
+            A[:2] = e.raw_min
+            A[2:4] = e.raw_max
+            got = capi.run(d, np.zeros(rows, dtype=oracle.host_dtype(ec)), A, np.ones(K, dtype=np.int32))
+            assert np.array_equal(got, oracle.gemm(d, A, np.ones(K, dtype=np.int32), ec)), (str(e), rows, K)
+    # a GEMV (B is a vector of the element type, products rounded into a 32-bit format)
+    for K in (64, 2048):
+        d = lower(q, q, Qu(28, 12), 130, 1, K, mul_args=Qu(15, 16, True, RND.POS_INF, SAT.TCPL), add_args=[Qu(28, 16), Qu(28, 12)])
+        assert capi.KERNEL_NAMES[capi.classify(d).kernel] == "gemv_i64"
+        A, B = oracle.fill(q, 130 * K, 5, 0), oracle.fill(q, K, 6, 0)
+        got = capi.run(d, np.zeros(130, dtype=oracle.host_dtype(Qu(28, 12))), A, B)
+        assert np.array_equal(got, oracle.gemm(d, A, B, Qu(28, 12)))
+
