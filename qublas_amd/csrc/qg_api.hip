@@ -185,7 +185,7 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
         // (a node whose right child is a zero leaf / zero subtree is the reference's converting copy of an odd leftover)
         const bool t64 = kernel == QG_KERNEL_TREE_I64 && an->tree64_ok && fast;   // the 2x2-per-lane 64-bit kernel, not the general one
         const int64_t Kt = (kernel == QG_KERNEL_TREE_I32 || kernel == QG_KERNEL_TREE_CPLX_I32 || kernel == QG_KERNEL_GEMV_I32 || kernel == QG_KERNEL_GEMV_I64 || t64)
-                               ? ((int64_t)1 << d->n_levels) : d->K;
+                               ? ((int64_t)1 << an->tree.n_levels_k) : d->K;   // (n_levels_k: at least 5 levels, qg_plan.h)
         *pa = QPackedGeom{d->M, Kt, info->in_bits[0] <= 32 ? 4 : 8, 0, 0, 0};
         *pb = QPackedGeom{d->N, Kt, info->in_bits[1] <= 32 ? 4 : 8, 0, 0, 0};
         pc->Mp = d->M;
@@ -887,27 +887,27 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
         return QG_OK;
     }
     case QG_KERNEL_TREE_I32:
-        QG_HIP(qg_launch_tree_fast(p->dev_table, (int)p->desc.n_levels, p->an.split_s, p->an.mul24_ok,
+        QG_HIP(qg_launch_tree_fast(p->dev_table, p->an.tree.n_levels_k, p->an.split_s, p->an.mul24_ok,
                                    (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : p->an.fast_mode, packedA, packedB, packedC,
                                    p->desc.M, p->desc.N, p->pa.K_p, pcg.cbytes, st));
         return QG_OK;
     case QG_KERNEL_GEMV_I64:
-        QG_HIP(qg_launch_gemv(p->dev_table, (int)p->desc.n_levels, p->an.gemv_b_bit, 0, packedA, packedB, packedC, p->desc.M, p->pa.K_p,
+        QG_HIP(qg_launch_gemv(p->dev_table, p->an.tree.n_levels_k, p->an.gemv_b_bit, 0, packedA, packedB, packedC, p->desc.M, p->pa.K_p,
                               pcg.cbytes, st, 1));
         return QG_OK;
     case QG_KERNEL_GEMV_I32:
-        QG_HIP(qg_launch_gemv(p->dev_table, (int)p->desc.n_levels, p->an.gemv_b_bit, (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : p->an.gemv_fixed,
+        QG_HIP(qg_launch_gemv(p->dev_table, p->an.tree.n_levels_k, p->an.gemv_b_bit, (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : p->an.gemv_fixed,
                               packedA, packedB, packedC, p->desc.M, p->pa.K_p,
                               pcg.cbytes, st));
         return QG_OK;
     case QG_KERNEL_TREE_CPLX_I32:
-        QG_HIP(qg_launch_tree_cplx_fast(p->dev_table, (int)p->desc.n_levels, (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : p->an.cplx_fixed_ok,
+        QG_HIP(qg_launch_tree_cplx_fast(p->dev_table, p->an.tree.n_levels_k, (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : p->an.cplx_fixed_ok,
                                         packedA, packedB, packedC, p->desc.M, p->desc.N,
                                         p->pa.K_p, pcg.cbytes, st));
         return QG_OK;
     case QG_KERNEL_TREE_I64:
         if (p->an.tree64_ok && !(p->flags & QG_OPT_GENERIC_TREE)) {
-            QG_HIP(qg_launch_tree64(p->dev_table, (int)p->desc.n_levels, packedA, packedB, packedC, p->desc.M, p->desc.N, p->pa.K_p,
+            QG_HIP(qg_launch_tree64(p->dev_table, p->an.tree.n_levels_k, packedA, packedB, packedC, p->desc.M, p->desc.N, p->pa.K_p,
                                     p->pa.cbytes, p->pb.cbytes, pcg.cbytes, st));
             return QG_OK;
         }

@@ -337,6 +337,16 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     T.is_complex = cx;
     T.cmul = d->cmul;
     T.n_levels = (int)d->n_levels;
+    T.n_levels_k = d->n_levels < 5 ? 5 : (int)d->n_levels;
+    for (int p = 0; p < 2; ++p)
+        for (int l = (int)d->n_levels; l < T.n_levels_k && l < QG_MAX_LEVELS; ++l) {   // identity levels behind a short tree
+            memset(&T.level_add[p][l], 0, sizeof T.level_add[p][l]);
+            T.level_add[p][l].q.identity = 1;
+            memset(&T.level_cvt[p][l], 0, sizeof T.level_cvt[p][l]);
+            T.level_cvt[p][l].identity = 1;
+            memset(&T.leftover[p][l], 0, sizeof T.leftover[p][l]);
+            T.leftover[p][l].identity = 1;
+        }
     T.parts = parts;
 
     for (int p = 0; p < parts; ++p)
@@ -455,7 +465,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     out->tree_fast_ok = 0;
     // (any K with 5..16 levels: the packed operands are zero-padded to 2^n_levels leaves — a node whose right child is a
     // zero is the reference's converting copy of an odd leftover, QuBLAS.h:4977-4980)
-    if (!cx && d->n_levels >= 5 && d->n_levels <= 16 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) {
+    if (!cx && d->n_levels <= 16 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) {
         const int bitsA = 1 + (int)d->a[0].I + (int)d->a[0].F, bitsB = 1 + (int)d->b[0].I + (int)d->b[0].F;
         const int sh = T.mul[0].q.d;
         int bh = bitsB - sh;
@@ -481,9 +491,9 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         if (one && W + 1 + T.mul[0].q.d <= 30) out->fast_mode = pf.O == QG_SAT_ZERO ? 1 : 2;
     }
     // one-column kernel (qg_gemv.hip): products are formed in 64 bits, everything else in 32
-    out->gemv_ok = (!cx && d->N == 1 && d->n_levels >= 4 && d->n_levels <= 30 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
+    out->gemv_ok = (!cx && d->N == 1 && d->n_levels <= 30 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     // ... with 64-bit tree values when only the ELEMENTS fit 32 storage bits (sums of 32-bit words, wide level types)
-    out->gemv_wide_ok = (!cx && !out->gemv_ok && d->N == 1 && d->n_levels >= 4 && d->n_levels <= 30 &&
+    out->gemv_wide_ok = (!cx && !out->gemv_ok && d->N == 1 && d->n_levels <= 30 &&
                          1 + (int)d->a[0].I + (int)d->a[0].F <= 32 && 1 + (int)d->b[0].I + (int)d->b[0].F <= 32) ? 1 : 0;
     // fast_mode 3: per-level formats, but every step "add a constant, shift right, clamp" (QFix, qg_plan.h): TRN::TCPL /
     // RND::POS_INF / RND::NEG_INF rounding; SAT::TCPL / SAT::SMGN (one clamp), SAT::ZERO (range test + select) or WRP::TCPL
@@ -511,12 +521,12 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         // (the split product is rounded inside its low half: its shift is the split, never a left shift)
         // (the one-column kernel forms its products itself: only the levels' records matter there)
         bool ok3 = out->gemv_ok || (okq(pq) && (out->split_s == 0 || (!pq.identity && pq.d == out->split_s)));
-        for (uint32_t l = 0; l < d->n_levels && ok3; ++l)
+        for (uint32_t l = 0; l < (uint32_t)T.n_levels_k && ok3; ++l)
             ok3 = okq(T.level_add[0][l].q) && T.level_cvt[0][l].identity && T.level_add[0][l].sa == 0 && T.level_add[0][l].sb == 0;
         if (ok3) {
             if (okq(pq)) fix_of(pq, &T.fmul[0]);
             bool clamps = out->gemv_ok || T.fmul[0].kb == 0;
-            for (uint32_t l = 0; l < d->n_levels; ++l) {
+            for (uint32_t l = 0; l < (uint32_t)T.n_levels_k; ++l) {
                 fix_of(T.level_add[0][l].q, &T.fadd[0][l]);
                 clamps = clamps && T.fadd[0][l].kb == 0;
             }
@@ -525,7 +535,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                                                        // 5: the records' overflow kinds on unbiased values (any format the kernel admits)
             if (!clamps && for_tree) {
                 QFix keep_mul = T.fmul[0];
-                std::vector<QFix> keep_add(T.fadd[0], T.fadd[0] + d->n_levels);
+                std::vector<QFix> keep_add(T.fadd[0], T.fadd[0] + (uint32_t)T.n_levels_k);
                 // 4: some step tests the range (SAT::ZERO) or wraps.  The running value is then kept BIASED by -lo of its own
                 // format, u = v - lo >= 0 (as the one-format SAT::ZERO form does): the range test is ONE unsigned compare
                 // against span = hi - lo with the biased zero as the select's other operand, a clamp is med3(u, 0, span) with
@@ -561,7 +571,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                 };
                 L cur = lv(pq);
                 put(pq, cur, 0, &T.fmul[0]);
-                for (uint32_t l = 0; l < d->n_levels; ++l) {
+                for (uint32_t l = 0; l < (uint32_t)T.n_levels_k; ++l) {
                     const L me = lv(T.level_add[0][l].q);
                     put(T.level_add[0][l].q, me, 2 * cur.B, &T.fadd[0][l]);
                     cur = me;
@@ -571,12 +581,12 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                     out->fast_mode = 4;
                 } else {   // too wide for the bias arithmetic: the unbiased records stand
                     T.fmul[0] = keep_mul;
-                    for (uint32_t l = 0; l < d->n_levels; ++l) T.fadd[0][l] = keep_add[l];
+                    for (uint32_t l = 0; l < (uint32_t)T.n_levels_k; ++l) T.fadd[0][l] = keep_add[l];
                 }
             }
         }
     }
-    out->tree64_ok = (!cx && d->n_levels >= 5 && d->n_levels <= 16) ? 1 : 0;   // (max_bits <= 62 was checked above)
+    out->tree64_ok = (!cx && d->n_levels <= 16) ? 1 : 0;   // (max_bits <= 62 was checked above)
     // (the Qreduce lowering: a * 1 into a's own format.  That is the identity for every raw value EXCEPT -2^W of a signed
     // SAT::SMGN format, which the conversion clamps to -(2^W - 1); the lowerings therefore name a's format with SAT::TCPL
     // as the leaf format of such element types, and only that form takes the shortcut)
@@ -596,7 +606,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         if (one) out->gemv_fixed = lf.O == QG_SAT_ZERO ? 1 : 2;
         else if (rec_form) out->gemv_fixed = rec_form;   // per-level formats in compact records (3: every level clamps, 5: kinds)
     }
-    out->cplx_fast_ok = (cx && d->n_levels >= 5 && d->n_levels <= 16 && c.max_bits <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
+    out->cplx_fast_ok = (cx && d->n_levels <= 16 && c.max_bits <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     // fixed-mode variant of the complex kernel (BASELINE configuration 5's "RND + SAT"): every sub-operation and every tree
     // step either the identity, or an exact left shift / a rounding shift with RND::POS_INF, followed by SAT::TCPL, so a
     // step is (v + 2^(d-1)) >> d (or v << -d) and one clamp
@@ -670,7 +680,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                 }
             }
             for (int p = 0; p < 2 && reg; ++p)
-                for (uint32_t l = 0; l < d->n_levels && reg; ++l) {
+                for (uint32_t l = 0; l < (uint32_t)T.n_levels_k && reg; ++l) {
                     reg = reg && T.level_add[p][l].sa == 0 && T.level_add[p][l].sb == 0;
                     fix_of(T.level_add[p][l].q, &T.fadd[p][l]);   // (a left shift at a node is QFix::ls)
                     fix_of(T.level_cvt[p][l], &T.fcvt[p][l]);

@@ -26,6 +26,10 @@ struct QFix {
 // everything a kernel needs about the arithmetic, laid out for device reads (plan-owned buffer)
 struct QTreeTable {
     int32_t is_complex, cmul, n_levels, parts;
+    // the 32-bit / 64-bit register-counter kernels walk at least 5 levels (32 leaves): a shorter tree is continued with identity
+    // levels (x + 0 in x's own format), its operands zero-padded to 32 leaves; n_levels_k = max(n_levels, 5) is what those
+    // kernels and the packed geometry use (the general kernel keeps n_levels)
+    int32_t n_levels_k, pad_[3];
     QNode mul[8];                         // product sub-ops in qgemul.h slot order
     QNode level_add[2][QG_MAX_LEVELS];    // pair add of level l (inputs have equal formats)
     QStep level_cvt[2][QG_MAX_LEVELS];    // store into the level buffer (identity for real GEMMs)

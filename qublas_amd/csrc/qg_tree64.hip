@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void k_tree64(QTree64Args g)
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int64_t tiles_n = (g.N + TNB - 1) / TNB;
     const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * TMB, n0 = (int64_t)(blockIdx.x % tiles_n) * TNB;
-    const int nl = tab->n_levels;
+    const int nl = tab->n_levels_k;   // (a tree shorter than 5 levels is continued with identity levels: qg_plan.h)
 
     int64_t low[4][4], up[MAXL - 4][4], v[4];
 #pragma unroll

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
     const int64_t grp = bid / (GMT * tiles_n), first_m = grp * GMT;
     const int64_t gsz = (tiles_m - first_m) < GMT ? (tiles_m - first_m) : GMT;
     const int64_t m0 = (first_m + (bid % (GMT * tiles_n)) % gsz) * TMB, n0 = ((bid % (GMT * tiles_n)) / gsz) * TNB;
-    const int nl = tab->n_levels;
+    const int nl = tab->n_levels_k;   // (a tree shorter than 5 levels is continued with identity levels: qg_plan.h)
     const int s = g.split_s;
     const int smask = SPLIT ? ((1 << s) - 1) : 0;
     const QStep pstep = tab->mul[0].q;

@@ -90,11 +90,21 @@ def test_any_length(oracle, K):
     _check(oracle, lower(E43, E43, Qu(12, 3), 100, 1, K), E43, E43, Qu(12, 3))
 
 
-def test_very_short_vectors_use_the_general_kernels(oracle):
-    for K in (1, 2, 5, 8):
-        d = lower_reduce(E88, 64, K)
-        assert capi.KERNEL_NAMES[capi.classify(d).kernel] != "gemv_i32"
-        _check(oracle, d, E88, None, E88, dist=1, ones=True, expect=capi.KERNEL_NAMES[capi.classify(d).kernel])
+def test_very_short_vectors(oracle):
+    """Fewer than 5 tree levels: the tree is continued with identity levels (x + 0 in x's own format) and the row zero-padded to
+    32 leaves, so that the one-column kernel takes these too (round 1 sent them to the general kernel)."""
+    for K in (1, 2, 5, 8, 13, 16):
+        for levels in (None, [Qu(12, 8)], [Qu(10, 8, True, TRN.TCPL, SAT.ZERO), Qu(14, 6)]):
+            d = lower_reduce(E88, 64, K, levels)
+            assert capi.KERNEL_NAMES[capi.classify(d).kernel] in ("gemv_i32", "mfma_i8_limb")   # (a level type that holds every sum: linear class)
+            assert levels or K == 1 or capi.KERNEL_NAMES[capi.classify(d).kernel] == "gemv_i32"   # (K = 1: no add at all, linear too)
+            from qublas_amd.desc import reduce_result_type
+            ec = reduce_result_type(E88, levels or [], K)
+            A = oracle.fill(E88, 64 * K, 3, 1)
+            exp = oracle.gemm(d, A, np.ones(K, dtype=np.int32), ec)
+            for flags in (0, capi.OPT_RUNTIME_MODES, capi.OPT_GENERIC_TREE):
+                got = capi.run(d, np.zeros(64, dtype=oracle.host_dtype(ec)), A, np.ones(K, dtype=np.int32), flags=flags)
+                assert np.array_equal(got, exp), (K, levels, flags)
 
 
 @pytest.mark.parametrize("K", [64, 256, 1000, 8192])

@@ -188,7 +188,7 @@ def test_config5_complex_tf(oracle):
                    expect_kernel="tree_cplx")
     assert fields_equal(a, b)
     _vs_oracle(oracle, c5, c5, wide, 40, 24, 100, dist=1, mul_args=BasicComplexMul(), transposed_a=True, expect_kernel="tree_cplx_i32")   # K = 100: zero-padded to 128 leaves
-    _vs_oracle(oracle, c5, c5, wide, 40, 24, 13, dist=1, mul_args=BasicComplexMul(), transposed_a=True, expect_kernel="tree_cplx")      # 4 levels: general kernel
+    _vs_oracle(oracle, c5, c5, wide, 40, 24, 13, dist=1, mul_args=BasicComplexMul(), transposed_a=True, expect_kernel="tree_cplx_i32")  # 4 levels: continued with an identity level
     _vs_oracle(oracle, c5, c5, wide, 70, 33, 256, dist=0, mul_args=BasicComplexMul(), transposed_a=True, expect_kernel="tree_cplx_i32")
 
 
@@ -229,6 +229,32 @@ def test_complex_fast_kernel_tags_and_levels(oracle):
         assert fields_equal(a, b)
 
 
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 7, 8, 12, 16])
+def test_short_trees_on_the_register_counter_kernels(oracle, K):
+    """K <= 16 (fewer than 5 tree levels) used to fall to the general tree kernel (4096 x 4096 x 16: 1.02 ms where K = 32 takes
+    0.11 ms).  The planner now continues a short tree with identity levels — x + 0 in x's own format — over operands
+    zero-padded to 32 leaves, so the 32-bit / 64-bit / complex register-counter kernels take them, in every step form."""
+    e88, e88z = Qu(8, 8), Qu(8, 8, True, TRN.TCPL, SAT.ZERO)
+    cases = [
+        (e88, e88, dict(), "tree_i32"), (e88z, e88z, dict(), "tree_i32"),
+        (e88, Qu(12, 8), dict(add_args=[Qu(12, 8)]), "tree_i32"),
+        (e88z, Qu(12, 6), dict(add_args=[Qu(10, 8, True, TRN.TCPL, SAT.ZERO), Qu(12, 6)]), "tree_i32"),
+        (e88, Qu(12, 8), dict(add_args=[Qu(12, 8, True, RND.CONV)], mul_args=Qu(10, 6, True, RND.CONV)), "tree_i32"),
+        (Qu(15, 16), Qu(20, 12), dict(add_args=[Qu(24, 16)]), "tree_i64"),
+    ]
+    for e, ec, kw, kern in cases:
+        d = lower(e, e, ec, 70, 41, K, **kw)
+        assert capi.KERNEL_NAMES[capi.classify(d).kernel] == kern
+        a = _vs_oracle(oracle, e, e, ec, 70, 41, K, expect_kernel=kern, **kw)
+        b = _vs_oracle(oracle, e, e, ec, 70, 41, K, flags=capi.OPT_GENERIC_TREE, **kw)
+        assert np.array_equal(a, b)
+    P = lambda i, f: Qu(i, f, True, RND.POS_INF, SAT.TCPL)
+    c5 = Qcomplex(P(6, 3), P(6, -3))
+    for mul in (TFComplexMul(), BasicComplexMul()):
+        for flags in (0, capi.OPT_RUNTIME_MODES):
+            _vs_oracle(oracle, c5, c5, c5, 33, 29, K, flags=flags, mul_args=mul, expect_kernel="tree_cplx_i32")
+
+
 def test_32_bit_fixed_point_words(oracle):
     """Operands of 32 storage bits (Q15.16 and friends): the unrounded product of two of them needs all 64 bits of an int64
     (|a * b| <= 2^62), which the planner admits for the ONE exact 64-bit multiply that feeds its rounding shift, while every
@@ -244,7 +270,7 @@ def test_32_bit_fixed_point_words(oracle):
     for ea, eb, ec, kw, kern in cases:
         for M, N, K, ta in ((37, 29, 64, False), (16, 40, 300, True), (50, 1, 1024, False)):
             d = lower(ea, eb, ec, M, N, K, transposed_a=ta, **kw)
-            assert capi.KERNEL_NAMES[capi.classify(d).kernel] == kern
+            assert capi.KERNEL_NAMES[capi.classify(d).kernel] == ("gemv_i64" if N == 1 else kern)
             A, B = oracle.fill(ea, M * K, 3, 0), oracle.fill(eb, K * N, 4, 0)
             A[:2] = ea.raw_min
             B[:2] = eb.raw_min                                                                            # (-2^31) * (-2^31) = 2^62 is present
