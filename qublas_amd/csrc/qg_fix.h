@@ -58,12 +58,33 @@ __device__ __forceinline__ void fx_finish_biased(int (&v)[N], const QFix& f)
 }
 // UNBIASED records with an overflow kind (the real kernel's fast_mode 5: formats too wide for the biased form), QFix::kb: 0 one clamp (SAT::TCPL, SAT::SMGN), 1 out of range -> 0 (SAT::ZERO), 2 wrap, signed (WRP::TCPL: keep the low
 // W + 1 bits, sign-extended; hi = 2^W - 1), 3 wrap, unsigned (v & hi).  Wave-uniform.
+// ... and a rounding kind (QFix::skip of such a record) for the modes whose addend depends on the value: 0 the constant
+// addend is already in (TRN::TCPL, RND::POS_INF, RND::NEG_INF); else the record's t is 0 and, with half = 2^(d-1) and c = QFix::ka,
+//   1 RND::ZERO   (v + (half - 1) + [v < 0]) >> d          c = half - 1
+//   2 RND::INF    (v + half - [v < 0]) >> d                c = half
+//   3 RND::CONV   (v + (half - 1) + bit d of v) >> d       c = half - 1      (bit d of v = the parity of the truncated result)
+//   4 TRN::SMGN   (v + ([v < 0] ? 2^d - 1 : 0)) >> d       c = 2^d - 1
+// (each equals the reference's fracConvert for that mode: qg_round in qg_ops.h; checked against it by the fuzz suites).
 template <int N>
 __device__ __forceinline__ void fx_finish_any(int (&v)[N], const QFix& f)
 {
     if (f.d) {
+        if (f.skip == 0) {
 #pragma unroll
-        for (int o = 0; o < N; ++o) v[o] >>= f.d;
+            for (int o = 0; o < N; ++o) v[o] >>= f.d;
+        } else if (f.skip == 1) {
+#pragma unroll
+            for (int o = 0; o < N; ++o) v[o] = (v[o] + f.ka + (int)((unsigned)v[o] >> 31)) >> f.d;
+        } else if (f.skip == 2) {
+#pragma unroll
+            for (int o = 0; o < N; ++o) v[o] = (v[o] + f.ka + (v[o] >> 31)) >> f.d;
+        } else if (f.skip == 3) {
+#pragma unroll
+            for (int o = 0; o < N; ++o) v[o] = (v[o] + f.ka + ((v[o] >> f.d) & 1)) >> f.d;
+        } else {
+#pragma unroll
+            for (int o = 0; o < N; ++o) v[o] = (v[o] + ((v[o] >> 31) & f.ka)) >> f.d;
+        }
     }
     if (f.kb == 0) {
         const int hi = f.hi;

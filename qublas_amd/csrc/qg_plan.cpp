@@ -502,9 +502,12 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     int rec_form = 0;   // 3 / 5: the unbiased records are valid (every level clamps / overflow kinds), for the one-column kernel
     if (((out->tree_fast_ok && out->mul24_ok && out->fast_mode == 0) || out->gemv_ok)) {
         const bool for_tree = out->tree_fast_ok && out->mul24_ok && out->fast_mode == 0 && !out->gemv_ok;
-        auto okq = [](const QStep& q) {
-            return q.identity || (q.d >= -22 && q.d <= 29 && (q.O == QG_SAT_TCPL || q.O == QG_SAT_SMGN || q.O == QG_SAT_ZERO || (q.O == QG_WRP_TCPL && q.W >= 1)) &&
-                                  (q.d <= 0 || q.Q == QG_RND_POS_INF || q.Q == QG_TRN_TCPL || q.Q == QG_RND_NEG_INF));
+        auto okq = [](const QStep& q) {   // (every QuMode: the value-dependent ones as a rounding kind of the unbiased form)
+            return q.identity || (q.d >= -22 && q.d <= 29 && (q.O == QG_SAT_TCPL || q.O == QG_SAT_SMGN || q.O == QG_SAT_ZERO || (q.O == QG_WRP_TCPL && q.W >= 1)));
+        };
+        auto rk_of = [](const QStep& q) {
+            if (q.identity || q.d <= 0) return 0;
+            return q.Q == QG_RND_ZERO ? 1 : q.Q == QG_RND_INF ? 2 : q.Q == QG_RND_CONV ? 3 : q.Q == QG_TRN_SMGN ? 4 : 0;
         };
         auto fix_of = [](const QStep& q, QFix* f) {
             memset(f, 0, sizeof *f);
@@ -516,6 +519,16 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
             if (q.d < 0) { f->ls = -q.d; return; }
             f->d = q.d;
             f->t = q.d == 0 ? 0 : q.Q == QG_RND_POS_INF ? (1 << (q.d - 1)) : q.Q == QG_RND_NEG_INF ? (1 << (q.d - 1)) - 1 : 0;
+            if (q.d > 0) {   // value-dependent roundings: kind + constant (qg_fix.h)
+                const int32_t half = 1 << (q.d - 1);
+                switch (q.Q) {
+                case QG_RND_ZERO: f->skip = 1; f->ka = half - 1; break;
+                case QG_RND_INF: f->skip = 2; f->ka = half; break;
+                case QG_RND_CONV: f->skip = 3; f->ka = half - 1; break;
+                case QG_TRN_SMGN: f->skip = 4; f->ka = (int32_t)(((int64_t)1 << q.d) - 1); break;
+                default: break;
+                }
+            }
         };
         const QStep& pq = T.mul[0].q;
         // (the split product is rounded inside its low half: its shift is the split, never a left shift)
@@ -525,15 +538,17 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
             ok3 = okq(T.level_add[0][l].q) && T.level_cvt[0][l].identity && T.level_add[0][l].sa == 0 && T.level_add[0][l].sb == 0;
         if (ok3) {
             if (okq(pq)) fix_of(pq, &T.fmul[0]);
-            bool clamps = out->gemv_ok || T.fmul[0].kb == 0;
+            bool clamps = out->gemv_ok || (T.fmul[0].kb == 0 && rk_of(pq) == 0);
+            bool plain_rounding = out->gemv_ok || rk_of(pq) == 0;   // no value-dependent rounding anywhere: the biased form applies
             for (uint32_t l = 0; l < (uint32_t)T.n_levels_k; ++l) {
                 fix_of(T.level_add[0][l].q, &T.fadd[0][l]);
-                clamps = clamps && T.fadd[0][l].kb == 0;
+                clamps = clamps && T.fadd[0][l].kb == 0 && rk_of(T.level_add[0][l].q) == 0;
+                plain_rounding = plain_rounding && rk_of(T.level_add[0][l].q) == 0;
             }
             rec_form = clamps ? 3 : 5;
             if (for_tree) out->fast_mode = rec_form;   // 3: every step clamps (one v_med3 per value, no branch on the overflow kind);
                                                        // 5: the records' overflow kinds on unbiased values (any format the kernel admits)
-            if (!clamps && for_tree) {
+            if (!clamps && for_tree && plain_rounding) {
                 QFix keep_mul = T.fmul[0];
                 std::vector<QFix> keep_add(T.fadd[0], T.fadd[0] + (uint32_t)T.n_levels_k);
                 // 4: some step tests the range (SAT::ZERO) or wraps.  The running value is then kept BIASED by -lo of its own

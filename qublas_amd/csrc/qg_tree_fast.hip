@@ -306,7 +306,30 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
                         if (SPLIT) blv[j] = e == 0 ? bl4[j].x : e == 1 ? bl4[j].y : e == 2 ? bl4[j].z : bl4[j].w;
                     }
                     // ---- leaves: 8 quantised products
-                    if (MODE >= 3) {
+                    if (MODE == 5 && fp.skip != 0) {
+                        // a product whose rounding looks at the value's sign or parity (RND::ZERO / INF / CONV, TRN::SMGN)
+                        if (SPLIT) {
+                            int lw[NOUT];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) {
+                                    const int t = __mul24(av[i], blv[j]);
+                                    v[i * 2 + j] = __mul24(av[i], bhv[j]) + (t >> s);
+                                    lw[i * 2 + j] = t & smask;
+                                }
+                            round_split_all(v, lw, s, fp.skip == 1 ? QG_RND_ZERO : fp.skip == 2 ? QG_RND_INF : fp.skip == 3 ? QG_RND_CONV : QG_TRN_SMGN);
+                            QFix f0 = fp;
+                            f0.d = 0;   // (rounded)
+                            fx_finish_any<NOUT>(v, f0);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) v[i * 2 + j] = __mul24(av[i], bhv[j]);
+                            fx_finish_any<NOUT>(v, fp);   // (d > 0: the rounding kind, the shift, the overflow kind)
+                        }
+                    } else if (MODE >= 3) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -334,6 +357,7 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
                         } else {
                             QFix f0 = fp;
                             f0.d = 0;   // (the shift is done)
+                            f0.skip = 0;
                             if (MODE == 4) fx_finish_biased<NOUT>(v, f0);
                             else fx_finish_any<NOUT>(v, f0);
                         }

@@ -19,7 +19,7 @@ from oracle import qoracle as oracle  # noqa: E402
 from qublas_amd import capi  # noqa: E402
 from qublas_amd.desc import ONE, Qu, RND, SAT, TRN, WRP, Tags, lower, lower_reduce, reduce_result_type  # noqa: E402
 
-QM = [TRN.TCPL, TRN.TCPL, RND.POS_INF, RND.NEG_INF]
+QM = [TRN.TCPL, TRN.TCPL, RND.POS_INF, RND.NEG_INF, RND.ZERO, RND.INF, RND.CONV, TRN.SMGN]   # (the last four: rounding kinds of the unbiased form)
 OM = [SAT.TCPL, SAT.TCPL, SAT.SMGN, SAT.ZERO, SAT.ZERO, WRP.TCPL]
 
 

@@ -310,7 +310,10 @@ def test_real_tree_kernel_step_forms(oracle):
         # the README's own call (readme.md:28-36, :84-87): product and level 0 int<6,3> SAT::ZERO, later levels int<6,-3> with default modes
         (Qu(6, 3, True, TRN.TCPL, SAT.ZERO), Qu(6, 3, True, TRN.TCPL, SAT.ZERO),
          dict(mul_args=Qu(6, 3, True, TRN.TCPL, SAT.ZERO), add_args=[Qu(6, 3, True, TRN.TCPL, SAT.ZERO), Qu(6, -3)], transposed_a=True), "per-level formats, compact"),
-        (e88, Qu(12, 8), dict(add_args=[Qu(12, 8, True, RND.CONV)], mul_args=Qu(10, 6, True, RND.CONV)), "run-time modes"),
+        # roundings that look at the value's sign or parity: rounding kinds of the unbiased form (split and direct products)
+        (e88, Qu(12, 8), dict(add_args=[Qu(12, 8, True, RND.CONV)], mul_args=Qu(10, 6, True, RND.CONV)), "per-level formats, compact (unbiased)"),
+        (Qu(4, 3), Qu(8, 1, True, RND.ZERO, SAT.ZERO), dict(mul_args=Qu(6, 4, True, RND.INF, SAT.SMGN), add_args=[Qu(8, 3, True, TRN.SMGN, SAT.TCPL), Qu(8, 1, True, RND.ZERO, SAT.ZERO)]),
+         "per-level formats, compact (unbiased)"),
     ]
     for K in (64, 300):
         for e, ec, kw, form in cases:

@@ -30,6 +30,9 @@ CASES = [
     ("same, run-time modes forced",
      lower(Qu(6, 3, True, TRN.TCPL, SAT.ZERO), Qu(6, 3, True, TRN.TCPL, SAT.ZERO), Qu(6, 3, True, TRN.TCPL, SAT.ZERO), S, S, S,
            mul_args=Qu(6, 3, True, TRN.TCPL, SAT.ZERO), add_args=[Qu(6, 3, True, TRN.TCPL, SAT.ZERO), Qu(6, -3)], transposed_a=True), capi.OPT_RUNTIME_MODES),
+    ("int<8,8> RND::CONV, default tags (a rounding that looks at the value: rounding kind of the unbiased form)",
+     lower(Qu(8, 8, True, RND.CONV), Qu(8, 8, True, RND.CONV), Qu(8, 8, True, RND.CONV), S, S, S), 0),
+    ("same, run-time modes forced", lower(Qu(8, 8, True, RND.CONV), Qu(8, 8, True, RND.CONV), Qu(8, 8, True, RND.CONV), S, S, S), capi.OPT_RUNTIME_MODES),
     ("complex int<6,3>/int<6,-3> DEFAULT modes, TFComplexMul", lower(CD, CD, CD, S, S, S, mul_args=TFComplexMul()), 0),
     ("same, run-time modes forced", lower(CD, CD, CD, S, S, S, mul_args=TFComplexMul()), capi.OPT_RUNTIME_MODES),
 ]
