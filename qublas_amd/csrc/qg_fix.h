@@ -103,6 +103,92 @@ __device__ __forceinline__ void fx_finish_any(int (&v)[N], const QFix& f)
         for (int o = 0; o < N; ++o) v[o] &= f.hi;
     }
 }
+// COMPLEX records carry both factors, so their kinds are packed into QFix::skip: bit 0 identity, bits 8..15 the rounding kind
+// (as above), bits 16.. the overflow kind (0 clamp, 1 SAT::ZERO, 2 / 3 WRP::TCPL signed / unsigned); the rounding kind's
+// constant follows from d.  Unbiased values.
+template <int N>
+__device__ __forceinline__ void fx_finish_packed(int (&v)[N], const QFix& f)
+{
+    const int rk = (f.skip >> 8) & 0xff, ok = f.skip >> 16;
+    if (f.d) {
+        const int half = 1 << (f.d - 1);
+        if (rk == 0) {
+#pragma unroll
+            for (int o = 0; o < N; ++o) v[o] >>= f.d;
+        } else if (rk == 1) {
+#pragma unroll
+            for (int o = 0; o < N; ++o) v[o] = (v[o] + (half - 1) + (int)((unsigned)v[o] >> 31)) >> f.d;
+        } else if (rk == 2) {
+#pragma unroll
+            for (int o = 0; o < N; ++o) v[o] = (v[o] + half + (v[o] >> 31)) >> f.d;
+        } else if (rk == 3) {
+#pragma unroll
+            for (int o = 0; o < N; ++o) v[o] = (v[o] + (half - 1) + ((v[o] >> f.d) & 1)) >> f.d;
+        } else {
+            const int mask = (half << 1) - 1;
+#pragma unroll
+            for (int o = 0; o < N; ++o) v[o] = (v[o] + ((v[o] >> 31) & mask)) >> f.d;
+        }
+    }
+    if (ok == 0) {
+        const int hi = f.hi;
+#pragma unroll
+        for (int o = 0; o < N; ++o) asm("v_med3_i32 %0, %0, %1, %2" : "+v"(v[o]) : "s"(f.lo), "v"(hi));
+    } else if (ok == 1) {
+        const unsigned span = (unsigned)f.hi - (unsigned)f.lo;
+#pragma unroll
+        for (int o = 0; o < N; ++o) v[o] = ((unsigned)v[o] - (unsigned)f.lo > span) ? 0 : v[o];
+    } else if (ok == 2) {
+        const int sh = __builtin_clz((unsigned)f.hi) - 1;
+#pragma unroll
+        for (int o = 0; o < N; ++o) v[o] = (int)((unsigned)v[o] << sh) >> sh;
+    } else {
+#pragma unroll
+        for (int o = 0; o < N; ++o) v[o] &= f.hi;
+    }
+}
+// ... and the same WITHOUT a branch on the kind, for descriptors whose kinds are all among FEAT's (the scalar branch ladder of
+// fx_finish_packed costs more than the vector work it selects): bit 0 (R) roundings that add one bit of the value —
+// RND::ZERO (+ the sign bit), RND::CONV (+ bit d), TRN::SMGN (+ sign * (2^d - 1)) — as v_bfe_u32 + v_mad_i32_i24 with the
+// bit's offset in skip[12:8] and the factor k (0: none) handed in; the bit is read AFTER the step's constant t = 2^(d-1) - 1
+// was added, which moves it only where the result does not depend on it.  Bit 1 (Z) SAT::ZERO next to clamps: w = med3(v),
+// v = (w == v) ? v : (w & cm), cm = -1 clamp / 0 zero in skip[24].  Bit 2 (W) WRP::TCPL of signed formats: v_bfe_i32 of the low
+// skip[21:16] bits (31 = no wrap: every value of the 32-bit kernels fits 31 bits).
+template <int FEAT, int N>
+__device__ __forceinline__ void fx_finish_feat(int (&v)[N], const QFix& f, int k)
+{
+    if (FEAT & 1) {
+        const int off = (f.skip >> 8) & 31;
+#pragma unroll
+        for (int o = 0; o < N; ++o) {
+            int c;
+            asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(c) : "v"(v[o]), "s"(off));
+            v[o] = mad24_vsv(c, k, v[o]);
+        }
+    }
+    if (f.d) {
+#pragma unroll
+        for (int o = 0; o < N; ++o) v[o] >>= f.d;
+    }
+    if (FEAT & 4) {
+        const int wd = (f.skip >> 16) & 63;
+#pragma unroll
+        for (int o = 0; o < N; ++o) asm("v_bfe_i32 %0, %0, 0, %1" : "+v"(v[o]) : "s"(wd));
+    }
+    const int hi = f.hi;
+    if (FEAT & 2) {
+        const int cm = -((f.skip >> 24) & 1);
+#pragma unroll
+        for (int o = 0; o < N; ++o) {
+            int w = v[o];
+            asm("v_med3_i32 %0, %0, %1, %2" : "+v"(w) : "s"(f.lo), "v"(hi));
+            v[o] = (w == v[o]) ? w : (w & cm);
+        }
+    } else {
+#pragma unroll
+        for (int o = 0; o < N; ++o) asm("v_med3_i32 %0, %0, %1, %2" : "+v"(v[o]) : "s"(f.lo), "v"(hi));
+    }
+}
 // the rounding addend in a VGPR, so that it can ride in a multiply-add next to a scalar factor (one scalar operand per instruction)
 __device__ __forceinline__ int fx_vgpr(int s)
 {

@@ -641,10 +641,10 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         // overflow that is one clamp — SAT::TCPL (the reference's default OfMode) or SAT::SMGN ([-hi, hi]); the values that
         // enter a multiplication or an alignment fit 24 bits (v_mad_i32_i24), alignment and exact left shifts are folded
         // into power-of-two factors of at most 2^22
-        auto ok2 = [](const QStep& q) {
-            return q.identity || (q.d >= -22 && q.d <= 29 && (q.O == QG_SAT_TCPL || q.O == QG_SAT_SMGN) &&
-                                  (q.d <= 0 || q.Q == QG_RND_POS_INF || q.Q == QG_TRN_TCPL || q.Q == QG_RND_NEG_INF));
+        auto ok2 = [](const QStep& q) {   // (the other modes as rounding / overflow kinds: cplx_fixed_ok = 3, 8 + features)
+            return q.identity || (q.d >= -22 && q.d <= 29 && (q.O == QG_SAT_TCPL || q.O == QG_SAT_SMGN || q.O == QG_SAT_ZERO || (q.O == QG_WRP_TCPL && q.W >= 1)));
         };
+        bool kinds = false;
         bool all2 = true;
         for (int i = 0; i < ns; ++i) all2 = all2 && ok2(T.mul[i].q);
         for (int p = 0; p < 2; ++p)
@@ -664,44 +664,68 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                 slots = {{QG_B_AC, true, a, cc}, {QG_B_BD, true, b, dd}, {QG_B_AD, true, a, dd}, {QG_B_BC, true, b, cc},
                          {QG_B_RE, false, d->mul[QG_B_AC], d->mul[QG_B_BD]}, {QG_B_IM, false, d->mul[QG_B_AD], d->mul[QG_B_BC]}};
             }
-            auto fix_of = [](const QStep& q, QFix* f) {   // the rounding / clamp part; false when the step shifts left
+            // kinds: any rounding / overflow kind met; feat: the branch-free feature bits they need (qg_fix.h, fx_finish_feat:
+            // 1 R, 2 Z, 4 W), -1 once a kind only the branching form covers was met (RND::INF, unsigned WRP::TCPL, TRN::SMGN by > 23 bits)
+            int feat = 0;
+            bool bf = false;   // second pass: pack for the branch-free form
+            // the rounding / overflow part; returns the rounding factor k of the branch-free form
+            auto fix_of = [&kinds, &feat, &bf](const QStep& q, QFix* f) -> int32_t {
                 memset(f, 0, sizeof *f);
                 f->ka = f->kb = 1;
-                if (q.identity) { f->skip = 1; f->lo = INT32_MIN; f->hi = INT32_MAX; return true; }
+                if (q.identity) { f->skip = bf ? (1 | 31 << 16 | 1 << 24) : 1; f->lo = INT32_MIN; f->hi = INT32_MAX; return 0; }
                 f->lo = q.O == QG_SAT_SMGN ? (q.S ? -(int32_t)q.hi : 0) : (int32_t)q.lo;
                 f->hi = (int32_t)q.hi;
-                if (q.d < 0) { f->ls = -q.d; return false; }
+                const int ok = q.O == QG_SAT_ZERO ? 1 : q.O == QG_WRP_TCPL ? (q.S ? 2 : 3) : 0;
+                int rk = 0;
+                if (q.d > 0) rk = q.Q == QG_RND_ZERO ? 1 : q.Q == QG_RND_INF ? 2 : q.Q == QG_RND_CONV ? 3 : q.Q == QG_TRN_SMGN ? 4 : 0;
+                kinds = kinds || rk || ok;
+                if (rk == 2 || ok == 3 || (rk == 4 && q.d > 23)) feat = -1;
+                else if (feat >= 0) feat |= (rk ? 1 : 0) | (ok == 1 ? 2 : 0) | (ok == 2 ? 4 : 0);
+                int32_t k = 0;
+                if (bf) {
+                    const int off = rk == 3 ? q.d : 31;
+                    f->skip = off << 8 | (ok == 2 ? q.W + 1 : 31) << 16 | (ok == 1 ? 0 : 1) << 24;
+                    k = rk == 4 ? ((int32_t)1 << q.d) - 1 : rk ? 1 : 0;
+                } else {
+                    f->skip = (rk << 8) | (ok << 16);   // (qg_fix.h, fx_finish_packed)
+                }
+                if (q.d < 0) { f->ls = -q.d; return 0; }
                 f->d = q.d;
-                f->t = q.d == 0 ? 0 : q.Q == QG_RND_POS_INF ? (1 << (q.d - 1)) : q.Q == QG_RND_NEG_INF ? (1 << (q.d - 1)) - 1 : 0;
-                return true;
+                const int32_t half = q.d ? (int32_t)1 << (q.d - 1) : 0;
+                f->t = q.d == 0 ? 0 : q.Q == QG_RND_POS_INF ? half : q.Q == QG_RND_NEG_INF ? half - 1 : (bf && (rk == 1 || rk == 3)) ? half - 1 : 0;
+                return k;
             };
             bool reg = true;
-            memset(T.fmul, 0, sizeof T.fmul);
-            for (const Slot& sl : slots) {
-                const QNode& n = T.mul[sl.idx];
-                QFix& f = T.fmul[sl.idx];
-                const bool nonneg = fix_of(n.q, &f);
-                const int ls = (!n.q.identity && n.q.d < 0) ? -n.q.d : 0;   // exact left shift after the operation: folded into the factors
-                if (n.q.identity) f.skip = 0;   // (the operation itself still runs; only its rounding / clamp is the identity)
-                (void)nonneg;
-                auto pow2 = [](int sh) { return sh >= 0 && sh <= 22 ? (int32_t)1 << sh : 0; };   // (0: out of the form's range, see reg)
-                if (sl.mul) {
-                    f.ka = pow2(ls);
-                    reg = reg && ls <= 22 && b24(sl.x, ls) && b24(sl.y, 0);
-                } else {
-                    f.ka = pow2(n.sa + ls);
-                    f.kb = pow2(n.sb + ls);
-                    reg = reg && n.sa >= 0 && n.sb >= 0 && n.sa + ls <= 22 && n.sb + ls <= 22 && b24(sl.x, 0) && b24(sl.y, 0);
+            for (int pass = 0; pass < 2 && reg; ++pass) {
+                bf = pass == 1;
+                memset(T.fmul, 0, sizeof T.fmul);
+                for (const Slot& sl : slots) {
+                    const QNode& n = T.mul[sl.idx];
+                    QFix& f = T.fmul[sl.idx];
+                    const int32_t k = fix_of(n.q, &f);
+                    const int ls = (!n.q.identity && n.q.d < 0) ? -n.q.d : 0;   // exact left shift after the operation: folded into the factors
+                    if (n.q.identity) f.skip &= ~1;   // (the operation itself still runs; only its rounding / overflow is the identity)
+                    f.ls = k;                         // (slots fold their shift into the factors: ls carries the rounding factor)
+                    auto pow2 = [](int sh) { return sh >= 0 && sh <= 22 ? (int32_t)1 << sh : 0; };   // (0: out of the form's range, see reg)
+                    if (sl.mul) {
+                        f.ka = pow2(ls);
+                        reg = reg && ls <= 22 && b24(sl.x, ls) && b24(sl.y, 0);
+                    } else {
+                        f.ka = pow2(n.sa + ls);
+                        f.kb = pow2(n.sb + ls);
+                        reg = reg && n.sa >= 0 && n.sb >= 0 && n.sa + ls <= 22 && n.sb + ls <= 22 && b24(sl.x, 0) && b24(sl.y, 0);
+                    }
                 }
+                for (int p = 0; p < 2 && reg; ++p)
+                    for (uint32_t l = 0; l < (uint32_t)T.n_levels_k && reg; ++l) {
+                        reg = reg && T.level_add[p][l].sa == 0 && T.level_add[p][l].sb == 0;
+                        T.fadd[p][l].ka = fix_of(T.level_add[p][l].q, &T.fadd[p][l]);   // (a left shift at a node is QFix::ls; ka: the rounding factor)
+                        T.fcvt[p][l].ka = fix_of(T.level_cvt[p][l], &T.fcvt[p][l]);
+                        if (T.level_add[p][l].q.identity) T.fadd[p][l].skip &= ~1;
+                    }
+                if (!kinds || feat <= 0) break;   // plain compact records, or the branching form: the first packing stands
             }
-            for (int p = 0; p < 2 && reg; ++p)
-                for (uint32_t l = 0; l < (uint32_t)T.n_levels_k && reg; ++l) {
-                    reg = reg && T.level_add[p][l].sa == 0 && T.level_add[p][l].sb == 0;
-                    fix_of(T.level_add[p][l].q, &T.fadd[p][l]);   // (a left shift at a node is QFix::ls)
-                    fix_of(T.level_cvt[p][l], &T.fcvt[p][l]);
-                    if (T.level_add[p][l].q.identity) T.fadd[p][l].skip = 0;
-                }
-            if (reg) out->cplx_fixed_ok = 2;
+            if (reg) out->cplx_fixed_ok = !kinds ? 2 : feat > 0 ? 8 + feat : 3;
         }
     }
     if (!out->linear_ok)

@@ -13,7 +13,8 @@
 //   multiply slot:   v = (x * ka) * y + t;          v >>= d;   v = clamp(v, lo, hi)       (ka = 2^(left shift of an exact product))
 //   tree node:       v = x + v + t;   v <<= ls;     v >>= d;   v = clamp(v, lo, hi)       (ls: a level type with MORE fraction bits)
 // t = the rounding mode's addend (TRN::TCPL 0, RND::POS_INF 2^(d-1), RND::NEG_INF 2^(d-1) - 1); an identity step is d = 0,
-// t = 0 and the full int32 range.
+// t = 0 and the full int32 range.  cplx_fixed_ok == 3 / >= 8: `skip` also packs the step's rounding / overflow kind
+// (qg_fix.h: fx_finish_packed / fx_finish_feat; the latter's rounding factor is `ls` of a slot, `ka` of a node).
 // Records of the REAL kernel (product, nodes) have no factors.  fast_mode 3 (every step clamps): as above.  fast_mode 4 (a step
 // tests the range or wraps): the value is kept biased by -lo of its format, and the fields mean: t = the node's one constant
 // (rounding addend, change of bias), kb = overflow kind (0 clamp, 1 SAT::ZERO, 2 WRP::TCPL, 4 none), hi = span = hi - lo,
@@ -61,7 +62,7 @@ struct QAnalysis {
     int split_s;             // > 0: product evaluated split at its rounding shift
     int mul24_ok;            // multiplies fit v_mul_i32_i24
     int cplx_fast_ok;        // the 32-bit complex tree kernel applies
-    int cplx_fixed_ok;       // ... and every step on the path is RND::POS_INF (or exact) + SAT::TCPL: fixed-mode variant (2: register-resident steps)
+    int cplx_fixed_ok;       // ... and every step on the path is RND::POS_INF (or exact) + SAT::TCPL: fixed-mode variant (2: compact records; 3: ... with rounding / overflow kinds; 8 + f: ... of the branch-free feature set f)
     int fast_mode;           // 0 runtime modes; 1 one format everywhere, TCPL + SAT::ZERO; 2 TCPL + SAT::TCPL; 3 / 4 / 5 per-level formats, compact steps (QFix; 3: every step clamps, 4: biased values, 5: unbiased)
     int tree64_ok;           // the 2x2-outputs-per-lane 64-bit tree kernel applies (real, 5..16 levels)
     int gemv_ok;             // the one-column 32-bit tree kernel applies (N = 1, K = 2^p >= 16)

@@ -79,16 +79,25 @@ __device__ __forceinline__ void node_n(int (&v)[N], const int (&x)[N], const QTr
 }
 
 // ---- MODE 2: the compact fixed-mode steps (qg_fix.h, QFix of qg_plan.h) ----
-template <int N>
+// KIND 0: every step adds a constant and clamps; 1: the records carry rounding / overflow kinds (fx_finish_packed, a branch
+// ladder per step); 8 + FEAT: kinds of the branch-free feature set FEAT (fx_finish_feat; k: the rounding's factor)
+template <int KIND, int N>
+__device__ __forceinline__ void fx_done(int (&v)[N], const QFix& f, int k)
+{
+    if constexpr (KIND >= 8) fx_finish_feat<KIND - 8, N>(v, f, k);
+    else if constexpr (KIND == 1) fx_finish_packed<N>(v, f);
+    else fx_finish<N>(v, f);
+}
+template <int KIND, int N>
 __device__ __forceinline__ void fx_addsub(int (&out)[N], const int (&x)[N], const int (&y)[N], const QFix& f, bool sub)
 {
     const int kb = sub ? -f.kb : f.kb;
     const int tv = fx_vgpr(f.t);
 #pragma unroll
     for (int o = 0; o < N; ++o) out[o] = mad24_vsv(y[o], kb, mad24_vsv(x[o], f.ka, tv));
-    fx_finish<N>(out, f);
+    fx_done<KIND, N>(out, f, f.ls);
 }
-template <int N>
+template <int KIND, int N>
 __device__ __forceinline__ void fx_mul(int (&out)[N], const int (&x)[N], const int (&y)[N], const QFix& f)
 {
     if (f.ka != 1) {   // an exact product that is brought to MORE fraction bits: scale one factor (wave-uniform, rare)
@@ -98,9 +107,9 @@ __device__ __forceinline__ void fx_mul(int (&out)[N], const int (&x)[N], const i
 #pragma unroll
         for (int o = 0; o < N; ++o) out[o] = mad24_vvs(x[o], y[o], f.t);
     }
-    fx_finish<N>(out, f);
+    fx_done<KIND, N>(out, f, f.ls);
 }
-template <int N>
+template <int KIND, int N>
 __device__ __forceinline__ void fx_node(int (&v)[N], const int (&x)[N], const QFix& fa, const QFix& fc)
 {
 #pragma unroll
@@ -109,8 +118,8 @@ __device__ __forceinline__ void fx_node(int (&v)[N], const int (&x)[N], const QF
 #pragma unroll
         for (int o = 0; o < N; ++o) v[o] = (int)((unsigned)v[o] << fa.ls);
     }
-    fx_finish<N>(v, fa);
-    if (!fc.skip) {   // the level buffer's conversion (identity unless the level type differs from the add's result)
+    fx_done<KIND, N>(v, fa, fa.ka);
+    if (!(fc.skip & 1)) {   // the level buffer's conversion (identity unless the level type differs from the add's result)
         if (fc.ls) {
 #pragma unroll
             for (int o = 0; o < N; ++o) v[o] = (int)((unsigned)v[o] << fc.ls);
@@ -118,27 +127,29 @@ __device__ __forceinline__ void fx_node(int (&v)[N], const int (&x)[N], const QF
 #pragma unroll
             for (int o = 0; o < N; ++o) v[o] += fc.t;
         }
-        fx_finish<N>(v, fc);
+        fx_done<KIND, N>(v, fc, fc.ka);
     }
 }
 
-// MODE: 0 run-time modes, 1 fixed modes read from the step table, 2 fixed modes in the compact branch-free form
+// MODE: 0 run-time modes, 1 fixed modes read from the step table, 2 fixed modes in the compact branch-free form, 3 the compact
+// form with rounding / overflow kinds (SAT::ZERO, WRP::TCPL, RND::ZERO / INF / CONV, TRN::SMGN) behind a branch per step,
+// 8 + FEAT the same without the branch for the kinds of FEAT (qg_fix.h, fx_finish_feat)
 template <int MODE, int N>
 __device__ __forceinline__ void op_addsub(int (&out)[N], const int (&x)[N], const int (&y)[N], const QTreeTable* __restrict__ t, int slot, bool sub)
 {
-    if constexpr (MODE == 2) fx_addsub<N>(out, x, y, fx_at(t, FX_OFF_MUL(slot)), sub);
+    if constexpr (MODE >= 2) fx_addsub<(MODE >= 8 ? MODE : MODE == 3), N>(out, x, y, fx_at(t, FX_OFF_MUL(slot)), sub);
     else addsub_n<MODE == 1, N>(out, x, y, t->mul[slot], sub);
 }
 template <int MODE, int N>
 __device__ __forceinline__ void op_mul(int (&out)[N], const int (&x)[N], const int (&y)[N], const QTreeTable* __restrict__ t, int slot)
 {
-    if constexpr (MODE == 2) fx_mul<N>(out, x, y, fx_at(t, FX_OFF_MUL(slot)));
+    if constexpr (MODE >= 2) fx_mul<(MODE >= 8 ? MODE : MODE == 3), N>(out, x, y, fx_at(t, FX_OFF_MUL(slot)));
     else mul_n<MODE == 1, N>(out, x, y, t->mul[slot]);
 }
 template <int MODE, int N>
 __device__ __forceinline__ void op_node(int (&v)[N], const int (&x)[N], const QTreeTable* __restrict__ t, int part, int l)
 {
-    if constexpr (MODE == 2) fx_node<N>(v, x, fx_at(t, FX_OFF_ADD(part, l)), fx_at(t, FX_OFF_CVT(part, l)));
+    if constexpr (MODE >= 2) fx_node<(MODE >= 8 ? MODE : MODE == 3), N>(v, x, fx_at(t, FX_OFF_ADD(part, l)), fx_at(t, FX_OFF_CVT(part, l)));
     else node_n<MODE == 1, N>(v, x, t, part, l);
 }
 
@@ -333,7 +344,23 @@ hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, i
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
     // fixed: 0 run-time modes; 1 fixed modes, steps read from the step table; 2 fixed modes, compact branch-free steps
-    if (fixed == 2) {
+    if (fixed >= 8) {   // compact steps, branch-free kinds of the feature set fixed - 8 (1 R, 2 Z, 3 RZ, 4 W; the others run the full set)
+        const int feat = fixed - 8;
+#define QG_CPLX_FEAT(F)                                                                                                  \
+    do {                                                                                                                 \
+        if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12, 8 + F>), dim3((unsigned)blocks), dim3(256), 0, st, g);   \
+        else hipLaunchKernelGGL((k_tree_cplx<16, 8 + F>), dim3((unsigned)blocks), dim3(256), 0, st, g);                  \
+    } while (0)
+        if (feat == 1) QG_CPLX_FEAT(1);
+        else if (feat == 2) QG_CPLX_FEAT(2);
+        else if (feat == 3) QG_CPLX_FEAT(3);
+        else if (feat == 4) QG_CPLX_FEAT(4);
+        else QG_CPLX_FEAT(7);
+#undef QG_CPLX_FEAT
+    } else if (fixed == 3) {   // compact steps with rounding / overflow kinds
+        if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12, 3>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_tree_cplx<16, 3>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    } else if (fixed == 2) {
         if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g);
         else hipLaunchKernelGGL((k_tree_cplx<16, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     } else if (fixed) {

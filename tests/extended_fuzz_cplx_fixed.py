@@ -5,7 +5,8 @@ whose every step rounds by "add a constant, shift right" (TRN::TCPL, RND::POS_IN
 random sub-operation tags, 0..2 level types, any K >= 17 — so that the planner picks the compact branch-free steps, or the
 table-driven fixed steps where a condition of the compact form fails (left shifts at tree nodes, per-level formats).  Each
 case: GPU against the oracle, and against the same plan with run-time modes (QG_OPT_RUNTIME_MODES).
-usage: python tests/extended_fuzz_cplx_fixed.py [cases] [seed]"""
+With a third argument "all" the formats draw from every QuMode and OfMode (the compact form's rounding / overflow kinds).
+usage: python tests/extended_fuzz_cplx_fixed.py [cases] [seed] [all]"""
 import json
 import os
 import random
@@ -18,7 +19,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import qoracle as oracle  # noqa: E402
 from qublas_amd import capi  # noqa: E402
-from qublas_amd.desc import BasicComplexMul, Qcomplex, Qu, RND, SAT, TRN, Tags, TFComplexMul, lower  # noqa: E402
+from qublas_amd.desc import BasicComplexMul, Qcomplex, Qu, RND, SAT, TRN, WRP, Tags, TFComplexMul, lower  # noqa: E402
+
+ALL_MODES = len(sys.argv) > 3 and sys.argv[3] == "all"
 
 
 def rq(rng, bits):
@@ -30,6 +33,9 @@ def rq(rng, bits):
         i, f = i + shift, f - shift          # negative or smaller fracBits at the same width
     # modes the compact steps cover: "add a constant, shift right" roundings and one-clamp overflows (mixed modes between
     # two operands merge to the reference's defaults TRN::TCPL / SAT::TCPL, which are among them)
+    if ALL_MODES:   # (argv[3] == "all") ... and the modes the compact steps cover as rounding / overflow KINDS
+        return Qu(i, f, rng.random() < 0.85, rng.choice([RND.POS_INF, TRN.TCPL, RND.NEG_INF, RND.ZERO, RND.INF, RND.CONV, TRN.SMGN]),
+                  rng.choice([SAT.TCPL, SAT.SMGN, SAT.ZERO, WRP.TCPL]))
     return Qu(i, f, rng.random() < 0.85, rng.choice([RND.POS_INF, RND.POS_INF, TRN.TCPL, TRN.TCPL, RND.NEG_INF]), rng.choice([SAT.TCPL, SAT.TCPL, SAT.SMGN]))
 
 

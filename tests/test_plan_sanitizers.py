@@ -59,7 +59,7 @@ def random_descs(n, seed):
 
 def compact_form_descs(n, seed):
     """descriptors whose roundings add a constant and whose overflows clamp / test / wrap: the planner's compact step records
-    (QFix: fast_mode 3 / 4 / 5, cplx_fixed_ok 2, gemv_fixed 3 / 5) are built for most of them"""
+    (QFix: fast_mode 3 / 4 / 5, cplx_fixed_ok 2 / 3 / 8 + features, gemv_fixed 3 / 5) are built for most of them"""
     from qublas_amd.desc import BasicComplexMul, Qcomplex, TFComplexMul, lower_reduce
     rng = random.Random(seed)
     QM, OM = [5, 0, 1], [0, 0, 2, 1, 3]     # TRN::TCPL, RND::POS_INF, RND::NEG_INF; SAT::TCPL, SAT::SMGN, SAT::ZERO, WRP::TCPL
@@ -78,8 +78,16 @@ def compact_form_descs(n, seed):
                           add_args=[rq(rng.choice([10, 18, 26, 30])) for _ in range(rng.randint(0, 3))] or None)
             elif kind < 0.55:       # Qreduce lowering (incl. signed SAT::SMGN element types)
                 d = lower_reduce(rq(rng.choice([4, 8, 12])), rng.choice([1, 9]), rng.choice([1, 2, 16, 64, 4096]), [rq(rng.choice([10, 18])) for _ in range(rng.randint(0, 2))] or None)
-            else:                   # complex, clamping modes
-                c = lambda b: Qcomplex(rq(b, [0, 0, 2]), rq(b, [0, 0, 2]))
+            else:                   # complex: clamping modes, or (a third) any rounding / overflow kind
+                allk = rng.random() < 0.34
+                qm, om = (list(range(7)), [0, 1, 2, 3]) if allk else (QM, [0, 0, 2])
+
+                def c(b):
+                    parts = []
+                    for _ in range(2):
+                        i = rng.randint(0, b)
+                        parts.append(Qu(i, b - i, rng.random() < 0.85, rng.choice(qm), rng.choice(om)))
+                    return Qcomplex(*parts)
                 ea = c(rng.choice([5, 8, 11]))
                 mul = TFComplexMul(abcT=Tags(rng.randint(4, 12), rng.randint(-2, 8)), ABT=rq(rng.choice([8, 14, 29]), [0, 2]) if rng.random() < 0.3 else None) if rng.random() < 0.5 \
                     else BasicComplexMul(acT=Tags(rng.randint(4, 24), rng.randint(-2, 10)) if rng.random() < 0.5 else None)
@@ -117,4 +125,4 @@ def test_planner_under_asan_ubsan(tmp_path):
             n_ok += 1
     assert n_ok > 500
     # the record-building code ran under the sanitizers for every form
-    assert {1, 2, 3, 4, 5} <= forms["fast"] and {1, 2} <= forms["cplx"] and {1, 2, 3, 5} <= forms["gemv"], forms
+    assert {1, 2, 3, 4, 5} <= forms["fast"] and {1, 2, 3} <= forms["cplx"] and any(f >= 8 for f in forms["cplx"]) and {1, 2, 3, 5} <= forms["gemv"], forms

@@ -8,12 +8,16 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from qublas_amd import capi  # noqa: E402
-from qublas_amd.desc import Qcomplex, Qu, RND, SAT, TRN, TFComplexMul, lower  # noqa: E402
+from qublas_amd.desc import Qcomplex, Qu, RND, SAT, TRN, WRP, TFComplexMul, lower  # noqa: E402
 
 E = Qu(8, 8)
 EZ = Qu(8, 8, True, TRN.TCPL, SAT.ZERO)
 S = 2048
 CD = Qcomplex(Qu(6, 3), Qu(6, -3))     # configuration 5's widths with the reference's default modes
+CZ = Qcomplex(Qu(6, 3, True, TRN.TCPL, SAT.ZERO), Qu(6, -3, True, TRN.TCPL, SAT.ZERO))
+CC = Qcomplex(Qu(6, 3, True, RND.CONV), Qu(6, -3, True, RND.CONV))
+CW = Qcomplex(Qu(6, 3, True, TRN.TCPL, WRP.TCPL), Qu(6, -3, True, TRN.TCPL, WRP.TCPL))
+CI = Qcomplex(Qu(6, 3, True, RND.INF), Qu(6, -3, True, RND.INF))
 CASES = [
     ("int<8,8> default tags (one format, SAT::TCPL)", lower(E, E, E, S, S, S), 0),
     ("same, run-time modes forced", lower(E, E, E, S, S, S), capi.OPT_RUNTIME_MODES),
@@ -35,6 +39,12 @@ CASES = [
     ("same, run-time modes forced", lower(Qu(8, 8, True, RND.CONV), Qu(8, 8, True, RND.CONV), Qu(8, 8, True, RND.CONV), S, S, S), capi.OPT_RUNTIME_MODES),
     ("complex int<6,3>/int<6,-3> DEFAULT modes, TFComplexMul", lower(CD, CD, CD, S, S, S, mul_args=TFComplexMul()), 0),
     ("same, run-time modes forced", lower(CD, CD, CD, S, S, S, mul_args=TFComplexMul()), capi.OPT_RUNTIME_MODES),
+    # (the README's own Qcomplex<type1, type2> mixes SAT::ZERO and SAT::TCPL parts, which merge to the default modes: plain compact form)
+    ("complex int<6,3>/int<6,-3> SAT::ZERO (an overflow kind of the compact form), TFComplexMul", lower(CZ, CZ, CZ, S, S, S, mul_args=TFComplexMul()), 0),
+    ("same, run-time modes forced", lower(CZ, CZ, CZ, S, S, S, mul_args=TFComplexMul()), capi.OPT_RUNTIME_MODES),
+    ("complex int<6,3>/int<6,-3> RND::CONV, TFComplexMul", lower(CC, CC, CC, S, S, S, mul_args=TFComplexMul()), 0),
+    ("complex int<6,3>/int<6,-3> WRP::TCPL, TFComplexMul", lower(CW, CW, CW, S, S, S, mul_args=TFComplexMul()), 0),
+    ("complex int<6,3>/int<6,-3> RND::INF (the branching kinds form), TFComplexMul", lower(CI, CI, CI, S, S, S, mul_args=TFComplexMul()), 0),
 ]
 
 
