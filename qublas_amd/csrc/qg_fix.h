@@ -151,7 +151,8 @@ __device__ __forceinline__ void fx_finish_packed(int (&v)[N], const QFix& f)
 // fx_finish_packed costs more than the vector work it selects): bit 0 (R) roundings that add one bit of the value —
 // RND::ZERO (+ the sign bit), RND::CONV (+ bit d), TRN::SMGN (+ sign * (2^d - 1)) — as v_bfe_u32 + v_mad_i32_i24 with the
 // bit's offset in skip[12:8] and the factor k (0: none) handed in; the bit is read AFTER the step's constant t = 2^(d-1) - 1
-// was added, which moves it only where the result does not depend on it.  Bit 1 (Z) SAT::ZERO next to clamps: w = med3(v),
+// was added, which moves it only where the result does not depend on it.  RND::INF adds the INVERTED sign bit: its constant
+// carries 2^31 as well, and the shifted value is repaired by W's sign-extraction of the low 31 - d bits.  Bit 1 (Z) SAT::ZERO next to clamps: w = med3(v),
 // v = (w == v) ? v : (w & cm), cm = -1 clamp / 0 zero in skip[24].  Bit 2 (W) WRP::TCPL of signed formats: v_bfe_i32 of the low
 // skip[21:16] bits (31 = no wrap: every value of the 32-bit kernels fits 31 bits).
 template <int FEAT, int N>

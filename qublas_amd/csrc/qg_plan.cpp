@@ -665,7 +665,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                          {QG_B_RE, false, d->mul[QG_B_AC], d->mul[QG_B_BD]}, {QG_B_IM, false, d->mul[QG_B_AD], d->mul[QG_B_BC]}};
             }
             // kinds: any rounding / overflow kind met; feat: the branch-free feature bits they need (qg_fix.h, fx_finish_feat:
-            // 1 R, 2 Z, 4 W), -1 once a kind only the branching form covers was met (RND::INF, unsigned WRP::TCPL, TRN::SMGN by > 23 bits)
+            // 1 R, 2 Z, 4 W), -1 once a kind only the branching form covers was met (unsigned WRP::TCPL, TRN::SMGN by > 23 bits)
             int feat = 0;
             bool bf = false;   // second pass: pack for the branch-free form
             // the rounding / overflow part; returns the rounding factor k of the branch-free form
@@ -679,12 +679,16 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                 int rk = 0;
                 if (q.d > 0) rk = q.Q == QG_RND_ZERO ? 1 : q.Q == QG_RND_INF ? 2 : q.Q == QG_RND_CONV ? 3 : q.Q == QG_TRN_SMGN ? 4 : 0;
                 kinds = kinds || rk || ok;
-                if (rk == 2 || ok == 3 || (rk == 4 && q.d > 23)) feat = -1;
-                else if (feat >= 0) feat |= (rk ? 1 : 0) | (ok == 1 ? 2 : 0) | (ok == 2 ? 4 : 0);
+                if (ok == 3 || (rk == 4 && q.d > 23)) feat = -1;
+                else if (feat >= 0) feat |= (rk ? 1 : 0) | (ok == 1 ? 2 : 0) | (ok == 2 || rk == 2 ? 4 : 0);
                 int32_t k = 0;
                 if (bf) {
                     const int off = rk == 3 ? q.d : 31;
-                    f->skip = off << 8 | (ok == 2 ? q.W + 1 : 31) << 16 | (ok == 1 ? 0 : 1) << 24;
+                    int wd = ok == 2 ? q.W + 1 : 31;
+                    // RND::INF adds the INVERTED sign bit: the step's constant carries 2^31, which inverts bit 31 before it is read; the
+                    // shifted value is then right in its low 31 - d bits, which the wrap's sign-extraction (feature W) keeps
+                    if (rk == 2 && wd > 31 - q.d) wd = 31 - q.d;
+                    f->skip = off << 8 | wd << 16 | (ok == 1 ? 0 : 1) << 24;
                     k = rk == 4 ? ((int32_t)1 << q.d) - 1 : rk ? 1 : 0;
                 } else {
                     f->skip = (rk << 8) | (ok << 16);   // (qg_fix.h, fx_finish_packed)
@@ -692,7 +696,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                 if (q.d < 0) { f->ls = -q.d; return 0; }
                 f->d = q.d;
                 const int32_t half = q.d ? (int32_t)1 << (q.d - 1) : 0;
-                f->t = q.d == 0 ? 0 : q.Q == QG_RND_POS_INF ? half : q.Q == QG_RND_NEG_INF ? half - 1 : (bf && (rk == 1 || rk == 3)) ? half - 1 : 0;
+                f->t = q.d == 0 ? 0 : q.Q == QG_RND_POS_INF ? half : q.Q == QG_RND_NEG_INF ? half - 1 : (bf && (rk == 1 || rk == 3)) ? half - 1 : (bf && rk == 2) ? INT32_MIN + (half - 1) : 0;
                 return k;
             };
             bool reg = true;

@@ -344,7 +344,7 @@ hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, i
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
     // fixed: 0 run-time modes; 1 fixed modes, steps read from the step table; 2 fixed modes, compact branch-free steps
-    if (fixed >= 8) {   // compact steps, branch-free kinds of the feature set fixed - 8 (1 R, 2 Z, 3 RZ, 4 W; the others run the full set)
+    if (fixed >= 8) {   // compact steps, branch-free kinds of the feature set fixed - 8 (1 R, 2 Z, 3 RZ, 4 W, 5 RW; the other one runs the full set)
         const int feat = fixed - 8;
 #define QG_CPLX_FEAT(F)                                                                                                  \
     do {                                                                                                                 \
@@ -355,6 +355,7 @@ hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, i
         else if (feat == 2) QG_CPLX_FEAT(2);
         else if (feat == 3) QG_CPLX_FEAT(3);
         else if (feat == 4) QG_CPLX_FEAT(4);
+        else if (feat == 5) QG_CPLX_FEAT(5);
         else QG_CPLX_FEAT(7);
 #undef QG_CPLX_FEAT
     } else if (fixed == 3) {   // compact steps with rounding / overflow kinds

@@ -347,7 +347,7 @@ def test_complex_fixed_mode_step_forms(oracle):
         (Qcomplex(Qu(5, 4, True, RND.NEG_INF, SAT.SMGN), Qu(6, 2, True, RND.NEG_INF, SAT.SMGN)), Qcomplex(Qu(8, 2, True, RND.NEG_INF, SAT.SMGN), Qu(8, 2, True, TRN.TCPL, SAT.TCPL)),
          dict(mul_args=BasicComplexMul(), add_args=[Qcomplex(Qu(12, 3, True, RND.NEG_INF, SAT.SMGN), Qu(12, 1, True, RND.NEG_INF, SAT.SMGN))]), "fixed modes, compact"),
         # value-dependent roundings (RND::ZERO / INF / CONV, TRN::SMGN) and SAT::ZERO / WRP::TCPL: rounding / overflow kinds of the compact form,
-        # branch-free unless RND::INF or an unsigned WRP::TCPL is among them (the last case)
+        # branch-free unless an unsigned WRP::TCPL is among them (the last case)
         (Qcomplex(Qu(6, 3, True, RND.CONV), Qu(6, 3, True, RND.CONV)), Qcomplex(Qu(9, 3), Qu(9, 1)), dict(mul_args=TFComplexMul()), "compact, branch-free rounding / overflow kinds"),
         (Qcomplex(Qu(8, 3, True, TRN.TCPL, SAT.ZERO), Qu(4, 5, False, RND.POS_INF, SAT.SMGN)), Qcomplex(Qu(9, 3, True, RND.ZERO, SAT.ZERO), Qu(7, 1, True, TRN.SMGN, WRP.TCPL)),
          dict(mul_args=BasicComplexMul()), "compact, branch-free rounding / overflow kinds"),     # RND::ZERO, TRN::SMGN, SAT::ZERO, signed WRP::TCPL: all three feature bits
@@ -355,6 +355,9 @@ def test_complex_fixed_mode_step_forms(oracle):
          dict(mul_args=TFComplexMul()), "compact, branch-free rounding / overflow kinds"),        # SAT::ZERO everywhere
         (Qcomplex(Qu(6, 3, True, TRN.TCPL, WRP.TCPL), Qu(6, 1, True, TRN.TCPL, WRP.TCPL)), Qcomplex(Qu(7, 3, True, TRN.TCPL, WRP.TCPL), Qu(5, 1, True, TRN.TCPL, WRP.TCPL)),
          dict(mul_args=TFComplexMul()), "compact, branch-free rounding / overflow kinds"),        # signed WRP::TCPL everywhere
+        (Qcomplex(Qu(6, 3, True, RND.INF), Qu(6, 1, True, RND.INF, SAT.ZERO)), Qcomplex(Qu(7, 1, True, RND.INF), Qu(5, 0, True, RND.INF, WRP.TCPL)),
+         dict(mul_args=BasicComplexMul(acT=Tags(8, 4)), add_args=[Qcomplex(Qu(12, 2, True, RND.INF), Qu(12, 1, True, RND.INF, SAT.ZERO))]),
+         "compact, branch-free rounding / overflow kinds"),                                       # RND::INF: the inverted sign bit through a 2^31 bias
         (Qcomplex(Qu(5, 4, True, RND.INF, WRP.TCPL), Qu(6, 2, False, RND.ZERO, WRP.TCPL)), Qcomplex(Qu(6, 2, True, RND.INF, SAT.ZERO), Qu(5, 1, False, RND.CONV, WRP.TCPL)),
          dict(mul_args=TFComplexMul(), add_args=[Qcomplex(Qu(9, 3, True, RND.INF, WRP.TCPL), Qu(8, 1, False, TRN.SMGN, WRP.TCPL)),
                                                  Qcomplex(Qu(7, 2, True, RND.ZERO, SAT.ZERO), Qu(9, 3, True, RND.CONV, SAT.SMGN))]), "compact, rounding / overflow kinds"),

@@ -44,7 +44,7 @@ CASES = [
     ("same, run-time modes forced", lower(CZ, CZ, CZ, S, S, S, mul_args=TFComplexMul()), capi.OPT_RUNTIME_MODES),
     ("complex int<6,3>/int<6,-3> RND::CONV, TFComplexMul", lower(CC, CC, CC, S, S, S, mul_args=TFComplexMul()), 0),
     ("complex int<6,3>/int<6,-3> WRP::TCPL, TFComplexMul", lower(CW, CW, CW, S, S, S, mul_args=TFComplexMul()), 0),
-    ("complex int<6,3>/int<6,-3> RND::INF (the branching kinds form), TFComplexMul", lower(CI, CI, CI, S, S, S, mul_args=TFComplexMul()), 0),
+    ("complex int<6,3>/int<6,-3> RND::INF, TFComplexMul", lower(CI, CI, CI, S, S, S, mul_args=TFComplexMul()), 0),
 ]
 
 
