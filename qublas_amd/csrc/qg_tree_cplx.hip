@@ -165,8 +165,11 @@ struct QTreeCplxArgs {
 template <int MAXL, int MODE>
 __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
 {
-    __shared__ __attribute__((aligned(16))) int sA[2][TMB][PITCH];
-    __shared__ __attribute__((aligned(16))) int sB[2][TNB][PITCH];
+    // planes: BasicComplexMul {a, b} / {c, d}; TFComplexMul {a+b, b, b-a} / {c, c+d, d} — the three additions in front of
+    // TF's multiplications depend on ONE operand element each, so they are made once per element while the tile is staged,
+    // not once per output in the k loop (where they were 12 of 40 quantised values per k step and lane)
+    __shared__ __attribute__((aligned(16))) int sA[3][TMB][PITCH];
+    __shared__ __attribute__((aligned(16))) int sB[3][TNB][PITCH];
     const QTreeTable* __restrict__ tab = g.tab;
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
@@ -195,65 +198,93 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
 
     for (int64_t k0 = 0; k0 < g.K; k0 += KC) {
         __syncthreads();
-        // stage: A and B, 2 parts x 32 rows x 32 k = 512 16-byte chunks each, 2 per thread
+        // stage: A and B, 2 parts x 32 rows x 32 k = 512 16-byte chunks each; a thread takes both parts of one chunk
+        {
+            const int r = (tid >> 3) & 31, q = tid & 7;
+            int4 x[2], y[2];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int ch = tid + 256 * c, p = ch >> 8, r = (ch >> 3) & 31, q = ch & 7;
-            int4 x = make_int4(0, 0, 0, 0), y = make_int4(0, 0, 0, 0);
-            if (m0 + r < g.M) x = *(const int4*)(g.A + ((int64_t)p * g.M + m0 + r) * g.K + k0 + q * 4);
-            if (n0 + r < g.N) y = *(const int4*)(g.B + ((int64_t)p * g.N + n0 + r) * g.K + k0 + q * 4);
-            *(int4*)&sA[p][r][q * 4] = x;
-            *(int4*)&sB[p][r][q * 4] = y;
+            for (int p = 0; p < 2; ++p) {
+                x[p] = make_int4(0, 0, 0, 0);
+                y[p] = make_int4(0, 0, 0, 0);
+                if (m0 + r < g.M) x[p] = *(const int4*)(g.A + ((int64_t)p * g.M + m0 + r) * g.K + k0 + q * 4);
+                if (n0 + r < g.N) y[p] = *(const int4*)(g.B + ((int64_t)p * g.N + n0 + r) * g.K + k0 + q * 4);
+            }
+            if (tf) {
+                const int ar4[4] = {x[0].x, x[0].y, x[0].z, x[0].w}, ai4[4] = {x[1].x, x[1].y, x[1].z, x[1].w};
+                const int br4[4] = {y[0].x, y[0].y, y[0].z, y[0].w}, bi4[4] = {y[1].x, y[1].y, y[1].z, y[1].w};
+                int ab[4], ba[4], cd[4];
+                op_addsub<MODE, 4>(ab, ar4, ai4, tab, QG_T_AB, false);  // (a+b), per A element
+                op_addsub<MODE, 4>(ba, ai4, ar4, tab, QG_T_BA, true);   // (b-a), per A element
+                op_addsub<MODE, 4>(cd, br4, bi4, tab, QG_T_CD, false);  // (c+d), per B element
+                *(int4*)&sA[0][r][q * 4] = make_int4(ab[0], ab[1], ab[2], ab[3]);
+                *(int4*)&sA[1][r][q * 4] = x[1];
+                *(int4*)&sA[2][r][q * 4] = make_int4(ba[0], ba[1], ba[2], ba[3]);
+                *(int4*)&sB[0][r][q * 4] = y[0];
+                *(int4*)&sB[1][r][q * 4] = make_int4(cd[0], cd[1], cd[2], cd[3]);
+                *(int4*)&sB[2][r][q * 4] = y[1];
+            } else {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    *(int4*)&sA[p][r][q * 4] = x[p];
+                    *(int4*)&sB[p][r][q * 4] = y[p];
+                }
+            }
         }
         __syncthreads();
 #pragma unroll 1
         for (int kb = 0; kb < KC / 16; ++kb) {
 #pragma unroll
-            for (int kq = 0; kq < 4; ++kq) {
-                int4 a4[2][2], b4[2][2];  // [part][row/col of the 2x2 block]
+            for (int kq = 0; kq < 8; ++kq) {   // two leaves per LDS read: 8-byte reads keep 24 registers of operands live, 16-byte reads 48
+                int2 a4[3][2], b4[3][2];  // [plane][row/col of the 2x2 block]
 #pragma unroll
-                for (int p = 0; p < 2; ++p)
+                for (int p = 0; p < 3; ++p)
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        a4[p][i] = *(const int4*)&sA[p][ty * 2 + i][kb * 16 + kq * 4];
-                        b4[p][i] = *(const int4*)&sB[p][tx + 16 * i][kb * 16 + kq * 4];   // columns tx and tx + 16: 16 consecutive rows per read group, no bank conflict (qg_tree_fast.hip)
+                        if (p < 2 || tf) {
+                            a4[p][i] = *(const int2*)&sA[p][ty * 2 + i][kb * 16 + kq * 2];
+                            b4[p][i] = *(const int2*)&sB[p][tx + 16 * i][kb * 16 + kq * 2];   // columns tx and tx + 16: 16 consecutive rows per read group, no bank conflict (qg_tree_fast.hip)
+                        } else {
+                            a4[p][i] = make_int2(0, 0);
+                            b4[p][i] = make_int2(0, 0);
+                        }
                     }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int kk = kq * 4 + e;
-                    int ar[2], ai[2], br[2], bi[2];  // a = ar + i*ai (rows), b = br + i*bi (cols)
+                for (int e = 0; e < 2; ++e) {
+                    const int kk = kq * 2 + e;
+                    int a0[2], a1[2], a2[2], b0[2], b1[2], b2[2];  // planes of the A rows / B columns of this lane's 2 x 2 outputs
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        ar[i] = e == 0 ? a4[0][i].x : e == 1 ? a4[0][i].y : e == 2 ? a4[0][i].z : a4[0][i].w;
-                        ai[i] = e == 0 ? a4[1][i].x : e == 1 ? a4[1][i].y : e == 2 ? a4[1][i].z : a4[1][i].w;
-                        br[i] = e == 0 ? b4[0][i].x : e == 1 ? b4[0][i].y : e == 2 ? b4[0][i].z : b4[0][i].w;
-                        bi[i] = e == 0 ? b4[1][i].x : e == 1 ? b4[1][i].y : e == 2 ? b4[1][i].z : b4[1][i].w;
+                        a0[i] = e == 0 ? a4[0][i].x : a4[0][i].y;
+                        a1[i] = e == 0 ? a4[1][i].x : a4[1][i].y;
+                        a2[i] = e == 0 ? a4[2][i].x : a4[2][i].y;
+                        b0[i] = e == 0 ? b4[0][i].x : b4[0][i].y;
+                        b1[i] = e == 0 ? b4[1][i].x : b4[1][i].y;
+                        b2[i] = e == 0 ? b4[2][i].x : b4[2][i].y;
                     }
                     // ---- one complex product per output (x = a+bi from A, y = c+di from B)
-                    int xr[4], xi[4], yr[4], yi[4];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            xr[i * 2 + j] = ar[i]; xi[i * 2 + j] = ai[i];
-                            yr[i * 2 + j] = br[j]; yi[i * 2 + j] = bi[j];
-                        }
-                    if (tf) {
-                        int ab2[2], ba2[2], cd2[2];
-                        op_addsub<MODE, 2>(ab2, ar, ai, tab, QG_T_AB, false);  // (a+b), per A element
-                        op_addsub<MODE, 2>(ba2, ai, ar, tab, QG_T_BA, true);   // (b-a), per A element
-                        op_addsub<MODE, 2>(cd2, br, bi, tab, QG_T_CD, false);  // (c+d), per B element
-                        int ab[4], ba[4], cd[4], PA[4], PB[4], PC[4];
+                    if (tf) {   // planes {a+b, b, b-a} x {c, c+d, d}
+                        int ab[4], xi[4], ba[4], yr[4], cd[4], yi[4], PA[4], PB[4], PC[4];
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) { ab[i * 2 + j] = ab2[i]; ba[i * 2 + j] = ba2[i]; cd[i * 2 + j] = cd2[j]; }
+                            for (int j = 0; j < 2; ++j) {
+                                ab[i * 2 + j] = a0[i]; xi[i * 2 + j] = a1[i]; ba[i * 2 + j] = a2[i];
+                                yr[i * 2 + j] = b0[j]; cd[i * 2 + j] = b1[j]; yi[i * 2 + j] = b2[j];
+                            }
                         op_mul<MODE, 4>(PA, ab, yr, tab, QG_T_A);
                         op_mul<MODE, 4>(PB, cd, xi, tab, QG_T_B);
                         op_mul<MODE, 4>(PC, ba, yi, tab, QG_T_C);
                         op_addsub<MODE, 4>(v[0], PA, PB, tab, QG_T_RE, true);
                         op_addsub<MODE, 4>(v[1], PB, PC, tab, QG_T_IM, true);
                     } else {
+                        int xr[4], xi[4], yr[4], yi[4];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                xr[i * 2 + j] = a0[i]; xi[i * 2 + j] = a1[i];
+                                yr[i * 2 + j] = b0[j]; yi[i * 2 + j] = b1[j];
+                            }
                         int ac[4], bd[4], ad[4], bc[4];
                         op_mul<MODE, 4>(ac, xr, yr, tab, QG_B_AC);
                         op_mul<MODE, 4>(bd, xi, yi, tab, QG_B_BD);
