@@ -902,7 +902,7 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
         return QG_OK;
     case QG_KERNEL_TREE_CPLX_I32:
         QG_HIP(qg_launch_tree_cplx_fast(p->dev_table, p->an.tree.n_levels_k, (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : p->an.cplx_fixed_ok,
-                                        packedA, packedB, packedC, p->desc.M, p->desc.N,
+                                        p->desc.cmul == QG_CMUL_TF ? 1 : 0, packedA, packedB, packedC, p->desc.M, p->desc.N,
                                         p->pa.K_p, pcg.cbytes, st));
         return QG_OK;
     case QG_KERNEL_TREE_I64:

@@ -113,7 +113,7 @@ hipError_t qg_launch_gemv(const QTreeTable* dev_table, int n_levels, int b_is_bi
                           int64_t M, int64_t K, int cbytes, hipStream_t st, int wide = 0);   // wide: 64-bit tree values (4-byte elements)
 
 // exact tree evaluation, complex descriptors with K = 2^p >= 32 and 32-bit intermediates
-hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, int fixed_modes, const void* A, const void* B, void* C,
+hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, int fixed_modes, int tf, const void* A, const void* B, void* C,
                                     int64_t M, int64_t N, int64_t K, int cbytes, hipStream_t st);
 
 // linear class on int8 MFMA with LA x LB limbs

@@ -162,14 +162,16 @@ struct QTreeCplxArgs {
     int32_t cbytes;
 };
 
-template <int MAXL, int MODE>
+template <int MAXL, int MODE, bool TF>   // TF: TFComplexMul (3 multiplications), else BasicComplexMul (4)
 __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
 {
+    constexpr int NP = TF ? 3 : 2;   // LDS planes per operand
+    constexpr int RW = TF ? 2 : 4;   // leaves per LDS read: with three planes, 8-byte reads keep 24 registers of operands live where 16-byte reads keep 48
     // planes: BasicComplexMul {a, b} / {c, d}; TFComplexMul {a+b, b, b-a} / {c, c+d, d} — the three additions in front of
     // TF's multiplications depend on ONE operand element each, so they are made once per element while the tile is staged,
     // not once per output in the k loop (where they were 12 of 40 quantised values per k step and lane)
-    __shared__ __attribute__((aligned(16))) int sA[3][TMB][PITCH];
-    __shared__ __attribute__((aligned(16))) int sB[3][TNB][PITCH];
+    __shared__ __attribute__((aligned(16))) int sA[NP][TMB][PITCH];
+    __shared__ __attribute__((aligned(16))) int sB[NP][TNB][PITCH];
     const QTreeTable* __restrict__ tab = g.tab;
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
@@ -186,7 +188,6 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
     const int64_t gsz = (tiles_m - first_m) < GMT ? (tiles_m - first_m) : GMT;
     const int64_t m0 = (first_m + (bid % (GMT * tiles_n)) % gsz) * TMB, n0 = ((bid % (GMT * tiles_n)) / gsz) * TNB;
     const int nl = tab->n_levels_k;   // (a tree shorter than 5 levels is continued with identity levels: qg_plan.h)
-    const bool tf = tab->cmul == QG_CMUL_TF;
 
     int low[2][4][4];
     int up[2][MAXL - 4][4];
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
                 if (m0 + r < g.M) x[p] = *(const int4*)(g.A + ((int64_t)p * g.M + m0 + r) * g.K + k0 + q * 4);
                 if (n0 + r < g.N) y[p] = *(const int4*)(g.B + ((int64_t)p * g.N + n0 + r) * g.K + k0 + q * 4);
             }
-            if (tf) {
+            if constexpr (TF) {
                 const int ar4[4] = {x[0].x, x[0].y, x[0].z, x[0].w}, ai4[4] = {x[1].x, x[1].y, x[1].z, x[1].w};
                 const int br4[4] = {y[0].x, y[0].y, y[0].z, y[0].w}, bi4[4] = {y[1].x, y[1].y, y[1].z, y[1].w};
                 int ab[4], ba[4], cd[4];
@@ -234,35 +235,35 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
 #pragma unroll 1
         for (int kb = 0; kb < KC / 16; ++kb) {
 #pragma unroll
-            for (int kq = 0; kq < 8; ++kq) {   // two leaves per LDS read: 8-byte reads keep 24 registers of operands live, 16-byte reads 48
-                int2 a4[3][2], b4[3][2];  // [plane][row/col of the 2x2 block]
+            for (int kq = 0; kq < 16 / RW; ++kq) {
+                int a4[NP][2][RW], b4[NP][2][RW];  // [plane][row/col of the 2x2 block][leaf]
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int p = 0; p < NP; ++p)
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        if (p < 2 || tf) {
-                            a4[p][i] = *(const int2*)&sA[p][ty * 2 + i][kb * 16 + kq * 2];
-                            b4[p][i] = *(const int2*)&sB[p][tx + 16 * i][kb * 16 + kq * 2];   // columns tx and tx + 16: 16 consecutive rows per read group, no bank conflict (qg_tree_fast.hip)
+                        const int* pa = &sA[p][ty * 2 + i][kb * 16 + kq * RW];
+                        const int* pb = &sB[p][tx + 16 * i][kb * 16 + kq * RW];   // columns tx and tx + 16: 16 consecutive rows per read group, no bank conflict (qg_tree_fast.hip)
+                        if constexpr (RW == 4) {
+                            const int4 x = *(const int4*)pa, y = *(const int4*)pb;
+                            a4[p][i][0] = x.x; a4[p][i][1] = x.y; a4[p][i][2] = x.z; a4[p][i][3] = x.w;
+                            b4[p][i][0] = y.x; b4[p][i][1] = y.y; b4[p][i][2] = y.z; b4[p][i][3] = y.w;
                         } else {
-                            a4[p][i] = make_int2(0, 0);
-                            b4[p][i] = make_int2(0, 0);
+                            const int2 x = *(const int2*)pa, y = *(const int2*)pb;
+                            a4[p][i][0] = x.x; a4[p][i][1] = x.y;
+                            b4[p][i][0] = y.x; b4[p][i][1] = y.y;
                         }
                     }
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int kk = kq * 2 + e;
+                for (int e = 0; e < RW; ++e) {
+                    const int kk = kq * RW + e;   // compile-time leaf index inside the 16-leaf block
                     int a0[2], a1[2], a2[2], b0[2], b1[2], b2[2];  // planes of the A rows / B columns of this lane's 2 x 2 outputs
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        a0[i] = e == 0 ? a4[0][i].x : a4[0][i].y;
-                        a1[i] = e == 0 ? a4[1][i].x : a4[1][i].y;
-                        a2[i] = e == 0 ? a4[2][i].x : a4[2][i].y;
-                        b0[i] = e == 0 ? b4[0][i].x : b4[0][i].y;
-                        b1[i] = e == 0 ? b4[1][i].x : b4[1][i].y;
-                        b2[i] = e == 0 ? b4[2][i].x : b4[2][i].y;
+                        a0[i] = a4[0][i][e]; a1[i] = a4[1][i][e]; a2[i] = a4[NP - 1][i][e];
+                        b0[i] = b4[0][i][e]; b1[i] = b4[1][i][e]; b2[i] = b4[NP - 1][i][e];
                     }
                     // ---- one complex product per output (x = a+bi from A, y = c+di from B)
-                    if (tf) {   // planes {a+b, b, b-a} x {c, c+d, d}
+                    if constexpr (TF) {   // planes {a+b, b, b-a} x {c, c+d, d}
                         int ab[4], xi[4], ba[4], yr[4], cd[4], yi[4], PA[4], PB[4], PC[4];
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
 
 } // namespace
 
-hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, int fixed, const void* A, const void* B, void* C, int64_t M,
+hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, int fixed, int tf, const void* A, const void* B, void* C, int64_t M,
                                     int64_t N, int64_t K, int cbytes, hipStream_t st)
 {
     if (K % KC != 0 || n_levels < 5 || n_levels > 16) return hipErrorInvalidValue;
@@ -374,33 +375,33 @@ hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, i
     const int64_t blocks = ((M + TMB - 1) / TMB) * ((N + TNB - 1) / TNB);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
-    // fixed: 0 run-time modes; 1 fixed modes, steps read from the step table; 2 fixed modes, compact branch-free steps
-    if (fixed >= 8) {   // compact steps, branch-free kinds of the feature set fixed - 8 (1 R, 2 Z, 3 RZ, 4 W, 5 RW; the other one runs the full set)
-        const int feat = fixed - 8;
-#define QG_CPLX_FEAT(F)                                                                                                  \
-    do {                                                                                                                 \
-        if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12, 8 + F>), dim3((unsigned)blocks), dim3(256), 0, st, g);   \
-        else hipLaunchKernelGGL((k_tree_cplx<16, 8 + F>), dim3((unsigned)blocks), dim3(256), 0, st, g);                  \
+    // fixed: 0 run-time modes; 1 fixed modes, steps read from the step table; 2 fixed modes, compact branch-free steps; 3 compact
+    // steps with a branch on the rounding / overflow kind; 8 + f compact steps, branch-free kinds of the feature set f (1 R, 2 Z,
+    // 3 RZ, 4 W, 5 RW; the other ones run the full set)
+#define QG_CPLX_LAUNCH(MODE)                                                                                                      \
+    do {                                                                                                                          \
+        if (tf) {                                                                                                                 \
+            if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12, MODE, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);   \
+            else hipLaunchKernelGGL((k_tree_cplx<16, MODE, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);                  \
+        } else {                                                                                                                  \
+            if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12, MODE, false>), dim3((unsigned)blocks), dim3(256), 0, st, g);  \
+            else hipLaunchKernelGGL((k_tree_cplx<16, MODE, false>), dim3((unsigned)blocks), dim3(256), 0, st, g);                 \
+        }                                                                                                                         \
     } while (0)
-        if (feat == 1) QG_CPLX_FEAT(1);
-        else if (feat == 2) QG_CPLX_FEAT(2);
-        else if (feat == 3) QG_CPLX_FEAT(3);
-        else if (feat == 4) QG_CPLX_FEAT(4);
-        else if (feat == 5) QG_CPLX_FEAT(5);
-        else QG_CPLX_FEAT(7);
-#undef QG_CPLX_FEAT
-    } else if (fixed == 3) {   // compact steps with rounding / overflow kinds
-        if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12, 3>), dim3((unsigned)blocks), dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((k_tree_cplx<16, 3>), dim3((unsigned)blocks), dim3(256), 0, st, g);
-    } else if (fixed == 2) {
-        if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((k_tree_cplx<16, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g);
-    } else if (fixed) {
-        if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12, 1>), dim3((unsigned)blocks), dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((k_tree_cplx<16, 1>), dim3((unsigned)blocks), dim3(256), 0, st, g);
-    } else {
-        if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12, 0>), dim3((unsigned)blocks), dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((k_tree_cplx<16, 0>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    switch (fixed) {
+    case 0: QG_CPLX_LAUNCH(0); break;
+    case 1: QG_CPLX_LAUNCH(1); break;
+    case 2: QG_CPLX_LAUNCH(2); break;
+    case 3: QG_CPLX_LAUNCH(3); break;
+    case 9: QG_CPLX_LAUNCH(9); break;
+    case 10: QG_CPLX_LAUNCH(10); break;
+    case 11: QG_CPLX_LAUNCH(11); break;
+    case 12: QG_CPLX_LAUNCH(12); break;
+    case 13: QG_CPLX_LAUNCH(13); break;
+    case 14:
+    case 15: QG_CPLX_LAUNCH(15); break;
+    default: return hipErrorInvalidValue;
     }
+#undef QG_CPLX_LAUNCH
     return hipGetLastError();
 }
