@@ -209,6 +209,31 @@ __device__ __forceinline__ QFix fx_at(const QTreeTable* t, unsigned byte_off)
     f.ka = r[0]; f.kb = r[1]; f.t = r[2]; f.d = r[3]; f.lo = r[4]; f.hi = r[5]; f.skip = r[6]; f.ls = r[7];
     return f;
 }
+// two / three records whose steps follow each other: the loads go out back to back and share ONE wait (a step's first vector
+// instruction needs its record, so every separate load exposes a scalar-cache round trip that only other waves can cover)
+__device__ __forceinline__ QFix fx_of(const fx_v8i& r)
+{
+    QFix f;
+    f.ka = r[0]; f.kb = r[1]; f.t = r[2]; f.d = r[3]; f.lo = r[4]; f.hi = r[5]; f.skip = r[6]; f.ls = r[7];
+    return f;
+}
+__device__ __forceinline__ void fx_at2(const QTreeTable* t, unsigned o0, unsigned o1, QFix& f0, QFix& f1)
+{
+    fx_v8i r0, r1;
+    asm volatile("s_load_dwordx8 %0, %2, %3\n\ts_load_dwordx8 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r0), "=&s"(r1) : "s"(t), "s"(o0), "s"(o1));
+    f0 = fx_of(r0);
+    f1 = fx_of(r1);
+}
+__device__ __forceinline__ void fx_at3(const QTreeTable* t, unsigned o0, unsigned o1, unsigned o2, QFix& f0, QFix& f1, QFix& f2)
+{
+    fx_v8i r0, r1, r2;
+    asm volatile("s_load_dwordx8 %0, %3, %4\n\ts_load_dwordx8 %1, %3, %5\n\ts_load_dwordx8 %2, %3, %6\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(r0), "=&s"(r1), "=&s"(r2)
+                 : "s"(t), "s"(o0), "s"(o1), "s"(o2));
+    f0 = fx_of(r0);
+    f1 = fx_of(r1);
+    f2 = fx_of(r2);
+}
 #define FX_OFF_MUL(slot) ((unsigned)(offsetof(QTreeTable, fmul) + (slot) * sizeof(QFix)))
 #define FX_OFF_ADD(part, l) ((unsigned)(offsetof(QTreeTable, fadd) + ((part) * QG_MAX_LEVELS + (l)) * sizeof(QFix)))
 #define FX_OFF_CVT(part, l) ((unsigned)(offsetof(QTreeTable, fcvt) + ((part) * QG_MAX_LEVELS + (l)) * sizeof(QFix)))

@@ -149,8 +149,13 @@ __device__ __forceinline__ void op_mul(int (&out)[N], const int (&x)[N], const i
 template <int MODE, int N>
 __device__ __forceinline__ void op_node(int (&v)[N], const int (&x)[N], const QTreeTable* __restrict__ t, int part, int l)
 {
-    if constexpr (MODE >= 2) fx_node<(MODE >= 8 ? MODE : MODE == 3), N>(v, x, fx_at(t, FX_OFF_ADD(part, l)), fx_at(t, FX_OFF_CVT(part, l)));
-    else node_n<MODE == 1, N>(v, x, t, part, l);
+    if constexpr (MODE >= 2) {
+        QFix fa, fc;
+        fx_at2(t, FX_OFF_ADD(part, l), FX_OFF_CVT(part, l), fa, fc);
+        fx_node<(MODE >= 8 ? MODE : MODE == 3), N>(v, x, fa, fc);
+    } else {
+        node_n<MODE == 1, N>(v, x, t, part, l);
+    }
 }
 
 struct QTreeCplxArgs {
@@ -272,11 +277,23 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
                                 ab[i * 2 + j] = a0[i]; xi[i * 2 + j] = a1[i]; ba[i * 2 + j] = a2[i];
                                 yr[i * 2 + j] = b0[j]; cd[i * 2 + j] = b1[j]; yi[i * 2 + j] = b2[j];
                             }
-                        op_mul<MODE, 4>(PA, ab, yr, tab, QG_T_A);
-                        op_mul<MODE, 4>(PB, cd, xi, tab, QG_T_B);
-                        op_mul<MODE, 4>(PC, ba, yi, tab, QG_T_C);
-                        op_addsub<MODE, 4>(v[0], PA, PB, tab, QG_T_RE, true);
-                        op_addsub<MODE, 4>(v[1], PB, PC, tab, QG_T_IM, true);
+                        if constexpr (MODE >= 2) {   // records of steps that follow each other share a wait (qg_fix.h)
+                            constexpr int KIND = MODE >= 8 ? MODE : MODE == 3;
+                            QFix fA, fB, fC, fR, fI;
+                            fx_at3(tab, FX_OFF_MUL(QG_T_A), FX_OFF_MUL(QG_T_B), FX_OFF_MUL(QG_T_C), fA, fB, fC);
+                            fx_mul<KIND, 4>(PA, ab, yr, fA);
+                            fx_mul<KIND, 4>(PB, cd, xi, fB);
+                            fx_mul<KIND, 4>(PC, ba, yi, fC);
+                            fx_at2(tab, FX_OFF_MUL(QG_T_RE), FX_OFF_MUL(QG_T_IM), fR, fI);
+                            fx_addsub<KIND, 4>(v[0], PA, PB, fR, true);
+                            fx_addsub<KIND, 4>(v[1], PB, PC, fI, true);
+                        } else {
+                            op_mul<MODE, 4>(PA, ab, yr, tab, QG_T_A);
+                            op_mul<MODE, 4>(PB, cd, xi, tab, QG_T_B);
+                            op_mul<MODE, 4>(PC, ba, yi, tab, QG_T_C);
+                            op_addsub<MODE, 4>(v[0], PA, PB, tab, QG_T_RE, true);
+                            op_addsub<MODE, 4>(v[1], PB, PC, tab, QG_T_IM, true);
+                        }
                     } else {
                         int xr[4], xi[4], yr[4], yi[4];
 #pragma unroll
@@ -287,12 +304,26 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
                                 yr[i * 2 + j] = b0[j]; yi[i * 2 + j] = b1[j];
                             }
                         int ac[4], bd[4], ad[4], bc[4];
-                        op_mul<MODE, 4>(ac, xr, yr, tab, QG_B_AC);
-                        op_mul<MODE, 4>(bd, xi, yi, tab, QG_B_BD);
-                        op_mul<MODE, 4>(ad, xr, yi, tab, QG_B_AD);
-                        op_mul<MODE, 4>(bc, xi, yr, tab, QG_B_BC);
-                        op_addsub<MODE, 4>(v[0], ac, bd, tab, QG_B_RE, true);
-                        op_addsub<MODE, 4>(v[1], ad, bc, tab, QG_B_IM, false);
+                        if constexpr (MODE >= 2) {
+                            constexpr int KIND = MODE >= 8 ? MODE : MODE == 3;
+                            QFix f0, f1, f2, f3;
+                            fx_at2(tab, FX_OFF_MUL(QG_B_AC), FX_OFF_MUL(QG_B_BD), f0, f1);
+                            fx_mul<KIND, 4>(ac, xr, yr, f0);
+                            fx_mul<KIND, 4>(bd, xi, yi, f1);
+                            fx_at2(tab, FX_OFF_MUL(QG_B_AD), FX_OFF_MUL(QG_B_BC), f2, f3);
+                            fx_mul<KIND, 4>(ad, xr, yi, f2);
+                            fx_mul<KIND, 4>(bc, xi, yr, f3);
+                            fx_at2(tab, FX_OFF_MUL(QG_B_RE), FX_OFF_MUL(QG_B_IM), f0, f1);
+                            fx_addsub<KIND, 4>(v[0], ac, bd, f0, true);
+                            fx_addsub<KIND, 4>(v[1], ad, bc, f1, false);
+                        } else {
+                            op_mul<MODE, 4>(ac, xr, yr, tab, QG_B_AC);
+                            op_mul<MODE, 4>(bd, xi, yi, tab, QG_B_BD);
+                            op_mul<MODE, 4>(ad, xr, yi, tab, QG_B_AD);
+                            op_mul<MODE, 4>(bc, xi, yr, tab, QG_B_BC);
+                            op_addsub<MODE, 4>(v[0], ac, bd, tab, QG_B_RE, true);
+                            op_addsub<MODE, 4>(v[1], ad, bc, tab, QG_B_IM, false);
+                        }
                     }
                     // ---- lower four levels (compile-time leaf index)
 #pragma unroll
