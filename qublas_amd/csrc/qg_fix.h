@@ -234,6 +234,17 @@ __device__ __forceinline__ void fx_at3(const QTreeTable* t, unsigned o0, unsigne
     f1 = fx_of(r1);
     f2 = fx_of(r2);
 }
+__device__ __forceinline__ void fx_at4(const QTreeTable* t, unsigned o0, unsigned o1, unsigned o2, unsigned o3, QFix& f0, QFix& f1, QFix& f2, QFix& f3)
+{
+    fx_v8i r0, r1, r2, r3;
+    asm volatile("s_load_dwordx8 %0, %4, %5\n\ts_load_dwordx8 %1, %4, %6\n\ts_load_dwordx8 %2, %4, %7\n\ts_load_dwordx8 %3, %4, %8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(r0), "=&s"(r1), "=&s"(r2), "=&s"(r3)
+                 : "s"(t), "s"(o0), "s"(o1), "s"(o2), "s"(o3));
+    f0 = fx_of(r0);
+    f1 = fx_of(r1);
+    f2 = fx_of(r2);
+    f3 = fx_of(r3);
+}
 #define FX_OFF_MUL(slot) ((unsigned)(offsetof(QTreeTable, fmul) + (slot) * sizeof(QFix)))
 #define FX_OFF_ADD(part, l) ((unsigned)(offsetof(QTreeTable, fadd) + ((part) * QG_MAX_LEVELS + (l)) * sizeof(QFix)))
 #define FX_OFF_CVT(part, l) ((unsigned)(offsetof(QTreeTable, fcvt) + ((part) * QG_MAX_LEVELS + (l)) * sizeof(QFix)))

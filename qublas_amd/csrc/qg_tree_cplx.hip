@@ -158,6 +158,21 @@ __device__ __forceinline__ void op_node(int (&v)[N], const int (&x)[N], const QT
     }
 }
 
+// level l's node of BOTH parts: their four records in one wait
+template <int MODE, int N>
+__device__ __forceinline__ void op_node2(int (&v0)[N], int (&v1)[N], const int (&x0)[N], const int (&x1)[N], const QTreeTable* __restrict__ t, int l)
+{
+    if constexpr (MODE >= 2) {
+        QFix fa0, fc0, fa1, fc1;
+        fx_at4(t, FX_OFF_ADD(0, l), FX_OFF_CVT(0, l), FX_OFF_ADD(1, l), FX_OFF_CVT(1, l), fa0, fc0, fa1, fc1);
+        fx_node<(MODE >= 8 ? MODE : MODE == 3), N>(v0, x0, fa0, fc0);
+        fx_node<(MODE >= 8 ? MODE : MODE == 3), N>(v1, x1, fa1, fc1);
+    } else {
+        node_n<MODE == 1, N>(v0, x0, t, 0, l);
+        node_n<MODE == 1, N>(v1, x1, t, 1, l);
+    }
+}
+
 struct QTreeCplxArgs {
     const QTreeTable* tab;
     const int32_t* A;  // [2][M][K]
@@ -326,29 +341,19 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
                         }
                     }
                     // ---- lower four levels (compile-time leaf index)
+                    {
+                        bool parked_low = false;
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        if ((kk & 1) == 0) {
+                        for (int l = 0; l < 4; ++l) {
+                            if (!parked_low) {
+                                if (((kk >> l) & 1) == 0) {
 #pragma unroll
-                            for (int o = 0; o < 4; ++o) low[p][0][o] = v[p][o];
-                        } else {
-                            op_node<MODE, 4>(v[p], low[p][0], tab, p, 0);
-                            if ((kk & 2) == 0) {
+                                    for (int p = 0; p < 2; ++p)
 #pragma unroll
-                                for (int o = 0; o < 4; ++o) low[p][1][o] = v[p][o];
-                            } else {
-                                op_node<MODE, 4>(v[p], low[p][1], tab, p, 1);
-                                if ((kk & 4) == 0) {
-#pragma unroll
-                                    for (int o = 0; o < 4; ++o) low[p][2][o] = v[p][o];
+                                        for (int o = 0; o < 4; ++o) low[p][l][o] = v[p][o];
+                                    parked_low = true;
                                 } else {
-                                    op_node<MODE, 4>(v[p], low[p][2], tab, p, 2);
-                                    if ((kk & 8) == 0) {
-#pragma unroll
-                                        for (int o = 0; o < 4; ++o) low[p][3][o] = v[p][o];
-                                    } else {
-                                        op_node<MODE, 4>(v[p], low[p][3], tab, p, 3);
-                                    }
+                                    op_node2<MODE, 4>(v[0], v[1], low[0][l], low[1][l], tab, l);
                                 }
                             }
                         }
@@ -367,8 +372,7 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
                             for (int o = 0; o < 4; ++o) up[p][u][o] = v[p][o];
                         parked = true;
                     } else {
-                        op_node<MODE, 4>(v[0], up[0][u], tab, 0, 4 + u);
-                        op_node<MODE, 4>(v[1], up[1][u], tab, 1, 4 + u);
+                        op_node2<MODE, 4>(v[0], v[1], up[0][u], up[1][u], tab, 4 + u);
                     }
                 }
             }
