@@ -245,6 +245,20 @@ __device__ __forceinline__ void fx_at4(const QTreeTable* t, unsigned o0, unsigne
     f2 = fx_of(r2);
     f3 = fx_of(r3);
 }
+__device__ __forceinline__ void fx_at5(const QTreeTable* t, unsigned o0, unsigned o1, unsigned o2, unsigned o3, unsigned o4, QFix& f0, QFix& f1, QFix& f2, QFix& f3,
+                                       QFix& f4)
+{
+    fx_v8i r0, r1, r2, r3, r4;
+    asm volatile("s_load_dwordx8 %0, %5, %6\n\ts_load_dwordx8 %1, %5, %7\n\ts_load_dwordx8 %2, %5, %8\n\ts_load_dwordx8 %3, %5, %9\n\ts_load_dwordx8 %4, %5, %10\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(r0), "=&s"(r1), "=&s"(r2), "=&s"(r3), "=&s"(r4)
+                 : "s"(t), "s"(o0), "s"(o1), "s"(o2), "s"(o3), "s"(o4));
+    f0 = fx_of(r0);
+    f1 = fx_of(r1);
+    f2 = fx_of(r2);
+    f3 = fx_of(r3);
+    f4 = fx_of(r4);
+}
 #define FX_OFF_MUL(slot) ((unsigned)(offsetof(QTreeTable, fmul) + (slot) * sizeof(QFix)))
 #define FX_OFF_ADD(part, l) ((unsigned)(offsetof(QTreeTable, fadd) + ((part) * QG_MAX_LEVELS + (l)) * sizeof(QFix)))
 #define FX_OFF_CVT(part, l) ((unsigned)(offsetof(QTreeTable, fcvt) + ((part) * QG_MAX_LEVELS + (l)) * sizeof(QFix)))

@@ -295,11 +295,10 @@ __global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
                         if constexpr (MODE >= 2) {   // records of steps that follow each other share a wait (qg_fix.h)
                             constexpr int KIND = MODE >= 8 ? MODE : MODE == 3;
                             QFix fA, fB, fC, fR, fI;
-                            fx_at3(tab, FX_OFF_MUL(QG_T_A), FX_OFF_MUL(QG_T_B), FX_OFF_MUL(QG_T_C), fA, fB, fC);
+                            fx_at5(tab, FX_OFF_MUL(QG_T_A), FX_OFF_MUL(QG_T_B), FX_OFF_MUL(QG_T_C), FX_OFF_MUL(QG_T_RE), FX_OFF_MUL(QG_T_IM), fA, fB, fC, fR, fI);
                             fx_mul<KIND, 4>(PA, ab, yr, fA);
                             fx_mul<KIND, 4>(PB, cd, xi, fB);
                             fx_mul<KIND, 4>(PC, ba, yi, fC);
-                            fx_at2(tab, FX_OFF_MUL(QG_T_RE), FX_OFF_MUL(QG_T_IM), fR, fI);
                             fx_addsub<KIND, 4>(v[0], PA, PB, fR, true);
                             fx_addsub<KIND, 4>(v[1], PB, PC, fI, true);
                         } else {
