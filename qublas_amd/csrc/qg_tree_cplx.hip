@@ -11,9 +11,11 @@
 //
 // Mapping: as qg_tree_fast.hip — each lane owns a 2x2 block of complex outputs, the tree is a
 // register-resident binary counter (levels 0-3 unrolled over 16 leaves, upper levels statically
-// indexed), per-node modes are wave-uniform runtime values.  The operand-only sums (a+b), (b-a)
-// depend on the A element alone and (c+d) on the B element alone, so they are formed once per
-// staged element pair, not once per output.
+// indexed).  The multiplier is a template parameter.  TF's operand-only sums (a+b), (b-a) depend on the
+// A element alone and (c+d) on the B element alone: they are formed ONCE per element while the tile is
+// staged (LDS planes {a+b, b, b-a} / {c, c+d, d}), not in the k loop.  The step forms (MODE) are described
+// above op_addsub; compact step records are fetched with one s_load_dwordx8 each, the records of steps that
+// follow each other under one wait (qg_fix.h, fx_at2 ... fx_at5).
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
