@@ -184,8 +184,13 @@ struct QTreeCplxArgs {
     int32_t cbytes;
 };
 
+// Occupancy: the compact forms are bound by how well the other waves cover a wave's scalar-load round trips, so they are compiled
+// for one wave per SIMD more than their natural register count gives (4 at MAXL 12, 3 at MAXL 16; 10-20 spilled registers outside
+// the hot values) — except Basic's forms whose spill count would be 30-40 (the branching kinds form and the SAT::ZERO feature).
+template <int MODE, bool TF>
+constexpr bool cplx_dense_waves = MODE >= 2 && (TF || (MODE != 3 && !(MODE >= 8 && ((MODE - 8) & 2))));
 template <int MAXL, int MODE, bool TF>   // TF: TFComplexMul (3 multiplications), else BasicComplexMul (4)
-__global__ __launch_bounds__(256) void k_tree_cplx(QTreeCplxArgs g)
+__global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 4 : 3) : 1)) void k_tree_cplx(QTreeCplxArgs g)
 {
     constexpr int NP = TF ? 3 : 2;   // LDS planes per operand
     constexpr int RW = TF ? 2 : 4;   // leaves per LDS read: with three planes, 8-byte reads keep 24 registers of operands live where 16-byte reads keep 48
