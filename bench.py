@@ -45,7 +45,7 @@ INT8_DENSE_PEAK_OPS = 5.0e15   # MI355X dense int8 MFMA, /opt/skills/guides/MI35
 VALU_LANE_OPS_PEAK = 256 * 4 * 64 * 2.4e9 / 4.3
 # vector-ALU instructions per MAC of the tree kernels, from rocprofv3 SQ_INSTS_VALU (profiles/: r03d_c3T)
 # (c2T / c3Td: nodes and products that saturate (SAT::TCPL) clamp with one v_med3_i32: 5.3, profiles/r04c_c2T_pmc.json)
-VALU_PER_MAC = {"c3T": 6.7, "c2T": 5.3, "c3Td": 5.3, "c5TF": 24.77 / 3.0, "c5B": 27.37 / 4.0}   # per real MAC (complex TF: 24.8 per complex MAC = 3 real MACs, Basic 27.4 = 4 real MACs: profiles/r04i_c5TF_pmc.json, r04i_c5B_pmc.json; TF 51 with run-time modes, 30.9 before the additions moved to the tile staging)
+VALU_PER_MAC = {"c3T": 6.7, "c2T": 5.3, "c3Td": 5.3, "c5TF": 24.77 / 3.0, "c5B": 27.37 / 4.0}   # per real MAC (complex TF: 24.8 per complex MAC = 3 real MACs, Basic 27.4 = 4 real MACs: profiles/r04k_c5TF_pmc.json, r04k_c5B_pmc.json; TF 51 with run-time modes, 30.9 before the additions moved to the tile staging)
 HBM_PEAK = 8.0e12
 
 
