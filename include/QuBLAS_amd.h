@@ -690,7 +690,16 @@ auto Qreduce(const Qu_s<dim<D...>, Elem>& v)
     using lv_t = std::conditional_t<(smgn && std::is_same_v<list, TypeList<>>), TypeList<Elem>, list>;
     Qu_s<dim<1, 1>, std::conditional_t<(smgn && len <= 1), leaf_t, res_t>> c;
     [&]<class... Ls>(TypeList<Ls...>) {
-        Qgemul<QgemulAddArgs<Ls...>, QgemulMulArgs<leaf_t>, QgemulTransposedA<true>>(c, a, ones);
+        qgemul_desc d = Qgemul_lower<QgemulAddArgs<Ls...>, QgemulMulArgs<leaf_t>, QgemulTransposedA<true>>(c, a, ones);
+        // level 0's type IS the element type: the reference copies an odd leftover into the level-0 buffer unconverted
+        // (a same-type copy, QuBLAS.h:4977-4980), so the raw minimum survives it (include/qgemul.h, QG_DESC_LEFTOVER0_COPY)
+        if constexpr (smgn && sizeof...(Ls) > 0)
+            if (levels_of<TypeList<Ls...>>::value[0][0] == Elem::fmt) d.flags |= QG_DESC_LEFTOVER0_COPY;
+        qgemul_opts opts{};
+        opts.device = -1;
+        opts.flags = QgemulRunFlags();
+        const int st = qgemul_run(&d, c.data.data(), a.data.data(), ones.data.data(), &opts);
+        if (st != QG_OK) throw std::runtime_error(std::string("Qreduce: ") + qgemul_strerror(st));
     }(lv_t{});
     res_t r;
     r.data = typename res_t::raw_t(c.data[0].data);

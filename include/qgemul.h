@@ -94,7 +94,7 @@ typedef struct qfmt {
  *
  *   p[k]   = product(A'[i,k], B[k,j])                  mul[] slots above
  *   level l: next[t] = cvt_{level[l]}( add_{level_add[l]}(cur[2t], cur[2t+1]) ),
- *            odd leftover next[last] = cvt_{level[l]}(cur[len-1])        (QuBLAS.h:4973-4980)
+ *            odd leftover next[last] = cvt_{level[l]}(cur[len-1])        (QuBLAS.h:4973-4980; flags: QG_DESC_LEFTOVER0_COPY)
  *   C[i,j] = cvt_{c}( root )                                            (QuBLAS.h:2398-2411)
  *
  * where op_{f}(x) means: align/compute exactly, round to f.F with f.Q (fracConvert,
@@ -105,12 +105,20 @@ typedef struct qfmt {
  * level_add[l] is the default merge of the incoming format and level[l] is the level buffer's
  * type (QuBLAS.h:4966).  Index [0] = real part, [1] = imaginary part.
  */
+/* qgemul_desc.flags
+ * QG_DESC_LEFTOVER0_COPY: the odd leftover of tree level 0 is copied into the level buffer UNCONVERTED.  In the reference that
+ * copy (`res[last] = quants[len-1]`, QuBLAS.h:4977-4980) is the identity whenever level 0's type is the element type itself.
+ * The Qreduce lowering of a signed SAT::SMGN element type names the element's SAT::TCPL twin as the leaf format (so that the
+ * raw minimum -2^W, which Qu::fill() can produce, reaches the adders as it is); leaf and level 0 then differ in the descriptor
+ * although they are one type in the reference, and this flag restores the identity copy.  Only odd K is affected. */
+enum { QG_DESC_LEFTOVER0_COPY = 1u };
+
 typedef struct qgemul_desc {
     uint32_t abi;       /* QGEMUL_ABI_VERSION */
     uint8_t transA;     /* QgemulTransposedA<true>: A is declared dim<K,M>, A'[i,k] = A[k,i] */
     uint8_t is_complex; /* operands are Qcomplex */
     uint8_t cmul;       /* QG_CMUL_* (QG_CMUL_NONE for real) */
-    uint8_t reserved;
+    uint8_t flags;      /* QG_DESC_* (0 for every Qgemul; the Qreduce lowering may set QG_DESC_LEFTOVER0_COPY) */
     int64_t M, N, K;    /* C is M x N, reduction length K (runtime values, never template depth) */
     qfmt a[2], b[2], c[2];
     qfmt mul[8];

@@ -158,11 +158,12 @@ static void qo_product(const qgemul_desc* d, const qi x[2], const qi y[2], qi ou
  * Reducer::reduce_impl (vector overload), QuBLAS.h:4960-4984, one part of the value.
  * buf holds len values in format `fin`; returns the root and writes its format to *fout.
  * Level l: pairs are added into level_add[l] then stored into the level buffer of type level[l]
- * (:4966, :4974); an odd leftover is copied with the converting constructor (:4977-4980);
+ * (:4966, :4974); an odd leftover is copied with the converting constructor (:4977-4980; the identity for equal types,
+ * which the Qreduce lowering of a signed SAT::SMGN element type requests for level 0 with QG_DESC_LEFTOVER0_COPY);
  * a length-1 input is returned unconverted (:4967-4970).
  */
 static qi qo_tree(qi* buf, int64_t len, qfmt fin, const qfmt* level_add, const qfmt* level,
-                  qfmt* fout)
+                  qfmt* fout, int copy0)
 {
     int l = 0;
     qfmt cur = fin;
@@ -171,7 +172,8 @@ static qi qo_tree(qi* buf, int64_t len, qfmt fin, const qfmt* level_add, const q
         int64_t half = len / 2;
         for (int64_t t = 0; t < half; ++t)
             buf[t] = qo_cvt(qo_addsub(buf[2 * t], cur, buf[2 * t + 1], cur, fa, 0), fa, fl);
-        if (len & 1) buf[half] = qo_cvt(buf[len - 1], cur, fl);
+        /* copy0 (QG_DESC_LEFTOVER0_COPY): level 0's type IS the element type in the reference, the copy is the identity */
+        if (len & 1) buf[half] = (l == 0 && copy0) ? buf[len - 1] : qo_cvt(buf[len - 1], cur, fl);
         len = (len + 1) / 2;
         cur = fl;
         ++l;
@@ -271,7 +273,7 @@ static void* qo_worker(void* arg)
             char* pc = j->C + (row + col * j->ldc) * LC.size;
             for (int q = 0; q < parts; ++q) {
                 qfmt fr;
-                qi r = qo_tree(buf[q], K, qo_prod_fmt(d, q), d->level_add[q], d->level[q], &fr);
+                qi r = qo_tree(buf[q], K, qo_prod_fmt(d, q), d->level_add[q], d->level[q], &fr, d->flags & QG_DESC_LEFTOVER0_COPY);
                 qo_store(pc + LC.off[q], LC.sb[q], qo_cvt(r, fr, d->c[q]));
             }
         }
@@ -375,7 +377,7 @@ int64_t qoracle_reduce(const int64_t* v, int64_t len, qfmt fin, const qfmt* leve
     for (int l = 0; l < QG_MAX_LEVELS; ++l) lv[l] = nlev ? level[l < nlev ? l : nlev - 1] : fin;
     for (int64_t t = 0; t < len; ++t) buf[t] = v[t];
     qfmt fo;
-    qi r = qo_tree(buf, len, fin, lv, lv, &fo);
+    qi r = qo_tree(buf, len, fin, lv, lv, &fo, 0);
     free(buf);
     return (int64_t)r;
 }

@@ -144,6 +144,28 @@ static void reduce_min_table(FILE* out, const char* name)
     std::fprintf(out, "]}\n");
 }
 
+// ... with the raw minimum as the LAST element: for odd LEN it is the odd leftover of level 0, which the reference copies into
+// the level-0 buffer (a same-type copy when level 0's type is the element type: the raw minimum survives it)
+template <class T, size_t LEN, class... Levels>
+static void reduce_min_last_table(FILE* out, const char* name)
+{
+    std::string lv = "[";
+    ((lv += (lv.size() > 1 ? "," : "") + fmt_json<Levels>()), ...);
+    lv += "]";
+    constexpr int64_t rmin = T::isS ? -(int64_t(1) << (T::intB + T::fracB)) : 0;
+    std::fprintf(out, "{\"kind\":\"reduce\",\"name\":\"%s\",\"fin\":%s,\"levels\":%s,\"len\":%zu,\"dist\":1,\"seeds\":[1,2,3,4,5,6,7,8],\"min_at\":[%zu],\"y\":[", name,
+                 fmt_json<T>().c_str(), lv.c_str(), LEN, LEN - 1);
+    for (uint64_t seed = 1; seed <= 8; ++seed) {
+        Qu_s<dim<LEN>, T> v;
+        for (size_t i = 0; i < LEN; ++i) v[i].data.data = synth<T>(seed, 1, i, 0);   // small values: the sums stay in range
+        v[LEN - 1].data.data = rmin;
+        auto r = Qreduce<Levels...>(v);
+        using R = decltype(r);
+        std::fprintf(out, "%s[%lld,%s]", seed > 1 ? "," : "", (long long)r.data.data, fmt_json<R>().c_str());
+    }
+    std::fprintf(out, "]}\n");
+}
+
 // Qu_s(double): loadFromDouble into a 2400-bit buffer, then the type's own fracConvert / intConvert
 // (QuBLAS.h:2387-2393, :663-749).  Doubles are printed as hex-float so the table is exact.
 template <class T>
@@ -308,6 +330,32 @@ int main(int argc, char** argv)
         reduce_min_table<sm, 1000, lsm, lw>(out, "smgn_min_len1000_lsm_lw");
         reduce_min_table<st, 64>(out, "tcpl_min_len64_default");
         reduce_min_table<sz, 64, lz>(out, "zero_min_len64_lz");
+        break;
+    }
+    case 8: {
+        // the raw minimum of a signed SAT::SMGN element type as the odd leftover of level 0
+        using sm = Qu<intBits<3>, fracBits<4>, OfMode<SAT::SMGN>>;
+        using st = Qu<intBits<3>, fracBits<4>>;
+        using lw = Qu<intBits<9>, fracBits<4>>;
+        using lsm = Qu<intBits<5>, fracBits<3>, QuMode<RND::POS_INF>, OfMode<SAT::SMGN>>;
+        using lsw = Qu<intBits<6>, fracBits<4>, OfMode<SAT::SMGN>>;
+        reduce_min_last_table<sm, 1>(out, "smgn_last_len1_default");
+        reduce_min_last_table<sm, 3>(out, "smgn_last_len3_default");
+        reduce_min_last_table<sm, 5>(out, "smgn_last_len5_default");
+        reduce_min_last_table<sm, 7>(out, "smgn_last_len7_default");
+        reduce_min_last_table<sm, 9>(out, "smgn_last_len9_default");
+        reduce_min_last_table<sm, 17>(out, "smgn_last_len17_default");
+        reduce_min_last_table<sm, 33>(out, "smgn_last_len33_default");
+        reduce_min_last_table<sm, 65>(out, "smgn_last_len65_default");
+        reduce_min_last_table<sm, 999>(out, "smgn_last_len999_default");
+        reduce_min_last_table<sm, 5, sm>(out, "smgn_last_len5_sm");
+        reduce_min_last_table<sm, 9, sm, lw>(out, "smgn_last_len9_sm_lw");
+        reduce_min_last_table<sm, 5, lw>(out, "smgn_last_len5_lw");
+        reduce_min_last_table<sm, 5, lsm, lw>(out, "smgn_last_len5_lsm_lw");
+        reduce_min_last_table<sm, 17, lsw>(out, "smgn_last_len17_lsw");
+        reduce_min_last_table<sm, 6>(out, "smgn_last_len6_default");
+        reduce_min_last_table<sm, 10>(out, "smgn_last_len10_default");
+        reduce_min_last_table<st, 5>(out, "tcpl_last_len5_default");
         break;
     }
     default:

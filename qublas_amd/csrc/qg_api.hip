@@ -1039,8 +1039,9 @@ int qgemul_run(const qgemul_desc* d, void* C, const void* A, const void* B, cons
 // ---- the one-shot call keeps a per-thread cache: context, the plan of the last descriptor, grow-only device buffers ----
 // The reference is a synchronous library that user code calls in loops; creating a stream, a plan table and eight device
 // allocations per call cost 2.9 ms for the README's 4x4x4 example (tools/measure_run_latency.py).  The cache belongs to
-// the calling thread and is never touched by another one; qgemul_run_release() frees it.  (Nothing is freed at thread or
-// process exit: HIP may already be shut down when thread-local destructors run.)
+// the calling thread and is never touched by another one; qgemul_run_release() frees it, and so does the end of the thread
+// (RunCacheReaper below) — except once the process is exiting: a worker thread that is still alive or detached then may run its
+// thread-local destructors after HIP has been torn down, so the reaper only forgets its pointers (g_shutting_down).
 namespace {
 struct RunCache {
     qgemul_ctx* ctx = nullptr;
@@ -1062,17 +1063,30 @@ thread_local RunCache g_shard[QG_MAX_SHARDS];
 thread_local hipEvent_t g_shard_ev[QG_MAX_SHARDS] = {};
 // What a thread has cached is released when the thread ends (worker threads that call Qgemul<>() and exit must not leak a stream
 // and device buffers each).  For the main thread this runs inside exit() BEFORE any static object — HIP's included — is torn down.
+std::atomic<bool> g_shutting_down{false};
+void forget_caches();
 struct RunCacheReaper {
     bool armed = false;
-    ~RunCacheReaper() { if (armed) qgemul_run_release(); }
+    ~RunCacheReaper()
+    {
+        if (!armed) return;
+        int n = 0;
+        // exit() has begun (atexit handlers run before static destruction, HIP's included) or the runtime no longer answers:
+        // no HIP call from here, the driver reclaims the memory with the process
+        if (g_shutting_down.load(std::memory_order_acquire) || hipGetDeviceCount(&n) != hipSuccess) { forget_caches(); return; }
+        qgemul_run_release();
+    }
 };
 thread_local RunCacheReaper g_reaper;
+struct ShutdownHook {
+    ShutdownHook() { atexit([] { g_shutting_down.store(true, std::memory_order_release); }); }
+};
 
 // descriptors are compared field by field: padding and reserved bytes of a caller's struct are not part of its meaning, and a
 // descriptor that was not built with `{}` must still hit the cache
 bool same_desc(const qgemul_desc& x, const qgemul_desc& y)
 {
-    if (x.abi != y.abi || x.transA != y.transA || x.is_complex != y.is_complex || x.cmul != y.cmul || x.M != y.M || x.N != y.N ||
+    if (x.abi != y.abi || x.transA != y.transA || x.is_complex != y.is_complex || x.cmul != y.cmul || x.flags != y.flags || x.M != y.M || x.N != y.N ||
         x.K != y.K || x.n_levels != y.n_levels || x.n_levels > QG_MAX_LEVELS)
         return false;
     for (int p = 0; p < 2; ++p) {
@@ -1128,6 +1142,20 @@ static void release_cache(RunCache& c)
     c.device = -2;
 }
 
+namespace {
+void forget_caches()
+{
+    auto forget = [](RunCache& c) {
+        c.plan = nullptr;
+        c.ctx = nullptr;
+        c.device = -2;
+        for (int i = 0; i < RunCache::NBUF; ++i) { c.buf[i] = nullptr; c.cap[i] = 0; }
+    };
+    forget(g_run);
+    for (int i = 0; i < QG_MAX_SHARDS; ++i) { g_shard_ev[i] = nullptr; forget(g_shard[i]); }
+}
+} // namespace
+
 void qgemul_run_release(void)
 {
     release_cache(g_run);
@@ -1163,6 +1191,7 @@ static int run_view(const qgemul_desc* d, const EpView* ev, void* C, const void*
     opts.device = -1;
     if (o) opts = *o;
     g_reaper.armed = true;
+    static ShutdownHook hook;   // (installed once, at the first call: see RunCacheReaper)
     RunCache& c = g_run;
     if (opts.device < 0 && c.ctx) {   // "current device": follow hipSetDevice calls the caller made between two calls
         int cur = c.device;
@@ -1194,7 +1223,7 @@ static int run_view(const qgemul_desc* d, const EpView* ev, void* C, const void*
     if (d->M == 0 || d->N == 0) return QG_OK;
     int st = QG_OK;
     if (!c.ctx || (opts.device >= 0 && opts.device != c.device)) {
-        qgemul_run_release();
+        release_cache(c);   // (only the single-device cache: the sharded entry's contexts and plans stay warm)
         st = qgemul_ctx_create(opts.device, &c.ctx);
         if (st != QG_OK) { c.ctx = nullptr; return st; }
         c.device = c.ctx->device;
@@ -1294,6 +1323,7 @@ int qgemul_run_sharded(const qgemul_desc* d, void* C, const void* A, const void*
 {
     if (!d || !C || !A || !B || !devices || n < 1 || n > QG_MAX_SHARDS) return QG_EINVAL;
     g_reaper.armed = true;
+    static ShutdownHook hook;
     qgemul_opts opts;
     memset(&opts, 0, sizeof opts);
     if (o) opts = *o;

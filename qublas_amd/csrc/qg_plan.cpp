@@ -95,9 +95,8 @@ Rng through(Ctx& c, Rng in, int fromF, qfmt to, bool identity)
     // whose data is -1 (QuBLAS.h:361-377), so `val & mask` (:2328-2331) masks nothing and the value is stored unwrapped in
     // the 33-bit storage (-7 -> -7, 2^33 + 5 -> 2^33 + 5; pinned by tests/golden ref_scalar cvt tables).  An artefact of
     // the same family as the d = 32 RND case below: rejected, not imitated.  (Signed, 32 storage bits: the reference's
-    // int32 storage wraps by itself and agrees with the arithmetic definition.)
-    if (to.O == QG_WRP_TCPL && !to.S && (int)to.I + (int)to.F == 32)
-        c.fail(QG_EUNSUPPORTED, "unsigned WRP::TCPL into exactly 32 bits: reference result is an ArbiInt<32>::allOnes artefact");
+    // int32 storage wraps by itself and agrees with the arithmetic definition.)  Checked BELOW, only where a value can actually
+    // leave the range: an in-range value is untouched by the reference's `val & allOnes` too (uint32-style formats run).
     int d = fromF - (int)to.F;
     Rng r = in;
     if (d <= 0) {
@@ -118,6 +117,8 @@ Rng through(Ctx& c, Rng in, int fromF, qfmt to, bool identity)
     if (to.O == QG_SAT_SMGN) Re.lo = to.S ? -R.hi : 0;
     if (r.lo >= Re.lo && r.hi <= Re.hi) return r; // overflow handling is the identity
     c.exact = false;
+    if (to.O == QG_WRP_TCPL && !to.S && (int)to.I + (int)to.F == 32)
+        c.fail(QG_EUNSUPPORTED, "unsigned WRP::TCPL into exactly 32 bits: reference result is an ArbiInt<32>::allOnes artefact");
     switch (to.O) {
     case QG_SAT_TCPL:
     case QG_SAT_SMGN:
@@ -401,6 +402,12 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
             // odd leftover: the converting copy is on the path only when this level has odd length
             bool was_exact = c.exact;
             Val lf = do_cvt(c, cur, d->level[p][l], &T.leftover[p][l]);
+            if (l == 0 && (d->flags & QG_DESC_LEFTOVER0_COPY)) {
+                // the level-0 buffer has the leaf's own type in the reference: a same-type copy (QuBLAS.h:4977-4980, :2401-2404)
+                T.leftover[p][l].identity = 1;
+                lf.r = cur.r;
+                if (len & 1) c.exact = was_exact;
+            }
             if (!(len & 1)) c.exact = was_exact;
             else {
                 if (lf.r.lo < st.r.lo) st.r.lo = lf.r.lo;
@@ -602,6 +609,10 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         }
     }
     out->tree64_ok = (!cx && d->n_levels <= 16) ? 1 : 0;   // (max_bits <= 62 was checked above)
+    // QG_DESC_LEFTOVER0_COPY with an odd K: the zero-padded kernels would form the leftover as x + 0 in level 0's type — a
+    // conversion, where the reference copies — so only the general kernel, which has the leftover step itself, may run it
+    const bool copy0 = (d->flags & QG_DESC_LEFTOVER0_COPY) && (d->K & 1) && d->K > 1;
+    if (copy0) out->tree_fast_ok = out->fast_mode = out->tree64_ok = out->gemv_ok = out->gemv_wide_ok = 0;
     // (the Qreduce lowering: a * 1 into a's own format.  That is the identity for every raw value EXCEPT -2^W of a signed
     // SAT::SMGN format, which the conversion clamps to -(2^W - 1); the lowerings therefore name a's format with SAT::TCPL
     // as the leaf format of such element types, and only that form takes the shortcut)
@@ -621,7 +632,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         if (one) out->gemv_fixed = lf.O == QG_SAT_ZERO ? 1 : 2;
         else if (rec_form) out->gemv_fixed = rec_form;   // per-level formats in compact records (3: every level clamps, 5: kinds)
     }
-    out->cplx_fast_ok = (cx && d->n_levels <= 16 && c.max_bits <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
+    out->cplx_fast_ok = (cx && !copy0 && d->n_levels <= 16 && c.max_bits <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     // fixed-mode variant of the complex kernel (BASELINE configuration 5's "RND + SAT"): every sub-operation and every tree
     // step either the identity, or an exact left shift / a rounding shift with RND::POS_INF, followed by SAT::TCPL, so a
     // step is (v + 2^(d-1)) >> d (or v << -d) and one clamp

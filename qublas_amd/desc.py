@@ -42,6 +42,7 @@ QU_MODES = {"RND::POS_INF": 0, "RND::NEG_INF": 1, "RND::ZERO": 2, "RND::INF": 3,
 OF_MODES = {"SAT::TCPL": 0, "SAT::ZERO": 1, "SAT::SMGN": 2, "WRP::TCPL": 3}
 
 CMUL_NONE, CMUL_BASIC, CMUL_TF = 0, 1, 2
+DESC_LEFTOVER0_COPY = 1   # qgemul_desc.flags (include/qgemul.h)
 CLASS_LINEAR, CLASS_TREE = 1, 2
 
 
@@ -52,7 +53,7 @@ class qfmt(C.Structure):
 
 class qgemul_desc(C.Structure):
     _fields_ = [("abi", C.c_uint32), ("transA", C.c_uint8), ("is_complex", C.c_uint8),
-                ("cmul", C.c_uint8), ("reserved", C.c_uint8),
+                ("cmul", C.c_uint8), ("flags", C.c_uint8),
                 ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
                 ("a", qfmt * 2), ("b", qfmt * 2), ("c", qfmt * 2),
                 ("mul", qfmt * 8),
@@ -342,7 +343,7 @@ def desc_to_dict(d: qgemul_desc) -> Dict:
     f = lambda q: [q.I, q.F, q.S, q.Q, q.O]
     nl = d.n_levels
     return {
-        "M": d.M, "N": d.N, "K": d.K, "transA": d.transA, "is_complex": d.is_complex, "cmul": d.cmul,
+        "M": d.M, "N": d.N, "K": d.K, "transA": d.transA, "is_complex": d.is_complex, "cmul": d.cmul, "flags": d.flags,
         "a": [f(d.a[0]), f(d.a[1])], "b": [f(d.b[0]), f(d.b[1])], "c": [f(d.c[0]), f(d.c[1])],
         "mul": [f(d.mul[i]) for i in range(8)], "n_levels": nl,
         "level_add": [[f(d.level_add[0][l]), f(d.level_add[1][l])] for l in range(nl)],
@@ -355,6 +356,7 @@ def desc_from_dict(j: Dict) -> qgemul_desc:
     d = qgemul_desc()
     d.abi = QGEMUL_ABI_VERSION
     d.transA, d.is_complex, d.cmul = j["transA"], j["is_complex"], j["cmul"]
+    d.flags = j.get("flags", 0)
     d.M, d.N, d.K = j["M"], j["N"], j["K"]
     mk = lambda t: qfmt(t[0], t[1], t[2], t[3], t[4], 0)
     for p in range(2):
@@ -413,7 +415,12 @@ def lower_reduce(e: Qu, rows: int, length: int, levels=None) -> qgemul_desc:
         # therefore targets a's format with SAT::TCPL (the identity on every raw value), and the default level type — the
         # merge of two elements, i.e. the element type itself (AddMerger, QuBLAS.h:3125-3139) — is named explicitly.
         leaf = Qu(e.intBits, e.fracBits, e.isSigned, e.QuMode, SAT.TCPL)
-        return lower(e, ONE, leaf if length <= 1 else ec, rows, 1, length, add_args=levels or [e], mul_args=leaf, transposed_a=True)
+        d = lower(e, ONE, leaf if length <= 1 else ec, rows, 1, length, add_args=levels or [e], mul_args=leaf, transposed_a=True)
+        # ... and where level 0's type IS the element type, the reference's copy of an odd leftover into the level-0 buffer is a
+        # same-type copy (QuBLAS.h:4977-4980): the raw minimum survives it, so the descriptor asks for the unconverted copy
+        if (levels or [e])[0] == e:
+            d.flags |= DESC_LEFTOVER0_COPY
+        return d
     return lower(e, ONE, ec, rows, 1, length, add_args=levels, mul_args=e, transposed_a=True)
 
 

@@ -102,6 +102,12 @@ def test_rejections():
     for c in (Qu(32, 0, False, OfMode=3), Qu(16, 16, False, OfMode=3)):
         st, info = capi.classify_status(lower(e, e, c, 4, 4, 4))
         assert st == capi.QG_EUNSUPPORTED, info.reason
+    # ... unless no value can leave the range: the reference's `val & allOnes` is then a no-op as well (unsigned operands, sums
+    # below 2^32: uint32-style formats run; tests/golden/ref_scalar_6 holds in-range conversions into these types)
+    u = Qu(4, 3, False)
+    for c in (Qu(32, 0, False, OfMode=3), Qu(16, 16, False, OfMode=3)):
+        st, info = capi.classify_status(lower(u, u, c, 4, 4, 4))
+        assert st == capi.QG_OK, info.reason
     # ... and only that: 31 / 33 unsigned bits and the signed 32-storage-bit format wrap arithmetically in the reference too
     for c in (Qu(31, 0, False, OfMode=3), Qu(33, 0, False, OfMode=3), Qu(31, 0, True, OfMode=3), Qu(32, 0, False, OfMode=0)):
         st, info = capi.classify_status(lower(e, e, c, 4, 4, 4))

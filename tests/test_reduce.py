@@ -10,8 +10,9 @@ from qublas_amd.desc import ONE, Qu, lower_reduce, reduce_result_type
 
 
 def _tables():
-    # part 4: the reduce tables; part 7: signed SAT::SMGN (and TCPL / ZERO) element types with the raw minimum -2^W present
-    return [t for part in (4, 7) for t in G.scalar_tables(part) if t["kind"] == "reduce"]
+    # part 4: the reduce tables; part 7: signed SAT::SMGN (and TCPL / ZERO) element types with the raw minimum -2^W present;
+    # part 8: the raw minimum as the LAST element (odd lengths: the odd leftover of level 0, copied unconverted)
+    return [t for part in (4, 7, 8) for t in G.scalar_tables(part) if t["kind"] == "reduce"]
 
 
 def _batch(oracle, t):
