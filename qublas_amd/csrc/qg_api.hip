@@ -53,6 +53,29 @@ struct DeviceScope {
     DeviceScope dev_scope_((ctxp)->device); \
     QG_HIP(dev_scope_.err)
 
+// Composite linear plan.  The MFMA kernels take operands of at most 3 int8 limbs and keep exact int32 accumulators only while
+// K * min(LA, LB) < 2^17.  Beyond either bound the linear class used to fall to the 64-bit VALU tree kernel (40-300x slower); the
+// reference has no such boundary (Reducer, QuBLAS.h:4960-4990; ArbiInt elements up to 64 bits, :347-564).  Now:
+//   * an operand of L > 3 limbs is stored as limb GROUPS of 2-3 limbs (x = sum_g x_g * 256^limb0[g], every x_g a balanced
+//     base-256 number of its own), each group a complete packed operand of the existing layout;
+//   * K is cut into chunks of at most kc reduction indices (a multiple of 256), each chunk a complete packed operand as well;
+//   * every (chunk, A group, B group) is ONE launch of an existing MFMA kernel that stores raw dot products (identity
+//     epilogue) into a slab, and k_lin_combine (qg_pack.hip) adds the slabs by weight into an exact running sum and, after the
+//     last chunk, rounds + overflow-handles it once into C — the linear class's whole epilogue (QuBLAS.h:2398-2411).
+// Packed operand = the sub-operands back to back, chunk-major, each 256-byte aligned.
+struct QComposite {
+    int on;
+    int ga, gb;            // limb groups of A, B (1..3)
+    int la[3], lb[3];      // limbs per group
+    int la0[3], lb0[3];    // first limb of each group
+    int var[3][3];         // MFMA variant of the pair (A group, B group); one tile geometry for all pairs
+    int nc;                // k-chunks
+    int64_t kc;            // reduction indices per chunk (the last chunk: K - (nc - 1) * kc)
+    int slab_bytes;        // 4: single-limb pairs (raw int32), 8 otherwise
+    int wide;              // 128-bit sums
+    int64_t chunk_bytes[2];   // bytes of one FULL chunk of packed A / B (all groups)
+};
+
 struct qgemul_plan {
     qgemul_ctx* ctx;
     qgemul_desc desc;
@@ -80,6 +103,9 @@ struct qgemul_plan {
     void* cwork;
     int32_t* wide_ws;     // single-limb MFMA with a left-shifting epilogue that leaves 32 bits: raw int32 dot products
     void* hostc_pc;       // qgemul_execute_host_c on a kernel that cannot store the reference layout: its packed C
+    QComposite comp;      // composite linear plan (comp.on): limb groups x k-chunks of sub-GEMMs + an exact combine pass
+    void* comp_slabs;     // comp.ga * comp.gb slabs of raw dot products, one common packed-C layout
+    void* comp_acc;       // running exact sums between k-chunks (comp.nc > 1)
 };
 
 struct HostC { void* C; int64_t ld; };
@@ -97,11 +123,98 @@ static int pow2_bytes(int storage_bits)
 static bool same_fmt(const qfmt& x, const qfmt& y) { return x.I == y.I && x.F == y.F && x.S == y.S && x.Q == y.Q && x.O == y.O; }
 static int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// ---- composite linear plans: geometry helpers (see QComposite) ----
+static int64_t comp_sub_bytes(int limbs, int64_t rows_p, int64_t K_p)
+{
+    return round_up((int64_t)limbs * rows_p * K_p + (limbs > 1 ? QG_TRAILER_BYTES : 0), 256);
+}
+// reduction indices of chunk c
+static int64_t comp_chunk_len(const QComposite& q, int64_t K, int c) { return c + 1 < q.nc ? q.kc : K - (int64_t)(q.nc - 1) * q.kc; }
+// the packed sub-operand (chunk c, group g) of operand `which` (0 A, 1 B): its geometry and its byte offset in the packed operand
+static QPackedGeom comp_sub_geom(const QComposite& q, const QPackedGeom& base, int which, int64_t K, int c, int g, int64_t* off)
+{
+    const int* L = which ? q.lb : q.la;
+    const int* L0 = which ? q.lb0 : q.la0;
+    const int ng = which ? q.gb : q.ga;
+    const int64_t K_p = round_up(comp_chunk_len(q, K, c), base.bk);
+    QPackedGeom s = base;
+    s.K_p = K_p;
+    s.limbs = L[g];
+    s.limb0 = L0[g];
+    s.trailer = L[g] > 1 ? (int64_t)L[g] * base.rows_p * K_p : 0;
+    s.digit6 = 0;
+    int64_t o = (int64_t)c * q.chunk_bytes[which];
+    for (int h = 0; h < g && h < ng; ++h) o += comp_sub_bytes(L[h], base.rows_p, K_p);
+    if (off) *off = o;
+    return s;
+}
+// groups of 2-3 limbs, low limbs first
+static int comp_split(int L, int* sizes, int* first)
+{
+    static const int tab[9][3] = {{0, 0, 0}, {1, 0, 0}, {2, 0, 0}, {3, 0, 0}, {2, 2, 0}, {3, 2, 0}, {3, 3, 0}, {3, 2, 2}, {3, 3, 2}};
+    if (L < 1 || L > 8) return 0;
+    int n = 0, f = 0;
+    for (int i = 0; i < 3 && tab[L][i]; ++i) { sizes[n] = tab[L][i]; first[n] = f; f += tab[L][i]; ++n; }
+    return n;
+}
+static bool comp_geometry(int LA, int LB, const qgemul_desc* d, uint32_t flags, QComposite* q, QMfmaCfg* cfg)
+{
+    memset(q, 0, sizeof *q);
+    q->ga = comp_split(LA, q->la, q->la0);
+    q->gb = comp_split(LB, q->lb, q->lb0);
+    if (!q->ga || !q->gb) return false;
+    int maxa = 0, maxb = 0;
+    bool single = true;
+    for (int i = 0; i < q->ga; ++i)
+        for (int j = 0; j < q->gb; ++j) {
+            const QMfmaCfg c = qg_mfma_pick(q->la[i], q->lb[j], d->M, d->N, flags);
+            if (!c.variant) return false;
+            if (i + j == 0) *cfg = c;
+            else if (c.TM != cfg->TM || c.TN != cfg->TN || c.BK != cfg->BK) return false;   // (one packed layout for all pairs)
+            q->var[i][j] = c.variant;
+            if (q->la[i] > maxa) maxa = q->la[i];
+            if (q->lb[j] > maxb) maxb = q->lb[j];
+            single = single && q->la[i] == 1 && q->lb[j] == 1;
+        }
+    // int32 accumulators of a limb weight collect min(la, lb) products of magnitude <= 2^14 per reduction index
+    const int mn = maxa < maxb ? maxa : maxb;
+    const int64_t kmax = (((1ll << 17) - 1) / mn) / 256 * 256;
+    q->nc = (int)((d->K + kmax - 1) / kmax);
+    q->kc = q->nc > 1 ? kmax : d->K;
+    q->slab_bytes = single ? 4 : 8;
+    q->on = 1;
+    return true;
+}
+
+// composite plans: run `fn` on every (k-chunk, limb group) sub-operand of A or B — its view of the host tensor (the chunk's
+// reduction indices), its packed geometry, its byte offset inside the packed operand
+template <class F>
+static hipError_t comp_for_each_sub(const qgemul_plan* p, int operand, const QOperandGeom& g, F fn)
+{
+    const QComposite& q = p->comp;
+    const int w = operand == QG_OPERAND_A ? 0 : 1;
+    const QPackedGeom& base = w ? p->pb : p->pa;
+    for (int c = 0; c < q.nc; ++c)
+        for (int gi = 0; gi < (w ? q.gb : q.ga); ++gi) {
+            int64_t off = 0;
+            const QPackedGeom sp = comp_sub_geom(q, base, w, p->desc.K, c, gi, &off);
+            QOperandGeom sg = g;
+            sg.k0 = (int64_t)c * q.kc;
+            sg.K = comp_chunk_len(q, p->desc.K, c);
+            if (hipError_t e = fn(sg, sp, off); e != hipSuccess) return e;
+        }
+    return hipSuccess;
+}
+
 // fill info + geometry for a descriptor; no GPU access
 static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qgemul_info* info, int* pLA, int* pLB, QMfmaCfg* pVar,
                          QPackedGeom* pa, QPackedGeom* pb, QCGeom* pc, QHostElem* ha, QHostElem* hb, QHostElem* hc,
-                         const EpView* ev = nullptr, QEpTable* ept = nullptr, QCGeom* pc_c = nullptr, QEpTable* ept_im = nullptr)
+                         const EpView* ev = nullptr, QEpTable* ept = nullptr, QCGeom* pc_c = nullptr, QEpTable* ept_im = nullptr,
+                         QComposite* pcomp = nullptr)
 {
+    QComposite comp_local;
+    QComposite& comp = pcomp ? *pcomp : comp_local;
+    memset(&comp, 0, sizeof comp);
     const qgemul_epilogue* ep = ev ? ev->re : nullptr;
     qg_analyze(d, an);
     memset(info, 0, sizeof *info);
@@ -150,9 +263,16 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
         cfg = qg_mfma_pick(LA, LB, d->M * parts, d->N * parts, (ep ? QG_OPT_LOCKSTEP_TILES : 0u) | flags);   // (the fused / unfused element-wise chain keeps the kernel it was measured on)
         if (cfg.variant && (int64_t)mn * d->K <= (1ll << 17) - 1)
             kernel = d->is_complex ? QG_KERNEL_MFMA_CPLX : ((LA == 1 && LB == 1) ? QG_KERNEL_MFMA_I8 : QG_KERNEL_MFMA_I8_LIMB);
-        else {
+        // (one output column whose tree the one-column kernels can walk: those stream A once at HBM rate; a composite plan would read
+        // it once per limb group and write slabs — the batched Qreduce of 32-bit words with exact level types stays there)
+        else if (!d->is_complex && !(d->N == 1 && (an->gemv_ok || an->gemv_wide_ok) && !(flags & QG_OPT_GENERIC_TREE)) &&
+                 comp_geometry(LA, LB, d, flags, &comp, &cfg)) {
+            // more than 3 limbs, or K beyond the int32 accumulators' exact range: limb groups x k-chunks on the same kernels
+            kernel = (LA == 1 && LB == 1) ? QG_KERNEL_MFMA_I8 : QG_KERNEL_MFMA_I8_LIMB;
+            snprintf(info->reason, sizeof info->reason, "linear class: %d k-chunk(s) x %d x %d limb groups on the MFMA kernels, exact combine", comp.nc, comp.ga, comp.gb);
+        } else {
             LA = LB = 0;
-            snprintf(info->reason, sizeof info->reason, "linear class, but limbs/K outside the MFMA kernel's exact range: tree kernel");
+            snprintf(info->reason, sizeof info->reason, "linear class, but limbs/K outside the MFMA kernels' range: tree kernel");
         }
     }
     pc->M = d->M;
@@ -165,6 +285,11 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     if (kernel != QG_KERNEL_NONE) {
         *pa = QPackedGeom{round_up(d->M, cfg.TM), round_up(d->K, cfg.BK), 1, LA, cfg.TM, cfg.BK};
         *pb = QPackedGeom{round_up(d->N, cfg.TN), round_up(d->K, cfg.BK), 1, LB, cfg.TN, cfg.BK};
+        if (comp.on) {   // pa / pb: the first sub-operand (group 0 of chunk 0); the others through comp_sub_geom
+            pa->K_p = pb->K_p = round_up(comp.kc, cfg.BK);
+            pa->limbs = comp.la[0];
+            pb->limbs = comp.lb[0];
+        }
         pc->Mp = pa->rows_p;
         pc->Np = pb->rows_p;
         pc->tm = cfg.TM;
@@ -218,9 +343,28 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     // multi-limb operands carry their plane mask in a trailer behind the planes (QPackedGeom::trailer)
     if (pa->limbs > 1) { pa->trailer = info->packed_bytes[0]; info->packed_bytes[0] += QG_TRAILER_BYTES; }
     if (pb->limbs > 1) { pb->trailer = info->packed_bytes[1]; info->packed_bytes[1] += QG_TRAILER_BYTES; }
+    if (comp.on) {
+        // the packed operand = every (chunk, group) sub-operand back to back
+        for (int w = 0; w < 2; ++w) {
+            const QPackedGeom& base = w ? *pb : *pa;
+            const int ng = w ? comp.gb : comp.ga;
+            const int* L = w ? comp.lb : comp.la;
+            int64_t full = 0, last = 0;
+            const int64_t Kl = round_up(comp_chunk_len(comp, d->K, comp.nc - 1), base.bk);
+            for (int g = 0; g < ng; ++g) { full += comp_sub_bytes(L[g], base.rows_p, base.K_p); last += comp_sub_bytes(L[g], base.rows_p, Kl); }
+            comp.chunk_bytes[w] = full;
+            info->packed_bytes[w] = (int64_t)(comp.nc - 1) * full + last;
+        }
+        pa->trailer = pb->trailer = 0;   // (per sub-operand: comp_sub_geom)
+        if ((int64_t)comp.ga * comp.gb * pa->rows_p * pb->rows_p * comp.slab_bytes > (64ll << 30)) {
+            info->supported = 0;
+            snprintf(info->reason, sizeof info->reason, "composite linear plan: the slabs of raw dot products would exceed 64 GiB");
+            return QG_EUNSUPPORTED;
+        }
+    }
     // Karatsuba (qg_mfma.hip, KARA): two-limb operands whose biased values fit 12 bits are stored as two unsigned base-64
     // digits each, and the product takes 3 MFMAs per k-step instead of 4
-    {
+    if (!comp.on) {
         static const bool no_kara = QG_DIAG_ENV("QG_NO_KARA");   // A/B switch
         auto ubits = [](qfmt f) { return (int)f.I + (int)f.F + (f.S ? 1 : 0); };
         // (problems small enough for the 64x64 tiles are latency-bound: measured 9.5 vs 8.9 us at 1024^3, schoolbook kept there)
@@ -321,6 +465,7 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
 // 64-bit linear pass instead, which keeps the hot kernels' epilogue as it is.
 static bool wide_epilogue(const qgemul_plan* p)
 {
+    if (p->comp.on) return false;   // (the combine pass converts in 64-bit arithmetic anyway)
     const QStep& q = p->an.lin.to_c[0];
     // ... and a C format beyond 31 value bits does not fit the 32-bit epilogue's clamp bounds at all (second find of the
     // extended fuzz runs: int<7,-2> x int<7,-1> into Qu<24,9>)
@@ -334,7 +479,7 @@ extern "C" void qgemul_diag_set_stamps(void* dev) { g_diag_stamps = (uint32_t*)d
 
 static bool fuses_epilogue(const qgemul_plan* p)
 {
-    if (wide_epilogue(p)) return false;
+    if (wide_epilogue(p) || p->comp.on) return false;
     if (p->flags & QG_OPT_UNFUSED_EPILOGUE) return false;
     if (!p->ept.bits32) return false;
     if (p->info.kernel == QG_KERNEL_MFMA_I8_LIMB && p->LA == 3 && p->LB == 3) return true;
@@ -505,7 +650,7 @@ static int plan_create_view(qgemul_ctx* c, const qgemul_desc* d, const EpView* e
         }
     }
     int st = plan_geometry(d, opt_flags, &p->an, &p->info, &p->LA, &p->LB, &p->cfg, &p->pa, &p->pb, &p->pc, &p->ha, &p->hb, &p->hc,
-                           ev, &p->ept, &p->pc_c, &p->ept_im);
+                           ev, &p->ept, &p->pc_c, &p->ept_im, &p->comp);
     if (st != QG_OK) { delete p; return st; }
     p->variant = p->cfg.variant;
     DeviceScope scope(c->device);
@@ -533,6 +678,17 @@ static int plan_create_view(qgemul_ctx* c, const qgemul_desc* d, const EpView* e
         delete p;
         return QG_EHIP;
     }
+    if (p->comp.on) {
+        const size_t n = (size_t)p->pa.rows_p * (size_t)p->pb.rows_p;
+        const size_t sl = n * (size_t)(p->comp.ga * p->comp.gb) * (size_t)p->comp.slab_bytes;
+        const size_t ac = p->comp.nc > 1 ? n * (p->comp.wide ? 16 : 8) : 0;
+        if (hipMalloc(&p->comp_slabs, sl ? sl : 16) != hipSuccess || (ac && hipMalloc(&p->comp_acc, ac) != hipSuccess)) {
+            hipFree(p->dev_table);
+            hipFree(p->comp_slabs);
+            delete p;
+            return QG_EHIP;
+        }
+    }
     if (p->has_ep && !fuses_epilogue(p)) {
         // the tree kernels store C; the chain then runs as a pass over it
         const size_t cb = (size_t)(p->pc_c.parts * p->pc_c.Mp * p->pc_c.Np) * (size_t)p->pc_c.cbytes;
@@ -540,6 +696,8 @@ static int plan_create_view(qgemul_ctx* c, const qgemul_desc* d, const EpView* e
             hipFree(p->dev_table);
             hipFree(p->workspace);
             hipFree(p->wide_ws);
+            hipFree(p->comp_slabs);
+            hipFree(p->comp_acc);
             delete p;
             return QG_EHIP;
         }
@@ -558,6 +716,8 @@ void qgemul_plan_destroy(qgemul_plan* p)
     hipFree(p->cwork);
     hipFree(p->wide_ws);
     hipFree(p->hostc_pc);
+    hipFree(p->comp_slabs);
+    hipFree(p->comp_acc);
     delete p;
 }
 
@@ -607,6 +767,11 @@ int qgemul_pack(qgemul_plan* p, int operand, const void* src_dev, int64_t ld, vo
     const QPackedGeom& pg = operand == QG_OPERAND_A ? p->pa : p->pb;
     const int check = (p->flags & QG_OPT_CHECK_RANGE) ? 1 : 0;
     if (check) QG_HIP(hipMemsetAsync(p->ctx->flag_dev, 0, 4, p->ctx->stream));
+    if (p->comp.on) {
+        QG_HIP(comp_for_each_sub(p, operand, g, [&](const QOperandGeom& sg, const QPackedGeom& sp, int64_t off) {
+            return qg_launch_pack(sg, sp, src_dev, (char*)packed_dev + off, check, p->ctx->flag_dev, p->ctx->stream, (p->flags & QG_OPT_GENERIC_LAYOUT) ? 1 : 0);
+        }));
+    } else
     QG_HIP(qg_launch_pack(g, pg, src_dev, packed_dev, check, p->ctx->flag_dev, p->ctx->stream, (p->flags & QG_OPT_GENERIC_LAYOUT) ? 1 : 0));
     if (check) {
         int flag = 0;
@@ -630,6 +795,12 @@ int qgemul_pack_f64(qgemul_plan* p, int operand, const double* src_dev, int64_t 
     QG_ON_DEVICE(p->ctx);
     QOperandGeom g = operand_geom(p, operand, ld);
     const QPackedGeom& pg = operand == QG_OPERAND_A ? p->pa : p->pb;
+    if (p->comp.on) {
+        QG_HIP(comp_for_each_sub(p, operand, g, [&](const QOperandGeom& sg, const QPackedGeom& sp, int64_t off) {
+            return qg_launch_pack_f64(sg, sp, src_dev, (char*)packed_dev + off, p->ctx->stream, (p->flags & QG_OPT_GENERIC_LAYOUT) ? 1 : 0);
+        }));
+        return QG_OK;
+    }
     QG_HIP(qg_launch_pack_f64(g, pg, src_dev, packed_dev, p->ctx->stream, (p->flags & QG_OPT_GENERIC_LAYOUT) ? 1 : 0));
     return QG_OK;
 }
@@ -640,6 +811,12 @@ int qgemul_fill_packed(qgemul_plan* p, int operand, uint64_t seed, int dist, voi
     QG_ON_DEVICE(p->ctx);
     QOperandGeom g = operand_geom(p, operand, 0);
     const QPackedGeom& pg = operand == QG_OPERAND_A ? p->pa : p->pb;
+    if (p->comp.on) {
+        QG_HIP(comp_for_each_sub(p, operand, g, [&](const QOperandGeom& sg, const QPackedGeom& sp, int64_t off) {
+            return qg_launch_fill(sg, sp, seed, dist, (char*)packed_dev + off, p->ctx->stream);
+        }));
+        return QG_OK;
+    }
     QG_HIP(qg_launch_fill(g, pg, seed, dist, packed_dev, p->ctx->stream));
     return QG_OK;
 }
@@ -669,7 +846,7 @@ int qgemul_execute(qgemul_plan* p, void* packedC, const void* packedA, const voi
 // container equal to the host element, no raw-dot-product detour
 static bool stores_host_c(const qgemul_plan* p)
 {
-    if (p->has_ep || p->desc.is_complex || wide_epilogue(p)) return false;
+    if (p->has_ep || p->desc.is_complex || wide_epilogue(p) || p->comp.on) return false;
     if (p->info.kernel != QG_KERNEL_MFMA_I8 && p->info.kernel != QG_KERNEL_MFMA_I8_LIMB) return false;
     if (p->variant != 9 && p->variant != 10) return false;
     if (p->variant == 10 && (p->pa.rows_p / p->cfg.TM) * (p->pb.rows_p / p->cfg.TN) < 256) return false;   // (falls back to the lock-step kernel)
@@ -794,10 +971,58 @@ int qgemul_pack_e(qgemul_plan* p, int stage, const void* src_dev, int64_t ld, vo
     return QG_OK;
 }
 
+// composite linear plan: per k-chunk, one MFMA launch per (A group, B group) storing raw dot products into its slab, then the
+// exact combine pass (running sums between chunks; one round + overflow into C after the last)
+static int execute_composite(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB, const QCGeom& pcg)
+{
+    const QComposite& q = p->comp;
+    hipStream_t st = p->ctx->stream;
+    const int64_t n = p->pa.rows_p * p->pb.rows_p;
+    for (int c = 0; c < q.nc; ++c) {
+        QLinCombine cb;
+        memset(&cb, 0, sizeof cb);
+        for (int i = 0; i < q.ga; ++i)
+            for (int j = 0; j < q.gb; ++j) {
+                int64_t offA = 0, offB = 0;
+                const QPackedGeom sa = comp_sub_geom(q, p->pa, 0, p->desc.K, c, i, &offA);
+                const QPackedGeom sb = comp_sub_geom(q, p->pb, 1, p->desc.K, c, j, &offB);
+                char* slab = (char*)p->comp_slabs + (size_t)(i * q.gb + j) * (size_t)n * (size_t)q.slab_bytes;
+                QMfmaArgs a;
+                memset(&a, 0, sizeof a);
+                a.A = (const int8_t*)packedA + offA;
+                a.B = (const int8_t*)packedB + offB;
+                a.C = slab;
+                a.Mp = sa.rows_p;
+                a.Np = sb.rows_p;
+                a.Kp = sa.K_p;
+                a.cbytes = q.slab_bytes;
+                a.variant = q.var[i][j];
+                a.to_c.identity = 1;   // raw dot products
+                a.maskA = sa.trailer ? (const uint32_t*)((const char*)a.A + sa.trailer) : nullptr;
+                a.maskB = sb.trailer ? (const uint32_t*)((const char*)a.B + sb.trailer) : nullptr;
+                QG_HIP(qg_launch_mfma(sa.limbs, sb.limbs, a, st));
+                cb.slab[cb.n_slabs] = slab;
+                cb.sh[cb.n_slabs] = 8 * (sa.limb0 + sb.limb0);
+                ++cb.n_slabs;
+            }
+        cb.slab_bytes = q.slab_bytes;
+        cb.n = n;
+        cb.acc_in = c > 0 ? p->comp_acc : nullptr;
+        cb.acc_out = c + 1 < q.nc ? p->comp_acc : nullptr;
+        cb.out = packedC;
+        cb.cbytes = pcg.cbytes;
+        cb.wide = q.wide;
+        cb.to_c = p->an.lin.to_c[0];
+        QG_HIP(qg_launch_lin_combine(cb, st));
+    }
+    return QG_OK;
+}
+
 static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, const void* packedB, const qgemul_ep_args*, const HostC* hostc)
 {
     hipStream_t st = p->ctx->stream;
     const QCGeom& pcg = p->has_ep ? p->pc_c : p->pc;
+    if (p->comp.on) return execute_composite(p, packedC, packedA, packedB, pcg);
     switch (p->info.kernel) {
     case QG_KERNEL_MFMA_I8:
     case QG_KERNEL_MFMA_I8_LIMB: {

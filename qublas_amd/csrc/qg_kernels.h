@@ -18,6 +18,8 @@ struct QOperandGeom {
     int32_t parts;          // 1 real, 2 complex
     int32_t W[2], S[2];     // format of each part (range check, synthetic fill)
     int32_t F[2], Q[2], O[2]; // quantise-on-load: fracBits, QuMode, OfMode of each part
+    int64_t k0;             // this packed operand holds the reduction indices [k0, k0 + K) of the host tensor (a k-chunk of a
+                            // composite linear plan, qg_api.hip; 0 otherwise)
 };
 
 // packed (device-private) layouts
@@ -41,7 +43,10 @@ struct QPackedGeom {
     // Karatsuba layout (2 x 2 digits, operands of at most 12 value+sign bits): the two planes hold the UNSIGNED base-64 digits
     // of x + bias (bias = 2^W for a signed format, so the biased value is non-negative; padding holds 0), and int64
     // row_sum[rows_p] = sum_k (x + bias) follows the trailer — the kernel's epilogue takes the bias back out with it.
-    int32_t digit6, pad2_;
+    int32_t digit6;
+    // limb layout: the planes hold digits limb0 .. limb0 + limbs - 1 of the balanced base-256 expansion (a limb GROUP of an
+    // operand of more than 3 limbs, composite linear plans; 0 otherwise)
+    int32_t limb0;
     int64_t bias, rowsum_off;
 };
 enum { QG_TRAILER_BYTES = 256, QG_MASK_WORDS = 64 };
@@ -94,6 +99,25 @@ struct QCplxCombine {
     QStep to_c[2];
 };
 hipError_t qg_launch_cplx_combine(const QCplxCombine& g, hipStream_t st);
+
+// composite linear plans (operands of more than 3 int8 limbs, or K beyond the int32 accumulators' exact range): the limb-group /
+// k-chunk sub-GEMMs store RAW dot products (int32 for single-limb pairs, int64 otherwise) in slabs of one common packed-C
+// layout; this pass forms  s = acc_in + sum_j (slab_j << sh[j])  per element, exactly, and either keeps it for the next
+// k-chunk (acc_out) or rounds + overflow-handles it ONCE into C's format (out).  wide: 128-bit sums (two-word accumulator
+// elements, C containers of up to 16 bytes).
+enum { QG_MAX_SLABS = 9 };
+struct QLinCombine {
+    const void* slab[QG_MAX_SLABS];
+    int32_t sh[QG_MAX_SLABS];
+    int32_t n_slabs, slab_bytes;   // 4 | 8
+    int64_t n;                     // elements (the padded packed-C index space)
+    const void* acc_in;            // nullptr: start from 0
+    void* acc_out;                 // nullptr: this is the last chunk
+    void* out;                     // packed C (cbytes containers), written when acc_out == nullptr
+    int32_t cbytes, wide;
+    QStep to_c;
+};
+hipError_t qg_launch_lin_combine(const QLinCombine& g, hipStream_t st);
 
 // exact tree evaluation, any descriptor (real / complex, any K), 64-bit arithmetic
 hipError_t qg_launch_tree_generic(const QTreeTable* dev_table, int parts, const void* A, const void* B, void* C, int64_t M,

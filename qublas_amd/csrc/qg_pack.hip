@@ -89,6 +89,7 @@ __device__ __forceinline__ unsigned put_packed(const QPackedGeom& p, char* dst, 
             }
             return 0;
         }
+        for (int l = 0; l < p.limb0; ++l) v = (v - (int64_t)(int8_t)(v & 0xff)) >> 8;   // a limb group: the lower digits live elsewhere
         for (int l = 0; l < p.limbs; ++l) {
             int64_t d = (int64_t)(int8_t)(v & 0xff); // balanced digit in [-128,127]
             ((int8_t*)dst)[((blk + l) * p.tr + rl) * p.bk + slot * 16 + (kl & 15)] = (int8_t)d;
@@ -129,9 +130,9 @@ __global__ __launch_bounds__(256) void k_pack_limb32(QOperandGeom g, QPackedGeom
     const int64_t r = (int64_t)tr64 * 64 + row_l, k0 = (int64_t)tk * 64 + kc * 16;
     int32_t v[16];
     const bool row_in = r < g.rows;
-    const int32_t* q = src + r * g.rs + k0 * g.ks;
+    const int32_t* q = src + r * g.rs + (k0 + g.k0) * g.ks;
     if constexpr (F64) {
-        const double* qd = (const double*)src + r * g.rs + k0 * g.ks;
+        const double* qd = (const double*)src + r * g.rs + (k0 + g.k0) * g.ks;
         if (VEC && row_in && k0 + 16 <= g.K) {      // k contiguous: eight 16-byte loads of two doubles
             const double2* q2 = (const double2*)qd;
 #pragma unroll
@@ -168,6 +169,9 @@ __global__ __launch_bounds__(256) void k_pack_limb32(QOperandGeom g, QPackedGeom
     const int c = p.bk == 64 ? kc : (tk & 1) * 4 + kc;   // 16-byte chunk of this thread inside its k-tile
     const int64_t blk = ((r / p.tr) * (p.K_p / p.bk) + (p.bk == 64 ? tk : tk >> 1)) * p.limbs;
     int8_t* out = dst + (blk * p.tr + rl) * p.bk + ((c ^ sw) * 16);
+    for (int l = 0; l < p.limb0; ++l)   // a limb group: the lower digits live elsewhere
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = (int32_t)(((int64_t)v[j] - (int32_t)(int8_t)(v[j] & 0xff)) >> 8);
     for (int l = 0; l < p.limbs; ++l) {
         uint32_t w[4] = {0, 0, 0, 0};
         uint32_t any = 0;
@@ -233,14 +237,15 @@ __global__ __launch_bounds__(256) void k_pack(QOperandGeom g, QPackedGeom p, con
         int64_t k = tk * 64 + (r_fast ? i : tx);
         int64_t v = 0;
         if (r < g.rows && k < g.K) {
+            const int64_t kh = k + g.k0;   // reduction index in the host tensor (k: inside this packed operand)
             if (fill == 2) {
-                const double* ds = (const double*)src + (r * g.rs + k * g.ks) * g.parts + part;
+                const double* ds = (const double*)src + (r * g.rs + kh * g.ks) * g.parts + part;
                 v = quantize_f64(*ds, W, S, g.F[part], g.Q[part], g.O[part]);
             } else if (fill) {
                 // tight host linear index of the element, as a host-side fill of the tensor would see it
-                v = qg_synth(W, S, seed, dist, (uint64_t)(r * g.rs + k * g.ks), part);
+                v = qg_synth(W, S, seed, dist, (uint64_t)(r * g.rs + kh * g.ks), part);
             } else {
-                v = load_host_part(src, r * g.rs + k * g.ks, g.elem_bytes, g.off[part], g.sb[part]);
+                v = load_host_part(src, r * g.rs + kh * g.ks, g.elem_bytes, g.off[part], g.sb[part]);
                 if (check && (v < lo || v > hi)) bad = true;
             }
             if (p.digit6) v = (v + p.bias) & ((((int64_t)1) << (6 * p.limbs)) - 1);   // padding stays 0
@@ -403,7 +408,31 @@ __global__ __launch_bounds__(256) void k_bitstream_cplx(QBitsCplxArgs g)
     }
 }
 
+// composite linear plans: see QLinCombine (qg_kernels.h).  One thread per element, slabs and C share ONE layout: a linear pass.
+template <class SlabT, class AccT>
+__global__ __launch_bounds__(256) void k_lin_combine(QLinCombine g)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.n) return;
+    AccT s = g.acc_in ? ((const AccT*)g.acc_in)[i] : (AccT)0;
+#pragma unroll
+    for (int j = 0; j < QG_MAX_SLABS; ++j)
+        if (j < g.n_slabs) s += (AccT)(((const SlabT*)g.slab[j])[i]) * ((AccT)1 << g.sh[j]);
+    if (g.acc_out) { ((AccT*)g.acc_out)[i] = s; return; }
+    store_container((char*)g.out, i, g.cbytes, (int64_t)qg_step<AccT>(s, g.to_c));
+}
+
 } // namespace
+
+hipError_t qg_launch_lin_combine(const QLinCombine& g, hipStream_t st)
+{
+    if (g.n <= 0) return hipSuccess;
+    const int64_t blocks = (g.n + 255) / 256;
+    if (blocks > 0x7fffffffll || g.n_slabs < 1 || g.n_slabs > QG_MAX_SLABS || g.wide) return hipErrorInvalidValue;
+    if (g.slab_bytes == 4) hipLaunchKernelGGL((k_lin_combine<int32_t, int64_t>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((k_lin_combine<int64_t, int64_t>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    return hipGetLastError();
+}
 
 hipError_t qg_launch_bitstream_cplx(const QBitsCplxArgs& a, hipStream_t st)
 {
@@ -461,7 +490,7 @@ hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const voi
         const int64_t nblk = (p.K_p / 64) * (p.rows_p / 64);
         const unsigned nb = (unsigned)(nblk < 2048 ? nblk : 2048);   // grid-stride beyond 8 workgroups per CU
         if (g.rs == 1 && g.ks != 1) hipLaunchKernelGGL(k_pack_limb32<true>, dim3(nb), dim3(256), 0, st, g, p, (const int32_t*)src, (int8_t*)dst, check_range, range_flag);
-        else if (g.ks == 1 && g.rs % 4 == 0 && ((uintptr_t)src & 15) == 0)
+        else if (g.ks == 1 && g.rs % 4 == 0 && g.k0 % 4 == 0 && ((uintptr_t)src & 15) == 0)
             hipLaunchKernelGGL((k_pack_limb32<false, true>), dim3(nb), dim3(256), 0, st, g, p, (const int32_t*)src, (int8_t*)dst, check_range, range_flag);
         else hipLaunchKernelGGL(k_pack_limb32<false>, dim3(nb), dim3(256), 0, st, g, p, (const int32_t*)src, (int8_t*)dst, check_range, range_flag);
         return hipGetLastError();
@@ -482,7 +511,7 @@ hipError_t qg_launch_pack_f64(const QOperandGeom& g, const QPackedGeom& p, const
         const int64_t nblk = (p.K_p / 64) * (p.rows_p / 64);
         const unsigned nb = (unsigned)(nblk < 2048 ? nblk : 2048);
         if (g.rs == 1 && g.ks != 1) hipLaunchKernelGGL((k_pack_limb32<true, false, true>), dim3(nb), dim3(256), 0, st, g, p, (const int32_t*)src, (int8_t*)dst, 0, (int*)nullptr);
-        else if (g.ks == 1 && g.rs % 2 == 0 && ((uintptr_t)src & 15) == 0)
+        else if (g.ks == 1 && g.rs % 2 == 0 && g.k0 % 2 == 0 && ((uintptr_t)src & 15) == 0)
             hipLaunchKernelGGL((k_pack_limb32<false, true, true>), dim3(nb), dim3(256), 0, st, g, p, (const int32_t*)src, (int8_t*)dst, 0, (int*)nullptr);
         else hipLaunchKernelGGL((k_pack_limb32<false, false, true>), dim3(nb), dim3(256), 0, st, g, p, (const int32_t*)src, (int8_t*)dst, 0, (int*)nullptr);
         return hipGetLastError();

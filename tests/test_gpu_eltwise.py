@@ -50,7 +50,7 @@ def test_golden_cases_cover_fused_and_unfused_kernels():
     for j in CASES:
         ep, c, _ = G.eltwise_epilogue(j)
         kinds.add(capi.KERNEL_NAMES[capi.classify_ep_status(lower(c, ONE, c, j["n"], 1, 1, mul_args=c), ep)[1].kernel])
-    assert {"mfma_i8", "mfma_i8_limb"} <= kinds and (kinds & {"tree_i64", "tree_i32"})
+    assert {"mfma_i8", "mfma_i8_limb"} <= kinds and (kinds & {"tree_i64", "tree_i32", "gemv_i32", "gemv_i64"})   # (MFMA and exact-tree kernels)
 
 
 E88 = Qu(8, 8, True, TRN.TCPL, SAT.ZERO)
