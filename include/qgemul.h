@@ -18,7 +18,9 @@
  *     (reference tags include/QuBLAS.h:2346-2359).  W = I + F magnitude bits.  A raw integer r
  *     stands for the real value r * 2^-F.  Storage always has a sign bit (QuBLAS.h:2384-2385).
  *   - Host ("reference") layout of a tensor element: int32_t when 1+W <= 32, int64_t when
- *     1+W <= 64, holding the sign-extended raw value (ArbiInt<N<=64>, QuBLAS.h:347-353).  A complex
+ *     1+W <= 64, holding the sign-extended raw value (ArbiInt<N<=64>, QuBLAS.h:347-353); for
+ *     65 <= 1+W <= 128 — C only — two little-endian uint64_t words, 8-byte aligned, the upper one
+ *     carrying the sign (ArbiInt<N>64> is std::array<uint64_t, ceil(N/64)>, QuBLAS.h:572-573).  A complex
  *     element is the C struct { real; imag; } of those (QuBLAS.h:2512-2513).  Matrices are
  *     column-major, element (i,j) at i + j*ld (QuBLAS.h:2680-2692).
  *   - Mode codes are the reference's numeric values (QuBLAS.h:1986-1999, :2209-2225).
@@ -163,7 +165,8 @@ enum {
 enum {
     QG_OK = 0,
     QG_EINVAL = -1,       /* malformed descriptor / null pointer / bad size */
-    QG_EUNSUPPORTED = -2, /* e.g. WRP::TCPL_SAT, an intermediate wider than 62 bits (the unrounded product of two operands: 64) */
+    QG_EUNSUPPORTED = -2, /* e.g. WRP::TCPL_SAT, an intermediate wider than 120 bits (unrounded products: 127), an operand element wider
+                             than 64 storage bits, a combination the reference itself cannot compile or computes as a width artefact */
     QG_EHIP = -3,         /* a HIP runtime call failed; qgemul_last_hip_error() has the code */
     QG_ERCCL = -4,
     QG_ERANGE = -5,       /* QG_OPT_CHECK_RANGE: an input raw value is outside its format */
@@ -201,7 +204,9 @@ enum {
     QG_KERNEL_TREE_CPLX_I32 = 6,/* class T, complex, K = 2^p and 32-bit intermediates */
     QG_KERNEL_MFMA_CPLX = 7,    /* class L, complex: four real int8-limb dot products on MFMA + one combine pass */
     QG_KERNEL_GEMV_I32 = 8,     /* class T, N = 1 (batched Qreduce / GEMV), K = 2^p >= 16, 32-bit values: one wave per row (or per 256/K rows) */
-    QG_KERNEL_GEMV_I64 = 9      /* the same with 64-bit tree values on elements of at most 32 storage bits (32-bit words, wide level types) */
+    QG_KERNEL_GEMV_I64 = 9,     /* the same with 64-bit tree values on elements of at most 32 storage bits (32-bit words, wide level types) */
+    QG_KERNEL_TREE_I128 = 10    /* class T with intermediates / level formats / C beyond 62 bits (up to 120): the general tree kernel on
+                                   128-bit values — the reference's multi-word ArbiInt<N > 64>, QuBLAS.h:566-912; real or complex */
 };
 
 /* ---- descriptor analysis: pure host code, works without a GPU ---- */
@@ -366,9 +371,41 @@ int qgemul_run_epc(const qgemul_desc* d, const qgemul_epilogue_cplx* ep, void* D
  * codes and per-thread caching as qgemul_run (one context, plan and set of grow-only buffers per device of the list;
  * qgemul_run_release() frees them); opts->device is ignored.  A device may appear more than once in the list (two contexts
  * on one card: how the partition / reassembly logic is tested on a one-GPU box).  n <= 16.  Real and complex, any class.
- * (Multi-PROCESS sharding — one rank per GPU, RCCL gather — is qublas_amd/dist.py and bench.py; QG_ERCCL is reserved for a
- * library-owned RCCL transport and is not returned by this version.) */
+ * (Multi-PROCESS sharding — one rank per GPU, the library-owned RCCL gather — is qgemul_comm_* below.) */
 int qgemul_run_sharded(const qgemul_desc* d, void* C, const void* A, const void* B, const qgemul_opts* o, const int* devices, int n);
+
+/* ---- one process per GPU: the library-owned RCCL gather (SURVEY.md 8-e, 8-b "library owns ... RCCL comms") ----
+ * Rank r holds the packed operands of ITS band of rows (a plan for rows_r x N x K, B replicated), runs qgemul_execute on its
+ * context, and the ONE exchange step of the path moves the packed C bands to the root rank, which unpacks each band at its row
+ * offset (qgemul_unpack_c on a plan of the band's shape, destination pointer advanced by row0 elements, ld = the full M).
+ * The reference has no counterpart (no communication of any kind).  RCCL is bound at the first of these calls (the process's
+ * own librccl if one is loaded — a PyTorch process keeps ONE RCCL —, else librccl.so.1): single-GPU users never load it.
+ *   qgemul_comm_unique_id   rank 0 makes the 128-byte id (ncclGetUniqueId); the caller hands it to the other ranks by any means
+ *                           it has (MPI, a file, a TCP store): the only rendezvous the library needs
+ *   qgemul_comm_create      ncclCommInitRank on the context's device (collective: every rank calls it)
+ *   qgemul_gather_packed_c  asynchronous.  The band was produced on the context's stream; it travels on the communicator's own
+ *                           stream (grouped ncclSend / ncclRecv of bytes), so the next GEMM may run meanwhile.  On the root,
+ *                           recv[r] / recv_bytes[r] = where rank r's band lands (recv[root] may equal `send`: no copy);
+ *                           elsewhere they are ignored.  A shard cut into row chunks = one call per chunk.
+ *   qgemul_comm_fence       the context's stream waits (on the device) for the gathers issued so far: call it before work that
+ *                           overwrites a buffer a gather still reads / before the root unpacks
+ *   qgemul_comm_sync        the host waits for them
+ *   qgemul_comm_barrier / qgemul_comm_max_f64   every rank's streams drained / the maximum of one double over the ranks
+ *                           (timing of a multi-rank run without any other communication library)
+ * Errors: QG_ERCCL, qgemul_last_rccl_error() = the ncclResult_t (-1: no usable librccl). */
+typedef struct qgemul_comm qgemul_comm;
+#define QG_COMM_ID_BYTES 128
+int qgemul_comm_unique_id(void* id_out);
+int qgemul_comm_create(qgemul_ctx* c, int nranks, int rank, const void* unique_id, qgemul_comm** out);
+void qgemul_comm_destroy(qgemul_comm* m);
+int qgemul_comm_info(const qgemul_comm* m, int* nranks, int* rank, int* rccl_version);   /* ncclCommCount, ncclCommUserRank, ncclGetVersion */
+int qgemul_gather_packed_c(qgemul_comm* m, const void* send, size_t send_bytes, void* const* recv, const size_t* recv_bytes, int root);
+int qgemul_comm_fence(qgemul_comm* m);
+int qgemul_comm_sync(qgemul_comm* m);
+int qgemul_comm_barrier(qgemul_comm* m);
+int qgemul_comm_max_f64(qgemul_comm* m, double* inout);
+int qgemul_last_rccl_error(void);
+int qgemul_ctx_device(const qgemul_ctx* c);   /* the HIP device ordinal of a context */
 
 /* ---- BitStream export of the result tensor ----
  * What  BitStream<tensorProcessT, elemProcessT>(C)  returns in the reference (QuBLAS.h:4811-4827; demo main.cpp:9-18):

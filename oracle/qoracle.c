@@ -17,8 +17,9 @@
  * so the GEMM-level composition is "parity unpinned by reference tests" and pinned by (b) only.
  *
  * Every intermediate is held in __int128, so the restatement is exact for any expression whose
- * intermediates stay below 2^120; wider expressions are rejected (the reference would use its
- * multi-word ArbiInt<N>64> there, QuBLAS.h:566-912).
+ * intermediates stay below 2^120 (unrounded products: 2^127); the wide part of that range — values the
+ * reference keeps in its multi-word ArbiInt<N>64>, QuBLAS.h:566-912 — is pinned by tests/golden/ref_wide_*
+ * (oracle/ref_cases_wide.cpp).  Wider expressions are outside it.
  */
 #include "../include/qgemul.h"
 
@@ -61,12 +62,46 @@ static qi qo_round(qi x, int d, int mode)
     }
 }
 
-/* intConvert<I,F,S,OfMode>::convert, QuBLAS.h:2227-2334 */
-static qi qo_overflow(qi x, qfmt f)
+/*
+ * Width (in bits) of the ArbiInt that fracConvert<from,to,QuMode> returns for an N-bit input: staticShiftLeft / Right change
+ * the width by the shift (QuBLAS.h:1485-1701); the four RND modes (and CONV) end in `Xh + ArbiInt<1>`, one bit more
+ * (:2032, operator+ :917-938); TRN::TCPL / TRN::SMGN keep N - d (:2166, :2175-2178).
+ */
+static int qo_round_width(int N, int d, int mode)
+{
+    if (d <= 0) return N - d;
+    int w = N - d < 1 ? 1 : N - d;
+    return (mode == QG_TRN_TCPL || mode == QG_TRN_SMGN) ? w : w + 1;
+}
+
+/*
+ * The saturating modes compare the value with the target's bounds (`val > floor`, `val < ceil`, QuBLAS.h:2239-2250).  When the
+ * value is a MULTI-WORD ArbiInt (more than 64 bits wide as a TYPE) and the target's storage fits one word, that comparison is
+ * operator<=>(ArbiInt<N > 64>, ArbiInt<M <= 64>) (:1781-1793): the upper words are compared with the bound's sign extension
+ * and then the LOW word is compared AS A SIGNED 64-bit number — so a value in [2^63, 2^64) or [-2^64, -2^63) passes for one of
+ * the opposite sign and is neither above the maximum nor below the minimum; it is then narrowed by ArbiInt<M>(val), which keeps
+ * the low word (:436-441; int32_t storage for M <= 32).  Everything else agrees with the arithmetic definition.  This is what a
+ * user of the reference gets (tests/golden/ref_wide_*: the tables hold values in those bands), so it is restated, not "fixed".
+ */
+static int qo_ref_cmp(qi v, qi bound)   /* sign of (v <=> bound) as the reference computes it for a multi-word v, one-word bound */
+{
+    int64_t hi = (int64_t)(v >> 64), lo = (int64_t)(uint64_t)(qu)v, ext = bound < 0 ? -1 : 0;
+    if (hi != ext) return hi < ext ? -1 : 1;
+    return lo < (int64_t)bound ? -1 : (lo > (int64_t)bound ? 1 : 0);
+}
+
+/* intConvert<I,F,S,OfMode>::convert, QuBLAS.h:2227-2334; nin = width of the incoming ArbiInt type (0: a one-word value) */
+static qi qo_overflow_n(qi x, qfmt f, int nin)
 {
     int W = (int)f.I + (int)f.F;
     qi maxv = qo_pow2(W) - 1;                  /* ArbiInt<1+W>::maximum() */
     qi minv = f.S ? -qo_pow2(W) : 0;           /* minimum() or 0 */
+    if (nin > 64 && 1 + W <= 64 && f.O <= QG_SAT_SMGN) {
+        qi lo = f.O == QG_SAT_SMGN ? (f.S ? -maxv : 0) : minv;
+        if (qo_ref_cmp(x, maxv) > 0) return f.O == QG_SAT_ZERO ? 0 : maxv;
+        if (qo_ref_cmp(x, lo) < 0) return f.O == QG_SAT_ZERO ? 0 : lo;
+        return 1 + W <= 32 ? (qi)(int32_t)(uint32_t)(qu)x : (qi)(int64_t)(uint64_t)(qu)x;   /* ArbiInt<M>(val): the low word */
+    }
     switch (f.O) {
     case QG_SAT_TCPL:                                                           /* :2239-2250 */
         return x > maxv ? maxv : (x < minv ? minv : x);
@@ -87,6 +122,8 @@ static qi qo_overflow(qi x, qfmt f)
         return x; /* WRP::TCPL_SAT: stub returning its input, :2336-2344 (callers reject it) */
     }
 }
+static qi qo_overflow(qi x, qfmt f) { return qo_overflow_n(x, f, 0); }
+static int qo_sbits(qfmt f) { return 1 + (int)f.I + (int)f.F; }
 
 static inline int qo_same(qfmt a, qfmt b)
 {
@@ -98,13 +135,16 @@ static inline int qo_same(qfmt a, qfmt b)
 static qi qo_cvt(qi x, qfmt from, qfmt to)
 {
     if (qo_same(from, to)) return x;
-    return qo_overflow(qo_round(x, (int)from.F - (int)to.F, to.Q), to);
+    int d = (int)from.F - (int)to.F;
+    return qo_overflow_n(qo_round(x, d, to.Q), to, qo_round_width(qo_sbits(from), d, to.Q));
 }
 
 /* Qmul_s::mul, QuBLAS.h:3152-3170: full product, fracConvert<Fa+Fb -> Fr>, intConvert */
 static qi qo_mul(qi a, qfmt fa, qi b, qfmt fb, qfmt r)
 {
-    return qo_overflow(qo_round(a * b, (int)fa.F + (int)fb.F - (int)r.F, r.Q), r);
+    int d = (int)fa.F + (int)fb.F - (int)r.F;
+    /* operator*: an N-bit by an M-bit integer gives N + M bits (QuBLAS.h:1186-1207) */
+    return qo_overflow_n(qo_round(a * b, d, r.Q), r, qo_round_width(qo_sbits(fa) + qo_sbits(fb), d, r.Q));
 }
 
 /* Qadd_s::add / Qsub_s::sub, QuBLAS.h:3185-3203 / :3219-3234: align to max frac, add, convert */
@@ -113,7 +153,10 @@ static qi qo_addsub(qi a, qfmt fa, qi b, qfmt fb, qfmt r, int sub)
     int fm = fa.F > fb.F ? fa.F : fb.F;
     qi x = qo_shl(a, fm - fa.F), y = qo_shl(b, fm - fb.F);
     qi s = sub ? x - y : x + y;
-    return qo_overflow(qo_round(s, fm - (int)r.F, r.Q), r);
+    /* the aligned operands are N + shift bits wide, their sum / difference one bit more than the wider one (:914-1010) */
+    int na = qo_sbits(fa) + fm - fa.F, nb = qo_sbits(fb) + fm - fb.F;
+    int n = (na > nb ? na : nb) + 1;
+    return qo_overflow_n(qo_round(s, fm - (int)r.F, r.Q), r, qo_round_width(n, fm - (int)r.F, r.Q));
 }
 
 /* format of the value entering the tree, per part */
@@ -184,7 +227,13 @@ static qi qo_tree(qi* buf, int64_t len, qfmt fin, const qfmt* level_add, const q
 
 /* ---- host ("reference") element layout: ArbiInt<N<=32> is int32_t, <=64 int64_t
  *      (QuBLAS.h:353); a complex element is struct { real; imag; } (:2512-2513) ---- */
-static int qo_sbytes(qfmt f) { return (1 + (int)f.I + (int)f.F) <= 32 ? 4 : 8; }
+/* ArbiInt<N > 64> is a little-endian std::array<uint64_t, ceil(N/64)> whose top word carries the sign (QuBLAS.h:572-573,
+ * :635-638): 16 bytes, 8-byte aligned, for 65 .. 128 storage bits (wider elements are outside this restatement). */
+static int qo_sbytes(qfmt f)
+{
+    int b = 1 + (int)f.I + (int)f.F;
+    return b <= 32 ? 4 : b <= 64 ? 8 : 16;
+}
 
 typedef struct { int size, off[2], sb[2]; } qo_layout;
 
@@ -195,8 +244,9 @@ static qo_layout qo_elem_layout(const qfmt f[2], int is_complex)
     L.off[0] = 0;
     if (!is_complex) { L.sb[1] = 0; L.off[1] = 0; L.size = L.sb[0]; return L; }
     L.sb[1] = qo_sbytes(f[1]);
-    int al = L.sb[0] > L.sb[1] ? L.sb[0] : L.sb[1];
-    L.off[1] = (L.sb[0] + L.sb[1] - 1) / L.sb[1] * L.sb[1];
+    int a0 = L.sb[0] > 8 ? 8 : L.sb[0], a1 = L.sb[1] > 8 ? 8 : L.sb[1];   /* alignment of int32_t / int64_t / uint64_t[2] */
+    int al = a0 > a1 ? a0 : a1;
+    L.off[1] = (L.sb[0] + a1 - 1) / a1 * a1;
     L.size = (L.off[1] + L.sb[1] + al - 1) / al * al;
     return L;
 }
@@ -204,12 +254,15 @@ static qo_layout qo_elem_layout(const qfmt f[2], int is_complex)
 static inline qi qo_load(const char* p, int sb)
 {
     if (sb == 4) { int32_t v; memcpy(&v, p, 4); return v; }
-    int64_t v; memcpy(&v, p, 8); return v;
+    if (sb == 8) { int64_t v; memcpy(&v, p, 8); return v; }
+    uint64_t w[2]; memcpy(w, p, 16);
+    return (qi)(((qu)w[1] << 64) | (qu)w[0]);
 }
 static inline void qo_store(char* p, int sb, qi x)
 {
     if (sb == 4) { int32_t v = (int32_t)x; memcpy(p, &v, 4); }
-    else { int64_t v = (int64_t)x; memcpy(p, &v, 8); }
+    else if (sb == 8) { int64_t v = (int64_t)x; memcpy(p, &v, 8); }
+    else { uint64_t w[2] = {(uint64_t)(qu)x, (uint64_t)((qu)x >> 64)}; memcpy(p, w, 16); }
 }
 
 int qoracle_elem_bytes(const qfmt* f2, int is_complex)
@@ -358,6 +411,18 @@ int64_t qoracle_convert128(int64_t hi, uint64_t lo, qfmt from, qfmt to)
 {
     qi x = (qi)(((qu)(uint64_t)hi << 64) | (qu)lo);
     return (int64_t)qo_cvt(x, from, to);
+}
+/* ---- the same primitives on values of up to 128 bits: w = {low word, high word (signed)} ---- */
+static inline qi qo_from_w(const uint64_t w[2]) { return (qi)(((qu)w[1] << 64) | (qu)w[0]); }
+static inline void qo_to_w(qi x, uint64_t w[2]) { w[0] = (uint64_t)(qu)x; w[1] = (uint64_t)((qu)x >> 64); }
+void qoracle_convert_w(const uint64_t x[2], qfmt from, qfmt to, uint64_t y[2]) { qo_to_w(qo_cvt(qo_from_w(x), from, to), y); }
+void qoracle_mul_w(const uint64_t a[2], qfmt fa, const uint64_t b[2], qfmt fb, qfmt r, uint64_t y[2])
+{
+    qo_to_w(qo_mul(qo_from_w(a), fa, qo_from_w(b), fb, r), y);
+}
+void qoracle_add_w(const uint64_t a[2], qfmt fa, const uint64_t b[2], qfmt fb, qfmt r, int sub, uint64_t y[2])
+{
+    qo_to_w(qo_addsub(qo_from_w(a), fa, qo_from_w(b), fb, r, sub), y);
 }
 int64_t qoracle_round(int64_t x, int d, int mode) { return (int64_t)qo_round(x, d, mode); }
 int64_t qoracle_overflow(int64_t x, qfmt f) { return (int64_t)qo_overflow(x, f); }
@@ -520,8 +585,8 @@ int64_t qoracle_synth(qfmt f, uint64_t seed, int dist, uint64_t elem, int part)
     if (bits <= 0) return 0;
     uint64_t r = qo_rand(seed, elem * 2 + (uint64_t)part);
     uint64_t v = bits >= 64 ? r : (r >> (64 - bits));
-    int64_t lo = f.S ? -((int64_t)1 << b) : 0;
-    return lo + (int64_t)v;
+    uint64_t lo = f.S ? (uint64_t)0 - ((uint64_t)1 << b) : 0;   /* unsigned arithmetic: well defined for b = 63 too */
+    return (int64_t)(lo + v);
 }
 
 /* fill a tight host-layout tensor of n elements */

@@ -69,6 +69,13 @@ def lib() -> C.CDLL:
         L.qoracle_bitstream_cplx.argtypes = [qfmt, qfmt, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_char_p]
         L.qoracle_bitstream.restype = C.c_int
         L.qoracle_bitstream.argtypes = [qfmt, C.c_int64, C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_char_p]
+        pw = C.POINTER(C.c_uint64)
+        L.qoracle_convert_w.restype = None
+        L.qoracle_convert_w.argtypes = [pw, qfmt, qfmt, pw]
+        L.qoracle_mul_w.restype = None
+        L.qoracle_mul_w.argtypes = [pw, qfmt, pw, qfmt, qfmt, pw]
+        L.qoracle_add_w.restype = None
+        L.qoracle_add_w.argtypes = [pw, qfmt, pw, qfmt, qfmt, C.c_int, pw]
         L.qoracle_elem_bytes.restype = C.c_int
         L.qoracle_elem_bytes.argtypes = [C.POINTER(qfmt), C.c_int]
         L.qoracle_imag_offset.restype = C.c_int
@@ -77,13 +84,66 @@ def lib() -> C.CDLL:
     return _lib
 
 
+WIDE = np.dtype([("lo", "<u8"), ("hi", "<i8")])   # ArbiInt<N > 64>: two little-endian words, the top one carries the sign (QuBLAS.h:572-573)
+
+
+def _part_dtype(nbytes: int):
+    return "<i4" if nbytes == 4 else "<i8" if nbytes == 8 else WIDE
+
+
 def host_dtype(e) -> np.dtype:
-    """numpy dtype of one host-layout element (structured for complex)."""
+    """numpy dtype of one host-layout element (structured for complex, and for parts of more than 64 storage bits)."""
     size, off, (sr, si) = host_layout(e)
     if not isinstance(e, Qcomplex):
-        return np.dtype("<i4" if sr == 4 else "<i8")
-    return np.dtype({"names": ["re", "im"], "formats": ["<i4" if sr == 4 else "<i8", "<i4" if si == 4 else "<i8"],
-                     "offsets": [0, off], "itemsize": size})
+        return np.dtype(_part_dtype(sr))
+    return np.dtype({"names": ["re", "im"], "formats": [_part_dtype(sr), _part_dtype(si)], "offsets": [0, off], "itemsize": size})
+
+
+def to_host(values, e: Qu) -> np.ndarray:
+    """Python integers (any size) -> a host-layout array of a REAL element type"""
+    dt = host_dtype(e)
+    if dt != WIDE:
+        return np.asarray([int(v) for v in values], dtype=dt)
+    out = np.zeros(len(values), dtype=WIDE)
+    for i, v in enumerate(values):
+        v = int(v)
+        out[i] = (v & (2**64 - 1), v >> 64)
+    return out
+
+
+def from_host(arr: np.ndarray) -> list:
+    """a real host-layout array -> Python integers"""
+    if arr.dtype == WIDE:
+        return [(int(h) << 64) | int(l) for l, h in zip(arr["lo"], arr["hi"])]
+    return [int(v) for v in arr]
+
+
+def _w(v: int):
+    v = int(v)
+    return (C.c_uint64 * 2)(v & (2**64 - 1), (v >> 64) & (2**64 - 1))
+
+
+def _unw(w) -> int:
+    v = (int(w[1]) << 64) | int(w[0])
+    return v - (1 << 128) if v >> 127 else v
+
+
+def convert_w(x: int, f: Qu, to: Qu) -> int:
+    y = (C.c_uint64 * 2)()
+    lib().qoracle_convert_w(_w(x), f.c(), to.c(), y)
+    return _unw(y)
+
+
+def mul_w(a: int, fa: Qu, b: int, fb: Qu, r: Qu) -> int:
+    y = (C.c_uint64 * 2)()
+    lib().qoracle_mul_w(_w(a), fa.c(), _w(b), fb.c(), r.c(), y)
+    return _unw(y)
+
+
+def add_w(a: int, fa: Qu, b: int, fb: Qu, r: Qu, sub: bool = False) -> int:
+    y = (C.c_uint64 * 2)()
+    lib().qoracle_add_w(_w(a), fa.c(), _w(b), fb.c(), r.c(), int(sub), y)
+    return _unw(y)
 
 
 def _f2(e):

@@ -46,8 +46,8 @@ int64_t synth(uint64_t seed, int dist, uint64_t elem, int part)
     if (bits <= 0) return 0;
     uint64_t r = qrand(seed, elem * 2 + uint64_t(part));
     uint64_t v = bits >= 64 ? r : (r >> (64 - bits));
-    int64_t lo = T::isS ? -(int64_t(1) << b) : 0;
-    return lo + int64_t(v);
+    uint64_t lo = T::isS ? uint64_t(0) - (uint64_t(1) << b) : 0;   // unsigned arithmetic: well defined for b = 63 too
+    return int64_t(lo + v);
 }
 
 // ---- format printing ----
@@ -73,18 +73,61 @@ std::string fmt2_json()
     return "[" + fmt_json<typename parts<T>::re>() + "," + fmt_json<typename parts<T>::im>() + "]";
 }
 
-// raw access
-template <class T>
-void set_raw(T& x, int64_t re, int64_t im)
+// raw access.  ArbiInt<N <= 64> keeps an int32_t / int64_t in .data; ArbiInt<N > 64> a little-endian std::array<uint64_t, n>
+// whose top word carries the sign (QuBLAS.h:566-573, isNegative :635-638).  Values of up to 128 bits travel as __int128.
+using raw_t = __int128;
+template <class A>
+void put_words(A& a, raw_t v)
 {
-    if constexpr (is_cplx<T>) { x.real.data.data = re; x.imag.data.data = im; }
-    else { x.data.data = re; (void)im; }
+    if constexpr (requires { a.data.size(); }) {
+        static_assert(sizeof(a.data) <= 16, "the drivers handle values of at most 128 bits");
+        for (size_t i = 0; i < a.data.size(); ++i) a.data[i] = uint64_t(v >> (64 * i));
+    } else {
+        a.data = decltype(a.data)(v);
+    }
+}
+template <class A>
+raw_t get_words(const A& a)
+{
+    if constexpr (requires { a.data.size(); }) {
+        static_assert(sizeof(a.data) <= 16, "the drivers handle values of at most 128 bits");
+        unsigned __int128 u = 0;
+        for (size_t i = 0; i < a.data.size(); ++i) u |= (unsigned __int128)a.data[i] << (64 * i);
+        if (a.data.size() == 1) return raw_t(int64_t(a.data[0]));
+        return raw_t(u);
+    } else {
+        return raw_t(a.data);
+    }
 }
 template <class T>
-void get_raw(const T& x, int64_t& re, int64_t& im)
+void set_raw(T& x, raw_t re, raw_t im)
 {
-    if constexpr (is_cplx<T>) { re = x.real.data.data; im = x.imag.data.data; }
-    else { re = x.data.data; im = 0; }
+    if constexpr (is_cplx<T>) { put_words(x.real.data, re); put_words(x.imag.data, im); }
+    else { put_words(x.data, re); (void)im; }
+}
+template <class T>
+void get_raw(const T& x, raw_t& re, raw_t& im)
+{
+    if constexpr (is_cplx<T>) { re = get_words(x.real.data); im = get_words(x.imag.data); }
+    else { re = get_words(x.data); im = 0; }
+}
+template <class T>
+void get_raw(const T& x, int64_t& re, int64_t& im)   // (drivers whose values fit 64 bits)
+{
+    raw_t r, i;
+    get_raw(x, r, i);
+    re = int64_t(r);
+    im = int64_t(i);
+}
+// decimal, any magnitude below 2^127 (JSON readers with big integers take it as it is)
+inline std::string dec(raw_t v)
+{
+    if (v == 0) return "0";
+    const bool neg = v < 0;
+    unsigned __int128 u = neg ? -(unsigned __int128)v : (unsigned __int128)v;
+    std::string s;
+    while (u) { s.insert(s.begin(), char('0' + int(u % 10))); u /= 10; }
+    return neg ? "-" + s : s;
 }
 
 // ---- tag lists ----
@@ -275,7 +318,7 @@ void run_case(const char* name, const Inputs& in, FILE* out)
         set_raw(B[e], re, im);
     }
 
-    std::vector<int64_t> C(M * N * (cx ? 2 : 1));
+    std::vector<raw_t> C(M * N * (cx ? 2 : 1));
     std::vector<EA> arow(K);
     std::vector<EB> bcol(K);
     for (size_t j = 0; j < N; ++j) {
@@ -283,7 +326,7 @@ void run_case(const char* name, const Inputs& in, FILE* out)
         for (size_t i = 0; i < M; ++i) {
             for (size_t k = 0; k < K; ++k) arow[k] = TA ? A[k + i * K] : A[i + k * M];
             EC c = ref_dot<EA, EB, EC, MulList, AddList, K>(arow, bcol);
-            int64_t re, im;
+            raw_t re, im;
             get_raw(c, re, im);
             if (cx) { C[2 * (i + j * M)] = re; C[2 * (i + j * M) + 1] = im; }
             else C[i + j * M] = re;
@@ -308,7 +351,7 @@ void run_case(const char* name, const Inputs& in, FILE* out)
         std::fprintf(out, "]},\n");
     }
     std::fprintf(out, " \"C\":[");
-    for (size_t e = 0; e < C.size(); ++e) std::fprintf(out, "%s%lld", e ? "," : "", (long long)C[e]);
+    for (size_t e = 0; e < C.size(); ++e) std::fprintf(out, "%s%s", e ? "," : "", dec(C[e]).c_str());
     std::fprintf(out, "]}\n");
 }
 

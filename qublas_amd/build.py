@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["qg_api.hip", "qg_pack.hip", "qg_eltwise.hip", "qg_tree.hip", "qg_tree_fast.hip", "qg_tree64.hip", "qg_tree_cplx.hip", "qg_gemv.hip", "qg_mfma.hip", "qg_mfma_pp.hip", "qg_mfma_ppl.hip", "qg_plan.cpp"]
+SOURCES = ["qg_api.hip", "qg_pack.hip", "qg_eltwise.hip", "qg_tree.hip", "qg_tree_fast.hip", "qg_tree64.hip", "qg_tree_cplx.hip", "qg_gemv.hip", "qg_mfma.hip", "qg_mfma_pp.hip", "qg_mfma_ppl.hip", "qg_comm.hip", "qg_plan.cpp"]
 HEADERS = ["qg_ops.h", "qg_plan.h", "qg_kernels.h", "qg_step_all.h", "qg_eltwise.h", "qg_eltwise_args.h", "qg_fix.h", os.path.join("..", "..", "include", "qgemul.h")]
 LIB = os.path.join(HERE, "libqugemm.so")
 # the same sources with -DQG_DIAG: environment A/B switches and the ablation kernel variants (results may be WRONG by
@@ -47,7 +47,7 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
     if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]   # (RCCL is bound with dlopen: qg_comm.hip)
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -26,7 +26,7 @@ OPT_FORCE_TREE, OPT_CHECK_RANGE, OPT_GENERIC_TREE, OPT_RUNTIME_MODES, OPT_FUSED_
 OPT_GENERIC_LAYOUT, OPT_LOCKSTEP_TILES, OPT_ARITHMETIC_CONV, OPT_ALL_DEVICES = 64, 128, 256, 512
 OPERAND_A, OPERAND_B, OPERAND_C = 0, 1, 2
 BITS_ASCII, BITS_PACKED = 0, 1
-KERNEL_NAMES = {0: "none", 1: "mfma_i8", 2: "mfma_i8_limb", 3: "tree_i32", 4: "tree_i64", 5: "tree_cplx", 6: "tree_cplx_i32", 7: "mfma_cplx", 8: "gemv_i32", 9: "gemv_i64"}
+KERNEL_NAMES = {0: "none", 1: "mfma_i8", 2: "mfma_i8_limb", 3: "tree_i32", 4: "tree_i64", 5: "tree_cplx", 6: "tree_cplx_i32", 7: "mfma_cplx", 8: "gemv_i32", 9: "gemv_i64", 10: "tree_i128"}
 
 EXPORTS = [
     "qgemul_classify", "qgemul_strerror", "qgemul_abi_version", "qgemul_last_hip_error", "qgemul_run",
@@ -37,6 +37,8 @@ EXPORTS = [
     "qgemul_classify_ep", "qgemul_plan_create_ep", "qgemul_packed_e_bytes", "qgemul_pack_e", "qgemul_execute_ep",
     "qgemul_time_execute_ep", "qgemul_run_ep", "qgemul_plan_fuses_epilogue", "qgemul_classify_epc", "qgemul_plan_create_epc", "qgemul_run_epc",
     "qgemul_bitstream_bytes", "qgemul_export_bitstream", "qgemul_run_release", "qgemul_run_sharded", "qgemul_execute_host_c", "qgemul_plan_stores_host_c",
+    "qgemul_comm_unique_id", "qgemul_comm_create", "qgemul_comm_destroy", "qgemul_comm_info", "qgemul_gather_packed_c", "qgemul_comm_fence",
+    "qgemul_comm_sync", "qgemul_comm_barrier", "qgemul_comm_max_f64", "qgemul_last_rccl_error", "qgemul_ctx_device",
 ]
 
 _lib = None
@@ -106,6 +108,18 @@ def lib() -> C.CDLL:
         L.qgemul_execute_ep.argtypes = [vp, vp, vp, vp, pa]
         L.qgemul_time_execute_ep.argtypes = [vp, vp, vp, vp, pa, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.qgemul_run_ep.argtypes = [pd, pe, vp, vp, vp, C.POINTER(vp), C.POINTER(qgemul_opts)]
+        L.qgemul_comm_unique_id.argtypes = [vp]
+        L.qgemul_comm_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+        L.qgemul_comm_destroy.argtypes = [vp]
+        L.qgemul_comm_destroy.restype = None
+        pi = C.POINTER(C.c_int)
+        L.qgemul_comm_info.argtypes = [vp, pi, pi, pi]
+        L.qgemul_gather_packed_c.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_int]
+        L.qgemul_comm_fence.argtypes = [vp]
+        L.qgemul_comm_sync.argtypes = [vp]
+        L.qgemul_comm_barrier.argtypes = [vp]
+        L.qgemul_comm_max_f64.argtypes = [vp, C.POINTER(C.c_double)]
+        L.qgemul_ctx_device.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -218,6 +232,62 @@ class Context:
 
     def __exit__(self, *a):
         self.close()
+
+
+class Comm:
+    """The library-owned RCCL communicator of one rank (include/qgemul.h, qgemul_comm_*): the gather of packed C bands."""
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        _chk_rccl(lib().qgemul_comm_unique_id(buf), "qgemul_comm_unique_id")
+        return buf.raw
+
+    def __init__(self, ctx: "Context", nranks: int, rank: int, unique_id: bytes):
+        assert len(unique_id) == Comm.ID_BYTES
+        self.h = C.c_void_p()
+        self.nranks, self.rank = nranks, rank
+        self._id = C.create_string_buffer(unique_id, Comm.ID_BYTES)
+        _chk_rccl(lib().qgemul_comm_create(ctx.h, nranks, rank, self._id, C.byref(self.h)), "qgemul_comm_create")
+
+    def info(self):
+        """(ranks per ncclCommCount, this rank per ncclCommUserRank, ncclGetVersion code)"""
+        n, r, v = C.c_int(), C.c_int(), C.c_int()
+        _chk_rccl(lib().qgemul_comm_info(self.h, C.byref(n), C.byref(r), C.byref(v)), "qgemul_comm_info")
+        return n.value, r.value, v.value
+
+    def gather(self, send_ptr: int, send_bytes: int, recv_ptrs=None, recv_bytes=None, root: int = 0):
+        rp = rb = None
+        if recv_ptrs is not None:
+            rp = (C.c_void_p * self.nranks)(*[p or None for p in recv_ptrs])
+            rb = (C.c_size_t * self.nranks)(*recv_bytes)
+        _chk_rccl(lib().qgemul_gather_packed_c(self.h, C.c_void_p(send_ptr), send_bytes, rp, rb, root), "qgemul_gather_packed_c")
+
+    def fence(self):
+        _chk_rccl(lib().qgemul_comm_fence(self.h), "qgemul_comm_fence")
+
+    def sync(self):
+        _chk_rccl(lib().qgemul_comm_sync(self.h), "qgemul_comm_sync")
+
+    def barrier(self):
+        _chk_rccl(lib().qgemul_comm_barrier(self.h), "qgemul_comm_barrier")
+
+    def max_f64(self, v: float) -> float:
+        x = C.c_double(v)
+        _chk_rccl(lib().qgemul_comm_max_f64(self.h, C.byref(x)), "qgemul_comm_max_f64")
+        return x.value
+
+    def close(self):
+        if self.h:
+            lib().qgemul_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def _chk_rccl(st: int, what: str):
+    if st == QG_ERCCL:
+        raise QgemulError(st, f"{what} (ncclResult {lib().qgemul_last_rccl_error()})")
+    _chk(st, what)
 
 
 class Plan:

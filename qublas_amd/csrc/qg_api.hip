@@ -261,7 +261,7 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
         }
         const int mn = LA < LB ? LA : LB;
         cfg = qg_mfma_pick(LA, LB, d->M * parts, d->N * parts, (ep ? QG_OPT_LOCKSTEP_TILES : 0u) | flags);   // (the fused / unfused element-wise chain keeps the kernel it was measured on)
-        if (cfg.variant && (int64_t)mn * d->K <= (1ll << 17) - 1)
+        if (cfg.variant && (int64_t)mn * d->K <= (1ll << 17) - 1 && !an->wide)   // (wide plans: the kernels' own epilogues are 64-bit; the composite plan's combine pass is not)
             kernel = d->is_complex ? QG_KERNEL_MFMA_CPLX : ((LA == 1 && LB == 1) ? QG_KERNEL_MFMA_I8 : QG_KERNEL_MFMA_I8_LIMB);
         // (one output column whose tree the one-column kernels can walk: those stream A once at HBM rate; a composite plan would read
         // it once per limb group and write slabs — the batched Qreduce of 32-bit words with exact level types stays there)
@@ -269,7 +269,9 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
                  comp_geometry(LA, LB, d, flags, &comp, &cfg)) {
             // more than 3 limbs, or K beyond the int32 accumulators' exact range: limb groups x k-chunks on the same kernels
             kernel = (LA == 1 && LB == 1) ? QG_KERNEL_MFMA_I8 : QG_KERNEL_MFMA_I8_LIMB;
-            snprintf(info->reason, sizeof info->reason, "linear class: %d k-chunk(s) x %d x %d limb groups on the MFMA kernels, exact combine", comp.nc, comp.ga, comp.gb);
+            comp.wide = an->wide;
+            snprintf(info->reason, sizeof info->reason, "linear class: %d k-chunk(s) x %d x %d limb groups on the MFMA kernels, exact %s combine", comp.nc, comp.ga, comp.gb,
+                     comp.wide ? "128-bit" : "64-bit");
         } else {
             LA = LB = 0;
             snprintf(info->reason, sizeof info->reason, "linear class, but limbs/K outside the MFMA kernels' range: tree kernel");
@@ -279,6 +281,9 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     pc->N = d->N;
     pc->parts = parts;
     pc->cbytes = pow2_bytes(sbits(d->c));
+    // (a multi-word value in the band the reference mis-compares comes out as its low WORD — int32_t / int64_t — whatever C's
+    // format says: such plans keep the host element's width in packed C)
+    if (an->band && pc->cbytes < (hc->sb[0] > hc->sb[1] ? hc->sb[0] : hc->sb[1])) pc->cbytes = hc->sb[0] > hc->sb[1] ? hc->sb[0] : hc->sb[1];
     pc->ldc = d->M;
     pc->elem_bytes = hc->size;
     for (int p = 0; p < 2; ++p) { pc->off[p] = hc->off[p]; pc->sb[p] = hc->sb[p]; }
@@ -303,7 +308,7 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
         }
     } else {
         const bool fast = !(flags & QG_OPT_GENERIC_TREE);
-        kernel = d->is_complex ? ((an->cplx_fast_ok && fast) ? QG_KERNEL_TREE_CPLX_I32 : QG_KERNEL_TREE_CPLX)
+        kernel = an->wide ? QG_KERNEL_TREE_I128 : d->is_complex ? ((an->cplx_fast_ok && fast) ? QG_KERNEL_TREE_CPLX_I32 : QG_KERNEL_TREE_CPLX)
                                : ((an->gemv_ok && fast) ? QG_KERNEL_GEMV_I32 : (an->gemv_wide_ok && fast) ? QG_KERNEL_GEMV_I64
                                   : (an->tree_fast_ok && fast) ? QG_KERNEL_TREE_I32 : QG_KERNEL_TREE_I64);
         // the 32-bit tree kernels walk a perfect binary tree: their operands are zero-padded along K to 2^n_levels leaves
@@ -318,6 +323,8 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
         pc->tm = pc->tn = 0;
     }
     info->kernel = kernel;
+    if (kernel == QG_KERNEL_TREE_I128)
+        snprintf(info->reason, sizeof info->reason, "exact tree evaluation on 128-bit values (intermediates of %d bits)", an->max_bits);
     if (kernel == QG_KERNEL_TREE_I32) {
         const int fm = (flags & QG_OPT_RUNTIME_MODES) ? 0 : an->fast_mode;
         snprintf(info->reason, sizeof info->reason, "exact tree evaluation; tree kernel steps: %s",
@@ -386,6 +393,11 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     *pLB = LB;
     *pVar = cfg;
     if (pc_c) *pc_c = *pc;
+    if (ep && an->band) {
+        info->supported = 0;
+        snprintf(info->reason, sizeof info->reason, "element-wise chain after a plan whose C can leave its format (multi-word comparison artefact of the reference)");
+        return QG_EUNSUPPORTED;
+    }
     if (ep) {
         // D replaces C as the stored result: same index space, D's container and host element
         if ((d->is_complex != 0) != (ev->im != nullptr)) {
@@ -576,6 +588,7 @@ int qgemul_ctx_sync(qgemul_ctx* c)
 }
 
 void* qgemul_ctx_stream(qgemul_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int qgemul_ctx_device(const qgemul_ctx* c) { return c ? c->device : -1; }
 
 int qgemul_dev_alloc(qgemul_ctx* c, size_t bytes, void** out)
 {
@@ -1141,6 +1154,10 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
         QG_HIP(qg_launch_tree_generic(p->dev_table, p->desc.is_complex ? 2 : 1, packedA, packedB, packedC, p->desc.M, p->desc.N,
                                       p->desc.K, p->pa, p->pb, pcg, st));
         return QG_OK;
+    case QG_KERNEL_TREE_I128:
+        QG_HIP(qg_launch_tree_generic(p->dev_table, p->desc.is_complex ? 2 : 1, packedA, packedB, packedC, p->desc.M, p->desc.N,
+                                      p->desc.K, p->pa, p->pb, pcg, st, 1));
+        return QG_OK;
     default:
         return QG_EUNSUPPORTED;
     }
@@ -1168,6 +1185,7 @@ int qgemul_export_bitstream(qgemul_plan* p, const void* packedC, int tensor_chun
     const int w = p->desc.is_complex ? result_width(p, 0) + result_width(p, 1) + 4 : result_width(p);
     const int64_t n = p->desc.M * p->desc.N;
     if (w <= 0 || tensor_chunk < 0 || elem_chunk < 0) return QG_EINVAL;
+    if (!p->desc.is_complex && (w > 64 || p->pc.cbytes > 8)) return QG_EUNSUPPORTED;   // (multi-word elements: not exported)
     if (elem_chunk > 0 && w % elem_chunk) return QG_EINVAL;      // the reference throws (QuBLAS.h:4599-4602)
     if (tensor_chunk > 0 && n % tensor_chunk) return QG_EINVAL;  // the reference's loop does not terminate (:4745)
     QG_ON_DEVICE(p->ctx);

@@ -122,7 +122,7 @@ hipError_t qg_launch_lin_combine(const QLinCombine& g, hipStream_t st);
 // exact tree evaluation, any descriptor (real / complex, any K), 64-bit arithmetic
 hipError_t qg_launch_tree_generic(const QTreeTable* dev_table, int parts, const void* A, const void* B, void* C, int64_t M,
                                   int64_t N, int64_t K, const QPackedGeom& pa, const QPackedGeom& pb, const QCGeom& pc,
-                                  hipStream_t st);
+                                  hipStream_t st, int wide = 0);   // wide: 128-bit values (C containers of up to 16 bytes)
 
 // exact tree evaluation, real descriptors with K = 2^p >= 32 and 32-bit intermediates (A, B packed as int32)
 hipError_t qg_launch_tree_fast(const QTreeTable* dev_table, int n_levels, int split_s, int mul24, int mode, const void* A, const void* B,

@@ -419,7 +419,42 @@ __global__ __launch_bounds__(256) void k_lin_combine(QLinCombine g)
     for (int j = 0; j < QG_MAX_SLABS; ++j)
         if (j < g.n_slabs) s += (AccT)(((const SlabT*)g.slab[j])[i]) * ((AccT)1 << g.sh[j]);
     if (g.acc_out) { ((AccT*)g.acc_out)[i] = s; return; }
-    store_container((char*)g.out, i, g.cbytes, (int64_t)qg_step<AccT>(s, g.to_c));
+    if constexpr (sizeof(AccT) == 16) {
+        // wide plans: the reference's multi-word conversion (qg_step_w), containers of up to 16 bytes
+        const qg_i128 r = qg_step_w(s, g.to_c);
+        if (g.cbytes == 16) {
+            ((uint64_t*)g.out)[2 * i] = (uint64_t)(qg_u128)r;
+            ((uint64_t*)g.out)[2 * i + 1] = (uint64_t)((qg_u128)r >> 64);
+        } else {
+            store_container((char*)g.out, i, g.cbytes, (int64_t)r);
+        }
+    } else {
+        store_container((char*)g.out, i, g.cbytes, (int64_t)qg_step<AccT>(s, g.to_c));
+    }
+}
+
+// packed C of a wide plan -> host layout: 16-byte containers are two little-endian words (ArbiInt<65..128>, QuBLAS.h:572-573);
+// one thread per element, rows fastest (the host's order)
+__global__ __launch_bounds__(256) void k_unpack_c_w(QCGeom c, const char* __restrict__ packed, char* __restrict__ dst)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= c.M * c.N * c.parts) return;
+    const int part = (int)(idx / (c.M * c.N));
+    const int64_t e = idx % (c.M * c.N), m = e % c.M, n = e / c.M;
+    const int64_t pi = qg_c_index(c, part, m, n);
+    char* q = dst + (m + n * c.ldc) * c.elem_bytes + c.off[part];
+    uint64_t lo, hi;
+    if (c.cbytes == 16) {
+        lo = ((const uint64_t*)packed)[2 * pi];
+        hi = ((const uint64_t*)packed)[2 * pi + 1];
+    } else {
+        const int64_t v = load_container(packed, pi, c.cbytes);
+        lo = (uint64_t)v;
+        hi = (uint64_t)(v >> 63);
+    }
+    if (c.sb[part] == 4) *(int32_t*)q = (int32_t)lo;
+    else if (c.sb[part] == 8) *(int64_t*)q = (int64_t)lo;
+    else { ((uint64_t*)q)[0] = lo; ((uint64_t*)q)[1] = hi; }
 }
 
 } // namespace
@@ -428,8 +463,11 @@ hipError_t qg_launch_lin_combine(const QLinCombine& g, hipStream_t st)
 {
     if (g.n <= 0) return hipSuccess;
     const int64_t blocks = (g.n + 255) / 256;
-    if (blocks > 0x7fffffffll || g.n_slabs < 1 || g.n_slabs > QG_MAX_SLABS || g.wide) return hipErrorInvalidValue;
-    if (g.slab_bytes == 4) hipLaunchKernelGGL((k_lin_combine<int32_t, int64_t>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    if (blocks > 0x7fffffffll || g.n_slabs < 1 || g.n_slabs > QG_MAX_SLABS) return hipErrorInvalidValue;
+    if (g.wide) {
+        if (g.slab_bytes == 4) hipLaunchKernelGGL((k_lin_combine<int32_t, qg_i128>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_lin_combine<int64_t, qg_i128>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    } else if (g.slab_bytes == 4) hipLaunchKernelGGL((k_lin_combine<int32_t, int64_t>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     else hipLaunchKernelGGL((k_lin_combine<int64_t, int64_t>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     return hipGetLastError();
 }
@@ -536,6 +574,12 @@ hipError_t qg_launch_unpack_c(const QCGeom& c, const void* packed, void* dst, hi
     int64_t blocks = ((c.N + 63) / 64) * ((c.M + 63) / 64) * c.parts;
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
+    if (c.cbytes == 16 || c.sb[0] == 16 || c.sb[1] == 16) {   // wide plans
+        const int64_t n = c.M * c.N * c.parts;
+        if ((n + 255) / 256 > 0x7fffffffll) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_unpack_c_w, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c, (const char*)packed, (char*)dst);
+        return hipGetLastError();
+    }
     const bool no_fast = generic != 0;
     if (!no_fast && c.parts == 1 && c.cbytes == 4 && c.elem_bytes == 4 && c.sb[0] == 4 && c.off[0] == 0 && c.tm > 0 && c.tm % 4 == 0 &&
         ((uintptr_t)packed & 15) == 0 && ((uintptr_t)dst & 3) == 0) {

@@ -29,6 +29,7 @@ struct Ctx {
     int max_bits_np = 1;    // the same, not counting full-precision products before their rounding
     int max_fmt_bits = 1;   // widest storage (1 + W) of any format on the path
     bool raw_product = false;
+    bool band = false;      // a multi-word value in [2^63, 2^64) / [-2^64, -2^63) can reach a one-word target (through())
     void fail(int st, const char* why)
     {
         if (out->status == QG_OK) {
@@ -54,7 +55,10 @@ bool fmt_ok(Ctx& c, qfmt f)
     if (f.Q > QG_TRN_SMGN) { c.fail(QG_EINVAL, "unknown QuMode code"); return false; }
     if (f.O == QG_WRP_TCPL_SAT) { c.fail(QG_EUNSUPPORTED, "WRP::TCPL_SAT is a stub in the reference"); return false; }
     if (f.O > QG_WRP_TCPL_SAT) { c.fail(QG_EINVAL, "unknown OfMode code"); return false; }
-    if (W > 61) { c.fail(QG_EUNSUPPORTED, "format wider than 62 storage bits"); return false; }
+    if (W > 119) { c.fail(QG_EUNSUPPORTED, "format wider than 120 storage bits"); return false; }
+    // ArbiInt<65>::maximum() is -1 (oneBits = 65 % 64 - 1 = 0 selects ~0 for the top word, QuBLAS.h:594-603): every saturating
+    // conversion INTO a format of exactly 65 storage bits is an artefact in the reference (tests/golden/ref_wide_1: Qu<32,32>, Qu<64,0>)
+    if (W == 64) { c.fail(QG_EUNSUPPORTED, "a format of exactly 65 storage bits: ArbiInt<65>::maximum() artefact of the reference"); return false; }
     return true;
 }
 
@@ -80,13 +84,26 @@ QStep make_step(int fromF, qfmt to, bool identity)
     s.W = (int)to.I + (int)to.F;
     s.S = to.S;
     s.identity = identity ? 1 : 0;
-    s.hi = (int64_t)(((I128)1 << s.W) - 1);
-    s.lo = to.S ? -(int64_t)((I128)1 << s.W) : 0;
+    if (s.W <= 62) {   // (wide steps derive their bounds from W and S on the device: qg_overflow_w)
+        s.hi = (int64_t)(((I128)1 << s.W) - 1);
+        s.lo = to.S ? -(int64_t)((I128)1 << s.W) : 0;
+    }
     return s;
 }
 
-// propagate an exact interval (raw values at frac fromF) through round + overflow into `to`
-Rng through(Ctx& c, Rng in, int fromF, qfmt to, bool identity)
+// width of the ArbiInt that fracConvert returns for an n-bit input: shifts change the width by the shift (QuBLAS.h:1485-1701),
+// the RND modes end in `Xh + ArbiInt<1>` — one bit more (:2032) —, TRN::TCPL / TRN::SMGN keep n - d (:2166, :2175-2178)
+int round_width(int n, int d, int Q)
+{
+    if (d <= 0) return n - d;
+    const int w = n - d < 1 ? 1 : n - d;
+    return (Q == QG_TRN_TCPL || Q == QG_TRN_SMGN) ? w : w + 1;
+}
+
+// propagate an exact interval (raw values at frac fromF) through round + overflow into `to`.  nin: width of the ArbiInt TYPE
+// the value has in the reference before this step (0: not tracked — element-wise chains, which stay within 62 bits); st: the
+// step record, whose refcmp this sets.
+Rng through(Ctx& c, Rng in, int fromF, qfmt to, bool identity, int nin = 0, QStep* st = nullptr)
 {
     c.note(in);
     c.raw_product = false;
@@ -100,21 +117,51 @@ Rng through(Ctx& c, Rng in, int fromF, qfmt to, bool identity)
     int d = fromF - (int)to.F;
     Rng r = in;
     if (d <= 0) {
-        if (-d > 100) { c.fail(QG_EUNSUPPORTED, "left shift beyond 100 bits"); return in; }
+        if (-d > 100 || bits_of(in.lo) - d > 126 || bits_of(in.hi) - d > 126) { c.fail(QG_EUNSUPPORTED, "left shift beyond 127 bits"); return in; }
         r.lo = in.lo * ((I128)1 << -d);
         r.hi = in.hi * ((I128)1 << -d);
         c.note(r);
     } else {
-        if (d > 61) { c.fail(QG_EUNSUPPORTED, "rounding shift beyond 61 bits"); return in; }
+        if (d > 119) { c.fail(QG_EUNSUPPORTED, "rounding shift beyond 119 bits"); return in; }
         if ((d == 32 || d == 64) && to.Q <= QG_RND_CONV)
             c.fail(QG_EUNSUPPORTED, "RND over a 32/64-bit shift: reference result is an ArbiInt<32>::allOnes artefact");
+        // RND::CONV of a multi-word value: the reference's floor / ceil construction (QuBLAS.h:2137-2156) returns artefacts (every
+        // RND::CONV table of tests/golden/ref_wide_* with a source wider than 64 bits differs from round-half-to-even)
+        if (to.Q == QG_RND_CONV && nin > 64)
+            c.fail(QG_EUNSUPPORTED, "RND::CONV of a value wider than 64 bits: multi-word artefact of the reference");
         c.exact = false;
         r.lo = in.lo >> d;
         r.hi = (in.hi >> d) + 1;
     }
+    const int nr = nin ? round_width(nin, d, to.Q) : 0;   // type width of what reaches the overflow handling
+    const int mbits = 1 + (int)to.I + (int)to.F;
+    // signed WRP::TCPL from one multi-word type into another of a different width: operator| of two wide integers of different
+    // sizes is ill-formed (QuBLAS.h:1946-1950) — the reference does not compile such a conversion (oracle/ref_cases_wide_probe.log)
+    if (to.O == QG_WRP_TCPL && to.S && mbits > 64 && nr > 64 && nr != mbits)
+        c.fail(QG_EUNSUPPORTED, "signed WRP::TCPL between multi-word types of different widths: the reference does not compile it");
     Rng R = fmt_range(to);
     Rng Re = R;
     if (to.O == QG_SAT_SMGN) Re.lo = to.S ? -R.hi : 0;
+    if (nr > 64 && mbits <= 64 && to.O <= QG_SAT_SMGN) {
+        // a multi-word value compared with one-word bounds: the reference reads the low word as a signed number (operator<=>,
+        // QuBLAS.h:1781-1793) and narrows by keeping the low word (:436-441).  Identical to the arithmetic definition unless the
+        // value lies in [2^63, 2^64) or [-2^64, -2^63); the kernels reproduce it (QStep::refcmp, qg_overflow_w).
+        if (st) st->refcmp = 1;
+        const I128 b63 = (I128)1 << 63, b64 = (I128)1 << 64;
+        if ((r.hi >= b63 && r.lo < b64) || (r.lo < -b63 && r.hi >= -b64)) {
+            // ... reachable: such a value comes out as its low word, whatever the format says (int32_t / int64_t storage)
+            c.exact = false;
+            c.band = true;
+            const I128 full = mbits <= 32 ? ((I128)1 << 31) : ((I128)1 << 63);
+            Rng q = r;
+            if (q.lo < Re.lo) q.lo = Re.lo;
+            if (q.hi > Re.hi) q.hi = Re.hi;
+            if (to.O == QG_SAT_ZERO) { if (q.lo > 0) q.lo = 0; if (q.hi < 0) q.hi = 0; }
+            if (q.lo > -full) q.lo = -full;
+            if (q.hi < full - 1) q.hi = full - 1;
+            return q;
+        }
+    }
     if (r.lo >= Re.lo && r.hi <= Re.hi) return r; // overflow handling is the identity
     c.exact = false;
     if (to.O == QG_WRP_TCPL && !to.S && (int)to.I + (int)to.F == 32)
@@ -156,6 +203,8 @@ struct Val {
     Rng r;
     qfmt f;
 };
+int sbits(qfmt f) { return 1 + (int)f.I + (int)f.F; }   // storage bits = width of the value's ArbiInt type (QuBLAS.h:2384-2385)
+int rng_bits(Rng r) { const int a = bits_of(r.lo), b = bits_of(r.hi); return a > b ? a : b; }
 
 Val do_mul(Ctx& c, Val a, Val b, qfmt res, QNode* node)
 {
@@ -163,8 +212,11 @@ Val do_mul(Ctx& c, Val a, Val b, qfmt res, QNode* node)
     node->q = make_step((int)a.f.F + (int)b.f.F, res, false);
     Val v;
     v.f = res;
+    v.r = fmt_range(res);
+    if (rng_bits(a.r) + rng_bits(b.r) > 127) { c.fail(QG_EUNSUPPORTED, "a product needs more than 127 bits"); return v; }
     c.raw_product = true; // the unrounded product is noted for max_bits only
-    v.r = through(c, mul_rng(a.r, b.r), (int)a.f.F + (int)b.f.F, res, false);
+    // operator*: an N-bit by an M-bit integer gives N + M bits (QuBLAS.h:1186-1207)
+    v.r = through(c, mul_rng(a.r, b.r), (int)a.f.F + (int)b.f.F, res, false, sbits(a.f) + sbits(b.f), &node->q);
     return v;
 }
 
@@ -174,14 +226,21 @@ Val do_addsub(Ctx& c, Val a, Val b, qfmt res, bool sub, QNode* node)
     node->sa = fm - a.f.F;
     node->sb = fm - b.f.F;
     node->q = make_step(fm, res, false);
+    Val v;
+    v.f = res;
+    v.r = fmt_range(res);
+    if (rng_bits(a.r) + node->sa > 125 || rng_bits(b.r) + node->sb > 125) { c.fail(QG_EUNSUPPORTED, "an aligned operand needs more than 126 bits"); return v; }
     Rng x = {a.r.lo * ((I128)1 << node->sa), a.r.hi * ((I128)1 << node->sa)};
     Rng y = {b.r.lo * ((I128)1 << node->sb), b.r.hi * ((I128)1 << node->sb)};
     c.note(x);
     c.note(y);
+    // the aligned operands are N + shift bits wide, their sum / difference one bit more than the wider one (QuBLAS.h:914-1010)
+    const int na = sbits(a.f) + node->sa, nb = sbits(b.f) + node->sb;
+    // operator-(multi-word, one-word) loses the borrow / sign extension of the one-word operand (tests/golden/ref_wide_2:
+    // Qsub(Qu<43,32>, Qu<31,32>) is off by multiples of 2^63): an artefact, rejected
+    if (sub && na > 64 && nb <= 64) c.fail(QG_EUNSUPPORTED, "Qsub of a one-word value from a multi-word one: artefact of the reference's operator-");
     Rng s = sub ? Rng{x.lo - y.hi, x.hi - y.lo} : Rng{x.lo + y.lo, x.hi + y.hi};
-    Val v;
-    v.f = res;
-    v.r = through(c, s, fm, res, false);
+    v.r = through(c, s, fm, res, false, (na > nb ? na : nb) + 1, &node->q);
     return v;
 }
 
@@ -191,7 +250,7 @@ Val do_cvt(Ctx& c, Val a, qfmt to, QStep* st)
     *st = make_step((int)a.f.F, to, id);
     Val v;
     v.f = to;
-    v.r = through(c, a.r, (int)a.f.F, to, id);
+    v.r = through(c, a.r, (int)a.f.F, to, id, sbits(a.f), st);
     return v;
 }
 
@@ -281,7 +340,8 @@ int qg_analyze_ep(qfmt cfmt, const qgemul_epilogue* ep, QEpTable* out, int* max_
 QHostElem qg_host_elem(const qfmt f[2], int is_complex)
 {
     QHostElem L;
-    auto sb = [](qfmt q) { return (1 + (int)q.I + (int)q.F) <= 32 ? 4 : 8; };
+    // int32_t / int64_t (ArbiInt<N <= 64>, QuBLAS.h:353) or two little-endian uint64_t words (ArbiInt<65..128>, :572-573; 8-byte aligned)
+    auto sb = [](qfmt q) { const int b = 1 + (int)q.I + (int)q.F; return b <= 32 ? 4 : b <= 64 ? 8 : 16; };
     L.sb[0] = sb(f[0]);
     L.off[0] = 0;
     if (!is_complex) {
@@ -291,8 +351,9 @@ QHostElem qg_host_elem(const qfmt f[2], int is_complex)
         return L;
     }
     L.sb[1] = sb(f[1]);
-    int al = L.sb[0] > L.sb[1] ? L.sb[0] : L.sb[1];
-    L.off[1] = (L.sb[0] + L.sb[1] - 1) / L.sb[1] * L.sb[1];
+    const int a0 = L.sb[0] > 8 ? 8 : L.sb[0], a1 = L.sb[1] > 8 ? 8 : L.sb[1];
+    const int al = a0 > a1 ? a0 : a1;
+    L.off[1] = (L.sb[0] + a1 - 1) / a1 * a1;
     L.size = (L.off[1] + L.sb[1] + al - 1) / al * al;
     return L;
 }
@@ -350,8 +411,11 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         }
     T.parts = parts;
 
-    for (int p = 0; p < parts; ++p)
+    for (int p = 0; p < parts; ++p) {
         if (!fmt_ok(c, d->a[p]) || !fmt_ok(c, d->b[p]) || !fmt_ok(c, d->c[p])) return;
+        // operand ELEMENTS are one-word values (int32_t / int64_t host elements); products, sums, levels and C may be multi-word
+        if (sbits(d->a[p]) > 64 || sbits(d->b[p]) > 64) { c.fail(QG_EUNSUPPORTED, "operand element wider than 64 storage bits"); return; }
+    }
     const int nslots = !cx ? 1 : (d->cmul == QG_CMUL_TF ? 8 : 6);
     for (int i = 0; i < nslots; ++i)
         if (!fmt_ok(c, d->mul[i])) return;
@@ -425,8 +489,9 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
             // lies inside the root format's range.
             int fp = (int)d->a[0].F + (int)d->b[0].F;
             out->lin.to_c[0] = make_step(fp, d->c[0], false);
+            out->lin.to_c[0].refcmp = T.c_cvt[0].refcmp;   // (the root's type width decides how the reference compares with C's bounds)
             out->lin.to_c[1] = out->lin.to_c[0];
-            if (out->lin.to_c[0].d > 61 || out->lin.to_c[0].d < -61) c.exact = false;
+            if (out->lin.to_c[0].d > 100 || out->lin.to_c[0].d < -100) c.exact = false;
         }
     }
     if (cx) {
@@ -463,7 +528,13 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     // 64-bit kernels: every value within 62 bits, so that sums, alignment shifts and rounding addends stay inside int64 — except
     // the unrounded product of two operands, which is formed exactly by one 64-bit multiply and goes straight into its rounding
     // shift: it may use all of int64 (two signed 32-bit words: |a * b| <= 2^62).  32-bit fixed-point words therefore run.
-    if (c.max_bits_np > 62 || c.max_bits > 64) { c.fail(QG_EUNSUPPORTED, "an intermediate needs more than 62 bits"); return; }
+    // Beyond that ("wide" plans): 128-bit values — the reference's multi-word ArbiInt<N > 64> (QuBLAS.h:566-912) — on the
+    // general tree kernel's 128-bit instantiation, or, for the linear class, the composite MFMA plan with a 128-bit combine pass.
+    if (c.max_bits_np > 120 || c.max_bits > 127) { c.fail(QG_EUNSUPPORTED, "an intermediate needs more than 120 bits"); return; }
+    out->wide = (c.max_bits_np > 62 || c.max_bits > 64 || g_fmt_bits_seen > 62) ? 1 : 0;
+    out->band = c.band ? 1 : 0;
+    if (out->wide && cx) c.exact = false;   // (complex linear class: 62-bit combine only)
+    if (!out->wide && (out->lin.to_c[0].d > 61 || out->lin.to_c[0].d < -61)) c.exact = false;
     out->linear_ok = c.exact ? 1 : 0;
     out->cls = out->linear_ok ? QG_CLASS_LINEAR : QG_CLASS_TREE;
     // 32-bit tree kernel (qg_tree_fast.hip): real, K a power of two >= 32, every value except the
@@ -472,7 +543,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     out->tree_fast_ok = 0;
     // (any K with 5..16 levels: the packed operands are zero-padded to 2^n_levels leaves — a node whose right child is a
     // zero is the reference's converting copy of an odd leftover, QuBLAS.h:4977-4980)
-    if (!cx && d->n_levels <= 16 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) {
+    if (!cx && !out->wide && d->n_levels <= 16 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) {
         const int bitsA = 1 + (int)d->a[0].I + (int)d->a[0].F, bitsB = 1 + (int)d->b[0].I + (int)d->b[0].F;
         const int sh = T.mul[0].q.d;
         int bh = bitsB - sh;
@@ -498,9 +569,9 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         if (one && W + 1 + T.mul[0].q.d <= 30) out->fast_mode = pf.O == QG_SAT_ZERO ? 1 : 2;
     }
     // one-column kernel (qg_gemv.hip): products are formed in 64 bits, everything else in 32
-    out->gemv_ok = (!cx && d->N == 1 && d->n_levels <= 30 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
+    out->gemv_ok = (!cx && !out->wide && d->N == 1 && d->n_levels <= 30 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     // ... with 64-bit tree values when only the ELEMENTS fit 32 storage bits (sums of 32-bit words, wide level types)
-    out->gemv_wide_ok = (!cx && !out->gemv_ok && d->N == 1 && d->n_levels <= 30 &&
+    out->gemv_wide_ok = (!cx && !out->wide && !out->gemv_ok && d->N == 1 && d->n_levels <= 30 &&
                          1 + (int)d->a[0].I + (int)d->a[0].F <= 32 && 1 + (int)d->b[0].I + (int)d->b[0].F <= 32) ? 1 : 0;
     // fast_mode 3: per-level formats, but every step "add a constant, shift right, clamp" (QFix, qg_plan.h): TRN::TCPL /
     // RND::POS_INF / RND::NEG_INF rounding; SAT::TCPL / SAT::SMGN (one clamp), SAT::ZERO (range test + select) or WRP::TCPL
@@ -608,7 +679,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
             }
         }
     }
-    out->tree64_ok = (!cx && d->n_levels <= 16) ? 1 : 0;   // (max_bits <= 62 was checked above)
+    out->tree64_ok = (!cx && !out->wide && d->n_levels <= 16) ? 1 : 0;   // (64-bit values: not a wide plan)
     // QG_DESC_LEFTOVER0_COPY with an odd K: the zero-padded kernels would form the leftover as x + 0 in level 0's type — a
     // conversion, where the reference copies — so only the general kernel, which has the leftover step itself, may run it
     const bool copy0 = (d->flags & QG_DESC_LEFTOVER0_COPY) && (d->K & 1) && d->K > 1;
@@ -632,7 +703,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         if (one) out->gemv_fixed = lf.O == QG_SAT_ZERO ? 1 : 2;
         else if (rec_form) out->gemv_fixed = rec_form;   // per-level formats in compact records (3: every level clamps, 5: kinds)
     }
-    out->cplx_fast_ok = (cx && !copy0 && d->n_levels <= 16 && c.max_bits <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
+    out->cplx_fast_ok = (cx && !out->wide && !copy0 && d->n_levels <= 16 && c.max_bits <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     // fixed-mode variant of the complex kernel (BASELINE configuration 5's "RND + SAT"): every sub-operation and every tree
     // step either the identity, or an exact left shift / a rounding shift with RND::POS_INF, followed by SAT::TCPL, so a
     // step is (v + 2^(d-1)) >> d (or v << -d) and one clamp

@@ -8,7 +8,8 @@
 // (odd leftovers are flushed bottom-up with the converting copy, QuBLAS.h:4977-4980).
 //
 // k_tree_generic is the any-descriptor kernel: real or complex, any per-level formats and modes,
-// 64-bit arithmetic, node parameters read from the plan's QTreeTable.  It is the correctness
+// 64-bit arithmetic — or 128-bit arithmetic for "wide" plans, whose intermediates / level formats / C exceed 62 bits (the
+// reference's multi-word ArbiInt<N > 64>, QuBLAS.h:566-912) —, node parameters read from the plan's QTreeTable.  It is the correctness
 // backstop; shape-specialised kernels for the hot configurations live beside it.
 #include <hip/hip_runtime.h>
 
@@ -21,52 +22,79 @@ __device__ __forceinline__ int64_t ld_c(const char* p, int64_t idx, int cbytes)
     return cbytes == 4 ? (int64_t)((const int32_t*)p)[idx] : ((const int64_t*)p)[idx];
 }
 
-__device__ __forceinline__ void st_c(char* dst, int64_t idx, int cbytes, int64_t v)
+template <class T>
+__device__ __forceinline__ void st_c(char* dst, int64_t idx, int cbytes, T v)
 {
     switch (cbytes) {
     case 1: ((int8_t*)dst)[idx] = (int8_t)v; break;
     case 2: ((int16_t*)dst)[idx] = (int16_t)v; break;
     case 4: ((int32_t*)dst)[idx] = (int32_t)v; break;
-    default: ((int64_t*)dst)[idx] = v; break;
+    case 8: ((int64_t*)dst)[idx] = (int64_t)v; break;
+    default: {   // 16: two little-endian words, the upper one carries the sign (the reference's ArbiInt<65..128>, QuBLAS.h:572-573)
+        const qg_i128 w = (qg_i128)v;
+        ((uint64_t*)dst)[2 * idx] = (uint64_t)(qg_u128)w;
+        ((uint64_t*)dst)[2 * idx + 1] = (uint64_t)((qg_u128)w >> 64);
+        break;
+    }
     }
 }
 
+// the arithmetic of one value type: int64_t (every intermediate within 62 bits; unrounded products 64) or the 128-bit type of
+// wide plans (qg_ops.h: qg_step_w reproduces the reference's multi-word conversions)
+template <class T> struct Ar;
+template <> struct Ar<int64_t> {
+    static __device__ __forceinline__ int64_t mul(int64_t a, int64_t b, const QNode& n) { return qg_mul<int64_t>(a, b, n); }
+    static __device__ __forceinline__ int64_t add(int64_t a, int64_t b, const QNode& n) { return qg_add<int64_t>(a, b, n); }
+    static __device__ __forceinline__ int64_t sub(int64_t a, int64_t b, const QNode& n) { return qg_sub<int64_t>(a, b, n); }
+    static __device__ __forceinline__ int64_t step(int64_t a, const QStep& s) { return qg_step<int64_t>(a, s); }
+};
+template <> struct Ar<qg_i128> {
+    static __device__ __forceinline__ qg_i128 mul(qg_i128 a, qg_i128 b, const QNode& n) { return qg_mul_w(a, b, n); }
+    static __device__ __forceinline__ qg_i128 add(qg_i128 a, qg_i128 b, const QNode& n) { return qg_add_w(a, b, n); }
+    static __device__ __forceinline__ qg_i128 sub(qg_i128 a, qg_i128 b, const QNode& n) { return qg_sub_w(a, b, n); }
+    static __device__ __forceinline__ qg_i128 step(qg_i128 a, const QStep& s) { return qg_step_w(a, s); }
+};
+
 // one (possibly complex) product through the descriptor's sub-operations
-__device__ __forceinline__ void product(const QTreeTable* __restrict__ t, const int64_t x[2], const int64_t y[2], int64_t out[2])
+template <class T>
+__device__ __forceinline__ void product(const QTreeTable* __restrict__ t, const T x[2], const T y[2], T out[2])
 {
+    using A = Ar<T>;
     if (!t->is_complex) {
-        out[0] = qg_mul<int64_t>(x[0], y[0], t->mul[QG_MUL_REAL]);
+        out[0] = A::mul(x[0], y[0], t->mul[QG_MUL_REAL]);
         out[1] = 0;
         return;
     }
-    const int64_t a = x[0], b = x[1], c = y[0], d = y[1];
+    const T a = x[0], b = x[1], c = y[0], d = y[1];
     if (t->cmul == QG_CMUL_TF) {
-        int64_t ab = qg_add<int64_t>(a, b, t->mul[QG_T_AB]);
-        int64_t cd = qg_add<int64_t>(c, d, t->mul[QG_T_CD]);
-        int64_t ba = qg_sub<int64_t>(b, a, t->mul[QG_T_BA]);
-        int64_t A = qg_mul<int64_t>(ab, c, t->mul[QG_T_A]);
-        int64_t B = qg_mul<int64_t>(cd, b, t->mul[QG_T_B]);
-        int64_t C = qg_mul<int64_t>(ba, d, t->mul[QG_T_C]);
-        out[0] = qg_sub<int64_t>(A, B, t->mul[QG_T_RE]);
-        out[1] = qg_sub<int64_t>(B, C, t->mul[QG_T_IM]);
+        T ab = A::add(a, b, t->mul[QG_T_AB]);
+        T cd = A::add(c, d, t->mul[QG_T_CD]);
+        T ba = A::sub(b, a, t->mul[QG_T_BA]);
+        T PA = A::mul(ab, c, t->mul[QG_T_A]);
+        T PB = A::mul(cd, b, t->mul[QG_T_B]);
+        T PC = A::mul(ba, d, t->mul[QG_T_C]);
+        out[0] = A::sub(PA, PB, t->mul[QG_T_RE]);
+        out[1] = A::sub(PB, PC, t->mul[QG_T_IM]);
     } else {
-        int64_t ac = qg_mul<int64_t>(a, c, t->mul[QG_B_AC]);
-        int64_t bd = qg_mul<int64_t>(b, d, t->mul[QG_B_BD]);
-        int64_t ad = qg_mul<int64_t>(a, d, t->mul[QG_B_AD]);
-        int64_t bc = qg_mul<int64_t>(b, c, t->mul[QG_B_BC]);
-        out[0] = qg_sub<int64_t>(ac, bd, t->mul[QG_B_RE]);
-        out[1] = qg_add<int64_t>(ad, bc, t->mul[QG_B_IM]);
+        T ac = A::mul(a, c, t->mul[QG_B_AC]);
+        T bd = A::mul(b, d, t->mul[QG_B_BD]);
+        T ad = A::mul(a, d, t->mul[QG_B_AD]);
+        T bc = A::mul(b, c, t->mul[QG_B_BC]);
+        out[0] = A::sub(ac, bd, t->mul[QG_B_RE]);
+        out[1] = A::add(ad, bc, t->mul[QG_B_IM]);
     }
 }
 
 constexpr int TG_T = 16;  // 16x16 outputs per block, one per thread
 constexpr int TG_KC = 32; // k-chunk staged in LDS
 
+template <class T>
 __global__ __launch_bounds__(256) void k_tree_generic(const QTreeTable* __restrict__ tab, const char* __restrict__ A,
                                                       const char* __restrict__ B, char* __restrict__ C, int64_t M, int64_t N,
                                                       int64_t K, QPackedGeom pa, QPackedGeom pb, QCGeom pc)
 {
-    __shared__ int64_t sA[2][TG_T][TG_KC + 1];
+    using Arith = Ar<T>;
+    __shared__ int64_t sA[2][TG_T][TG_KC + 1];   // (operand elements are one-word values in both instantiations)
     __shared__ int64_t sB[2][TG_T][TG_KC + 1];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int64_t tiles_n = (N + TG_T - 1) / TG_T;
@@ -74,7 +102,7 @@ __global__ __launch_bounds__(256) void k_tree_generic(const QTreeTable* __restri
     const int parts = tab->parts;
     const int nl = tab->n_levels;
 
-    int64_t val[2][QG_MAX_LEVELS + 1];
+    T val[2][QG_MAX_LEVELS + 1];
     uint64_t has = 0; // bit l: a pending element of list l (the same for both parts)
 
     for (int64_t k0 = 0; k0 < K; k0 += TG_KC) {
@@ -96,16 +124,16 @@ __global__ __launch_bounds__(256) void k_tree_generic(const QTreeTable* __restri
         __syncthreads();
         const int kend = (K - k0) < TG_KC ? (int)(K - k0) : TG_KC;
         for (int kk = 0; kk < kend; ++kk) {
-            int64_t x[2] = {sA[0][ty][kk], parts > 1 ? sA[1][ty][kk] : 0};
-            int64_t y[2] = {sB[0][tx][kk], parts > 1 ? sB[1][tx][kk] : 0};
-            int64_t v[2];
-            product(tab, x, y, v);
+            T x[2] = {(T)sA[0][ty][kk], parts > 1 ? (T)sA[1][ty][kk] : (T)0};
+            T y[2] = {(T)sB[0][tx][kk], parts > 1 ? (T)sB[1][tx][kk] : (T)0};
+            T v[2];
+            product<T>(tab, x, y, v);
             // push into the binary counter: element of list l meets a pending one -> node of level l
             int l = 0;
             while ((has >> l) & 1) {
                 for (int p = 0; p < parts; ++p) {
-                    int64_t s = qg_add<int64_t>(val[p][l], v[p], tab->level_add[p][l]);
-                    v[p] = qg_step<int64_t>(s, tab->level_cvt[p][l]);
+                    T s = Arith::add(val[p][l], v[p], tab->level_add[p][l]);
+                    v[p] = Arith::step(s, tab->level_cvt[p][l]);
                 }
                 has &= ~(1ull << l);
                 ++l;
@@ -117,14 +145,14 @@ __global__ __launch_bounds__(256) void k_tree_generic(const QTreeTable* __restri
     // flush odd leftovers bottom-up (only when K is not a power of two)
     for (int l = 0; l < nl; ++l) {
         if (!((has >> l) & 1)) continue;
-        int64_t v[2];
-        for (int p = 0; p < parts; ++p) v[p] = qg_step<int64_t>(val[p][l], tab->leftover[p][l]);
+        T v[2];
+        for (int p = 0; p < parts; ++p) v[p] = Arith::step(val[p][l], tab->leftover[p][l]);
         has &= ~(1ull << l);
         int u = l + 1;
         while ((has >> u) & 1) {
             for (int p = 0; p < parts; ++p) {
-                int64_t s = qg_add<int64_t>(val[p][u], v[p], tab->level_add[p][u]);
-                v[p] = qg_step<int64_t>(s, tab->level_cvt[p][u]);
+                T s = Arith::add(val[p][u], v[p], tab->level_add[p][u]);
+                v[p] = Arith::step(s, tab->level_cvt[p][u]);
             }
             has &= ~(1ull << u);
             ++u;
@@ -135,8 +163,8 @@ __global__ __launch_bounds__(256) void k_tree_generic(const QTreeTable* __restri
     const int64_t m = m0 + ty, n = n0 + tx;
     if (m < M && n < N) {
         for (int p = 0; p < parts; ++p) {
-            int64_t r = qg_step<int64_t>(val[p][nl], tab->c_cvt[p]);
-            st_c(C, ((int64_t)p * pc.Mp + m) * pc.Np + n, pc.cbytes, r);
+            T r = Arith::step(val[p][nl], tab->c_cvt[p]);
+            st_c<T>(C, ((int64_t)p * pc.Mp + m) * pc.Np + n, pc.cbytes, r);
         }
     }
 }
@@ -145,13 +173,17 @@ __global__ __launch_bounds__(256) void k_tree_generic(const QTreeTable* __restri
 
 hipError_t qg_launch_tree_generic(const QTreeTable* dev_table, int parts, const void* A, const void* B, void* C, int64_t M,
                                   int64_t N, int64_t K, const QPackedGeom& pa, const QPackedGeom& pb, const QCGeom& pc,
-                                  hipStream_t st)
+                                  hipStream_t st, int wide)
 {
     (void)parts;
     int64_t blocks = ((M + TG_T - 1) / TG_T) * ((N + TG_T - 1) / TG_T);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_tree_generic, dim3((unsigned)blocks), dim3(256), 0, st, dev_table, (const char*)A, (const char*)B,
-                       (char*)C, M, N, K, pa, pb, pc);
+    if (wide)
+        hipLaunchKernelGGL(k_tree_generic<qg_i128>, dim3((unsigned)blocks), dim3(256), 0, st, dev_table, (const char*)A, (const char*)B,
+                           (char*)C, M, N, K, pa, pb, pc);
+    else
+        hipLaunchKernelGGL(k_tree_generic<int64_t>, dim3((unsigned)blocks), dim3(256), 0, st, dev_table, (const char*)A, (const char*)B,
+                           (char*)C, M, N, K, pa, pb, pc);
     return hipGetLastError();
 }

@@ -115,7 +115,8 @@ class Qu:
 
     @property
     def host_bytes(self) -> int:
-        return 4 if self.storage_bits <= 32 else 8  # ArbiInt<N>::data_t, QuBLAS.h:353
+        # ArbiInt<N>::data_t, QuBLAS.h:353; beyond 64 bits a little-endian std::array<uint64_t, ceil(N/64)> (:572-573)
+        return 4 if self.storage_bits <= 32 else 8 if self.storage_bits <= 64 else 8 * ((self.storage_bits + 63) // 64)
 
     @property
     def raw_min(self) -> int:
@@ -381,8 +382,9 @@ def host_layout(e: Elem) -> Tuple[int, int, Tuple[int, int]]:
     if not isinstance(e, Qcomplex):
         return e.host_bytes, 0, (e.host_bytes, 0)
     sr, si = e.real.host_bytes, e.imag.host_bytes
-    off = (sr + si - 1) // si * si
-    al = max(sr, si)
+    ar, ai = min(sr, 8), min(si, 8)       # alignment: int32_t / int64_t / uint64_t[n]
+    off = (sr + ai - 1) // ai * ai
+    al = max(ar, ai)
     size = (off + si + al - 1) // al * al
     return size, off, (sr, si)
 

@@ -73,12 +73,22 @@ def case_expected(j, qoracle):
     _, _, ec = case_elems(j)
     n = j["M"] * j["N"]
     arr = np.zeros(n, dtype=qoracle.host_dtype(ec))
+    if not j["is_complex"] and arr.dtype == qoracle.WIDE:   # values beyond 64 bits: JSON big integers -> two words
+        return qoracle.to_host(j["C"], ec)
     v = np.asarray(j["C"], dtype=np.int64)
     if j["is_complex"]:
         arr["re"], arr["im"] = v[0::2], v[1::2]
     else:
         arr[:] = v
     return arr
+
+
+def wide_tables(part=None):
+    pat = f"ref_wide_{part}.jsonl.gz" if part is not None else "ref_wide_*.jsonl.gz"
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLD, pat))):
+        out.extend(_records(p))
+    return out
 
 
 def eltwise_cases():

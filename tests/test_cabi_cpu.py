@@ -112,17 +112,20 @@ def test_rejections():
     for c in (Qu(31, 0, False, OfMode=3), Qu(33, 0, False, OfMode=3), Qu(31, 0, True, OfMode=3), Qu(32, 0, False, OfMode=0)):
         st, info = capi.classify_status(lower(e, e, c, 4, 4, 4))
         assert st == capi.QG_OK, info.reason
-    # wider than 62 bits
+    # wider than 120 bits
     d = lower(Qu(30, 30), Qu(30, 30), Qu(8, 8), 4, 4, 4, mul_args=Qu(60, 60))
     st, _ = capi.classify_status(d)
     assert st == capi.QG_EUNSUPPORTED
-    # ... but the UNROUNDED product of two operands may use all of an int64: signed 32-bit words (Q15.16) are admitted, two
-    # unsigned 32-bit words (a 64-bit magnitude) and a 33-bit pair are not
+    # The UNROUNDED product of two operands may use all of an int64 on the 64-bit kernels: signed 32-bit words (Q15.16) run there;
+    # two unsigned 32-bit words (a 64-bit magnitude) or a 33-bit pair need the 128-bit kernel (round 2 refused them)
     q = Qu(15, 16)
     st, info = capi.classify_status(lower(q, q, q, 4, 4, 64))
-    assert st == capi.QG_OK and info.max_bits == 64, info.reason
+    assert st == capi.QG_OK and info.max_bits == 64 and capi.KERNEL_NAMES[info.kernel] == "tree_i64", info.reason
     for a, b in ((Qu(16, 16, False), Qu(16, 16, False)), (Qu(16, 16), Qu(15, 16))):
-        assert capi.classify_status(lower(a, b, q, 4, 4, 64))[0] == capi.QG_EUNSUPPORTED
+        st, info = capi.classify_status(lower(a, b, q, 4, 4, 64))
+        assert st == capi.QG_OK and capi.KERNEL_NAMES[info.kernel] == "tree_i128", info.reason
+    # operand ELEMENTS stay one-word values
+    assert capi.classify_status(lower(Qu(40, 30), q, q, 4, 4, 4))[0] == capi.QG_EUNSUPPORTED
     d = lower(e, e, e, 4, 4, 4)
     d.n_levels = 5
     st, _ = capi.classify_status(d)

@@ -282,10 +282,12 @@ def test_32_bit_fixed_point_words(oracle):
         assert capi.KERNEL_NAMES[capi.classify(d).kernel] == "tree_cplx"
         A, B = oracle.fill(cq, 21 * 64, 5, 0), oracle.fill(cq, 64 * 17, 6, 0)
         assert fields_equal(run_gpu(d, A, B, cq, oracle), oracle.gemm(d, A, B, cq, nthreads=8))
-    # two UNSIGNED 32-bit words: the product needs 64 magnitude bits and is still refused
+    # two UNSIGNED 32-bit words: the product needs 64 magnitude bits — the 128-bit tree kernel (round 2 refused it; tests/test_wide.py)
     u = Qu(16, 16, False)
-    st, info = capi.classify_status(lower(u, u, u, 8, 8, 64))
-    assert st == capi.QG_EUNSUPPORTED and b"62 bits" in info.reason
+    d = lower(u, u, u, 8, 8, 64)
+    assert capi.KERNEL_NAMES[capi.classify(d).kernel] == "tree_i128"
+    A, B = oracle.fill(u, 8 * 64, 7, 0), oracle.fill(u, 64 * 8, 8, 0)
+    assert fields_equal(run_gpu(d, A, B, u, oracle), oracle.gemm(d, A, B, u, nthreads=4))
 
 
 def test_real_tree_kernel_step_forms(oracle):
