@@ -1,15 +1,14 @@
-"""Row-shard + single-gather orchestration (qublas_amd/dist.py) on CPU: world_size 2 and 3 with the
-gloo backend, the per-rank engine call replaced by the CPU oracle (tests only).  Checks the row
-partition, the strided/contiguous shard views for both A orientations, padding of unequal shards and
-the reassembly of the column-major C against a single-process oracle run."""
+"""Row-shard + single-gather orchestration (qublas_amd/dist.py) on CPU: world_size 2 and 3 over the TCP control channel
+(qublas_amd.dist.HostChannel; round 2 used torch.distributed's gloo backend here, which the product path no longer imports), the
+per-rank engine call replaced by the CPU oracle (tests only).  Checks the row partition, the strided / contiguous shard views
+for both A orientations, unequal shards and the reassembly of the column-major C against a single-process oracle run."""
+import multiprocessing as mp
 import os
 import socket
 import sys
 
 import numpy as np
 import pytest
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -51,10 +50,9 @@ CASES = {
 
 
 def _worker(rank, world, port, name, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import qoracle
+    from qublas_amd.dist import HostChannel
+    ch = HostChannel(rank, world, "127.0.0.1", port)
     c = CASES[name]
     M, N, K = c["M"], c["N"], c["K"]
     A = qoracle.fill(c["ea"], M * K, 1, 1)
@@ -63,15 +61,16 @@ def _worker(rank, world, port, name, q):
     def compute(d, a_view, b, ec, lda, ldb):
         return qoracle.gemm(d, a_view, b, ec, lda=lda, ldb=ldb)
 
-    out = qgemul_row_sharded(A, B, c["ea"], c["eb"], c["ec"], M, N, K, align=128, compute=compute, **c["kw"])
+    out = qgemul_row_sharded(A, B, c["ea"], c["eb"], c["ec"], M, N, K, align=128, compute=compute, channel=ch, **c["kw"])
     if rank == 0:
         d = lower(c["ea"], c["eb"], c["ec"], M, N, K, **c["kw"])
         exp = qoracle.gemm(d, A, B, c["ec"])
         q.put(out.tobytes() == exp.tobytes())
     else:
         assert out is None
-    dist.barrier()
-    dist.destroy_process_group()
+    ch.barrier()
+    assert ch.max_f64(float(rank)) == float(world - 1)
+    ch.close()
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -87,3 +86,10 @@ def test_row_sharded_gather_gloo(name, world):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_the_engine_path_imports_no_torch():
+    """qublas_amd.dist and qublas_amd.capi — the product-side Python plumbing of the multi-GPU path — do not import torch"""
+    import subprocess
+    code = "import sys; import qublas_amd.dist, qublas_amd.capi; assert 'torch' not in sys.modules, 'torch was imported'"
+    subprocess.check_call([sys.executable, "-c", code], cwd=ROOT)

@@ -1,8 +1,9 @@
 """bench.py as the driver runs it (run with -m gpu).  `python bench.py --gpus 2` must work as invoked: the parent touches no GPU
-and starts the two ranks itself; on the one-GPU test box both ranks share the card and rendezvous over gloo (the RCCL transport
-needs one GPU per rank: that run is the driver's).  The nccl branch — process group, gather, device-side stream ordering — runs
-here with a world of ONE rank.  Both legs of the JSON line are checked: the metric workload and extra.c4 (configuration 4,
-strong scaling, with and without the gather)."""
+and starts the two ranks itself; on the one-GPU test box both ranks share the card and the packed bands travel over the host
+transport (`--backend host`: RCCL refuses two ranks on one device; that run is the driver's).  The RCCL branch — the library's
+communicator, the gather on its own stream, device-side ordering against the GEMMs, barrier and max — runs here with a world of
+ONE rank.  Both legs of the JSON line are checked: the metric workload and extra.c4 (configuration 4, strong scaling, with and
+without the gather).  bench.py imports no PyTorch."""
 import json
 import os
 import subprocess
@@ -36,10 +37,10 @@ def check_common(j, world):
     return c4
 
 
-def test_self_launcher_two_ranks_gloo():
-    j = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "5", "--warmup", "2", "--prewarm", "20", "--no-cpu", "--c4-steps", "3")
+def test_self_launcher_two_ranks_host_transport():
+    j = run_bench("--gpus", "2", "--backend", "host", "--steps", "5", "--warmup", "2", "--prewarm", "20", "--no-cpu", "--c4-steps", "3")
     c4 = check_common(j, 2)
-    assert j["rccl_world_size"] == 2 and j["backend"] == "gloo" and j["gather_bytes_per_step_per_rank"] == 4096 * 4096 * 4
+    assert j["rccl_world_size"] == 2 and j["backend"] == "host" and j["gather_bytes_per_step_per_rank"] == 4096 * 4096 * 4
     assert c4["rows_per_rank"] == [8192, 8192] and c4["rccl_world_size"] == 2
     assert c4["gather_bytes_per_rank"] == 8192 * 16384          # packed 1-byte C
     assert c4["value_one_gather"] > 0 and c4["chunks"] >= 2 and c4["value_chunked_gather"] > 0
@@ -47,17 +48,26 @@ def test_self_launcher_two_ranks_gloo():
 
 def test_self_launcher_three_ranks_ragged_partition():
     """16384 rows over 3 ranks: 64 blocks of 256 rows do not divide — bands of 22 / 21 / 21 blocks; the gather pads to the largest."""
-    j = run_bench("--gpus", "3", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--prewarm", "10", "--no-cpu", "--c4-steps", "2")
+    j = run_bench("--gpus", "3", "--backend", "host", "--steps", "3", "--warmup", "1", "--prewarm", "10", "--no-cpu", "--c4-steps", "2")
     c4 = check_common(j, 3)
     assert c4["rows_per_rank"] == [5632, 5376, 5376] and c4["gather_bytes_per_rank"] == 5632 * 16384
     assert c4["value_one_gather"] > 0
 
 
-def test_nccl_branch_with_one_rank():
+def test_rccl_branch_with_one_rank():
     j = run_bench("--gpus", "1", "--force-dist", "--steps", "5", "--warmup", "2", "--prewarm", "20", "--no-cpu", "--c4-steps", "3")
     c4 = check_common(j, 1)
-    assert j["rccl_world_size"] == 1 and j["backend"] == "nccl"
-    assert c4["rccl_world_size"] == 1 and c4["backend"] == "nccl" and c4["value_one_gather"] > 1e14
+    assert j["rccl_world_size"] == 1 and j["backend"] == "rccl" and j["rccl_version"] > 20000     # ncclCommCount / ncclGetVersion of the library's communicator
+    assert c4["rccl_world_size"] == 1 and c4["backend"] == "rccl" and c4["value_one_gather"] > 1e14
+    assert c4["ms_per_step_events_one_gather"] > 0 and c4["ms_per_step_events_compute_only"] > 0
+
+
+def test_bench_imports_no_torch():
+    import subprocess
+    code = ("import sys, runpy; sys.argv = ['bench.py', '--help']\n"
+            "try:\n    runpy.run_path('bench.py', run_name='__main__')\nexcept SystemExit:\n    pass\n"
+            "assert 'torch' not in sys.modules")
+    subprocess.check_call([sys.executable, "-c", code], cwd=ROOT)
 
 
 def test_a_failing_rank_fails_the_launcher():
@@ -72,9 +82,18 @@ def test_single_gpu_line_carries_every_baseline_configuration():
     check_common(j, 1)
     assert j["cpu_baseline"]["value"] and j["cpu_baseline"]["kind"] in ("reference", "port")
     ex = j["extra"]
-    for name, bound in (("c2L", "mfma"), ("c2T", "valu"), ("c3T", "valu"), ("c5TF", "valu"), ("c5B", "valu")):
+    for name, bound in (("c2L", "mfma"), ("c2T", "valu"), ("c3T", "valu"), ("c3Td", "valu"), ("c5TF", "valu"), ("c5B", "valu"), ("c5L", "mfma"), ("reduce", "hbm"),
+                        ("long_k", "mfma")):
         assert "error" not in ex[name], ex[name]
-        assert ex[name]["roofline"]["bound"] == bound and ex[name]["roofline"]["kernel_ms"] > 0
+        r = ex[name]["roofline"]
+        assert r["bound"] == bound and r["kernel_ms"] > 0
+        assert r["frac"] is None or 0 < r["frac"] <= 1.0, (name, r["frac"])          # no fraction above its roof
+        assert (r["profile"] is None) == (r["profile_note"] is not None)             # a block either quotes a matching profile or says why not
+        if bound == "valu" and r["profile"]:
+            assert r["instr_per_mac"] > 1 and r["valu_busy_in_profile"] <= 1.05
     assert ex["c4"]["roofline"]["bound"] == "mfma" and ex["c4"]["roofline"]["frac"] > 0.3
-    assert ex["c3T"]["launches_timed"] >= 10
+    # the c4 leg's wall clock per step stays close to its kernel time by HIP events (round 2: 10-13 % apart, no prewarm)
+    assert ex["c4"]["ms_per_step_compute_only"] < 1.06 * ex["c4"]["ms_per_step_events_compute_only"]
+    assert ex["c3T"]["launches_timed"] >= 10 and ex["reduce"]["roofline"]["frac"] > 0.3
+    assert j["ms_per_step_events"] > 0 and j["profile_key"]["engine_kernel"] == "mfma_i8_limb"
     assert j["roofline"]["traffic"] is None or "traffic_source" in j["roofline"]

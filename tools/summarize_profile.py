@@ -5,7 +5,10 @@ For every workload profiled it keeps
   profiles/<tag>_<WL>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, verbatim
   profiles/<tag>_<WL>.json               dominant kernel: calls, mean / median / min duration,
                                          PMC counters per launch, HBM traffic per launch
-and refreshes profiles/traffic.json, which bench.py reads for roofline.traffic.
+and refreshes profiles/kernels.json, which bench.py reads for what its roofline blocks quote from counters (vector instructions
+per MAC, VALU busy share, clock, MFMA pipe share, HBM-side traffic) — each entry together with the kernel symbol, the engine's
+kernel id and step form, the git HEAD and the source hashes it was measured on (qublas_amd/profmeta.py: a block quotes an entry only
+while those still match).
 
 HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are in
 KiB and come from separate --pmc passes (they do not fit one pass); on gfx950 FETCH_SIZE reports
@@ -33,8 +36,8 @@ def main():
     src, tag = sys.argv[1], sys.argv[2]
     prof = os.path.join(ROOT, "profiles")
     os.makedirs(prof, exist_ok=True)
-    traffic_path = os.path.join(prof, "traffic.json")
-    traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
+    kernels_path = os.path.join(prof, "kernels.json")
+    kernels = json.load(open(kernels_path)) if os.path.exists(kernels_path) else {}
     for tdir in sorted(glob.glob(os.path.join(src, "prof_*_trace"))):
         wl = os.path.basename(tdir)[5:-6]
         stats = find(tdir, "*kernel_stats.csv")
@@ -45,9 +48,23 @@ def main():
         rows = list(csv.DictReader(open(stats)))
         top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
         name = top["Name"]
+        steps = 10 if wl in ("c3T", "c3Td", "c5TF", "c5B", "long_k") else 200
         out = {"workload": wl, "kernel": name, "calls": int(top["Calls"]), "mean_us": float(top["AverageNs"]) / 1e3,
                "min_us": float(top["MinNs"]) / 1e3, "max_us": float(top["MaxNs"]) / 1e3,
-               "command": f"rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --steps {10 if wl == 'c3T' else 200} --warmup 5 --no-extra --no-cpu"}
+               "command": f"rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --steps {steps} --warmup 5 --no-extra --no-cpu"}
+        # what the profiled run says about itself (bench.py's `profile_key`: engine kernel, step form, MACs, source hashes, HEAD)
+        key = None
+        log = os.path.join(src, f"prof_{wl}_trace.log")
+        if os.path.exists(log):
+            for ln in open(log, errors="replace"):
+                if ln.startswith('{"metric"'):
+                    try:
+                        j = json.loads(ln)
+                        key = j.get("profile_key")
+                        out["bench_ms_per_step_events"] = j.get("ms_per_step_events")
+                    except Exception:
+                        pass
+        out["profile_key"] = key
         if trace:
             d = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(trace))
                  if r["Kernel_Name"] == name]
@@ -83,14 +100,32 @@ def main():
             out["hbm_bytes_per_launch"] = rd + wr
             out["traffic_note"] = ("FETCH_SIZE KiB x1024 x2 (gfx950 half-count of 16 B/lane streams) + WRITE_SIZE KiB x1024; "
                                    "WRITE_SIZE is uncalibrated for the epilogue's sub-16-B-per-lane stores")
-            traffic[wl] = {"hbm_bytes_per_launch": rd + wr, "read": rd, "write": wr, "profile": f"profiles/{tag}_{wl}.json"}
-        if "GRBM_GUI_ACTIVE" in pmc and "SQ_VALU_MFMA_BUSY_CYCLES" in pmc:
+        entry = {"profile": f"profiles/{tag}_{wl}.json", "kernel_symbol": name, "kernel_us": out.get("steady_mean_us", out["mean_us"])}
+        if "hbm_bytes_per_launch" in out:
+            entry["hbm"] = {"bytes_per_launch": out["hbm_bytes_per_launch"], "read": out["hbm_read_bytes_per_launch"], "write": out["hbm_write_bytes_per_launch"]}
+        if "GRBM_GUI_ACTIVE" in pmc:
             cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
             out["kernel_cycles"] = cyc
-            out["mfma_pipe_util"] = pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc  # 1024 SIMDs
+            entry["cycles"] = cyc
+            # clock the chip held under this kernel: cycles of a counter pass over the kernel's duration in the trace pass
+            entry["clock_ghz"] = cyc / (out.get("median_us", out["mean_us"]) * 1e3)
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in pmc:
+                out["mfma_pipe_util"] = pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc  # 1024 SIMDs
+                if pmc.get("SQ_INSTS_MFMA", 0) > 0:
+                    entry["mfma"] = {"pipe_busy": out["mfma_pipe_util"], "insts_mfma": pmc["SQ_INSTS_MFMA"]}
+            if "SQ_INSTS_VALU" in pmc and key and key.get("macs"):
+                v = {"insts_valu_wave64": pmc["SQ_INSTS_VALU"], "instr_per_mac": pmc["SQ_INSTS_VALU"] * 64.0 / key["macs"]}
+                if "SQ_ACTIVE_INST_VALU" in pmc:
+                    v["active_inst_valu"] = pmc["SQ_ACTIVE_INST_VALU"]
+                    v["valu_busy"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc)   # issue cycles (4 per wave64 instruction) over SIMD cycles
+                out["valu"] = v
+                entry["valu"] = v
+        if key:
+            entry.update({k: key[k] for k in ("engine_kernel", "engine_reason", "macs", "sources", "head")})
+            kernels[wl] = entry
         json.dump(out, open(os.path.join(prof, f"{tag}_{wl}.json"), "w"), indent=1)
         print(json.dumps(out))
-    json.dump(traffic, open(traffic_path, "w"), indent=1)
+    json.dump(kernels, open(kernels_path, "w"), indent=1)
     for f in ("bench.json", "pytest_gpu.log", "smoke.log"):
         p = os.path.join(src, f)
         if os.path.exists(p) and os.path.getsize(p):
