@@ -22,6 +22,7 @@
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <type_traits>
 #include <vector>
 
@@ -704,6 +705,68 @@ auto Qreduce(const Qu_s<dim<D...>, Elem>& v)
     res_t r;
     r.data = typename res_t::raw_t(c.data[0].data);
     return r;
+}
+
+// ---- the VARIADIC overload: Qreduce<L...>(q1, q2, ...) — any number of scalars of any (real) types (readme.md:62;
+// QuBLAS.h:4924-4951).  Level l adds neighbours with Qadd<T_l> (T_l = L[min(l, n-1)]; no L: the default merge of the two
+// operand types); an odd leftover is added AFTER the recursion over the pair sums, with the CURRENT level's type (the vector
+// overload above copies it into the next level instead: the two differ for lengths that are not powers of two).  Every
+// Qadd<T>(x, y) of two scalars is ONE two-term Qgemul on the engine: both operands are written exactly in a common
+// super-format (the alignment shifts Qadd performs itself, QuBLAS.h:3190), times 1, and level 0 is the node's result type.
+// "Please avoid using this version for efficiency" holds here as it does in the reference (a device call per node).
+namespace detail {
+template <class T> concept RealScalar = requires { T::fmt; typename T::raw_t; } && !T::is_complex && !requires { typename T::elem_t; };
+
+template <TagSet tags, class X, class Y>
+auto add_node(const X& x, const Y& y)
+{
+    constexpr Fmt fx = X::fmt, fy = Y::fmt, fr = merge_add(fx, fy, tags);
+    constexpr int F = fx.F > fy.F ? fx.F : fy.F;
+    constexpr Fmt sup{fx.I > fy.I ? fx.I : fy.I, F, fx.S || fy.S, int(QG_TRN_TCPL), int(QG_SAT_TCPL)};
+    using sup_t = scalar_of<sup>;
+    using res_t = scalar_of<fr>;
+    using one_t = Qu<intBits<1>, fracBits<0>, isSigned<false>>;
+    Qu_s<dim<2, 1>, sup_t> a;                    // dim<K, M> with TransposedA: the two operands are row 0 of A'
+    a.data[0].data = typename sup_t::raw_t(int64_t(x.data) << (F - fx.F));
+    a.data[1].data = typename sup_t::raw_t(int64_t(y.data) << (F - fy.F));
+    Qu_s<dim<2, 1>, one_t> ones;
+    for (auto& o : ones.data) o.data = 1;
+    Qu_s<dim<1, 1>, res_t> c;
+    Qgemul<QgemulAddArgs<res_t>, QgemulMulArgs<sup_t>, QgemulTransposedA<true>>(c, a, ones);
+    return c.data[0];
+}
+
+template <size_t layer, class List, class... Ts>
+auto reduce_variadic(const Ts&... q)
+{
+    constexpr size_t n = sizeof...(Ts);
+    auto tup = std::tie(q...);
+    if constexpr (n == 1) {
+        return std::get<0>(tup);
+    } else {
+        using L = levels_of<List>;
+        constexpr TagSet tags = [] {
+            if constexpr (L::n == 0) return TagSet{};
+            else {
+                constexpr Fmt f = L::value[layer < L::n ? layer : L::n - 1][0];
+                return TagSet{true, true, true, true, true, false, f.I, f.F, f.Q, f.O, f.S};
+            }
+        }();
+        auto rest = [&]<size_t... I>(std::index_sequence<I...>) {
+            return reduce_variadic<layer + 1, List>(add_node<tags>(std::get<2 * I>(tup), std::get<2 * I + 1>(tup))...);
+        }(std::make_index_sequence<n / 2>{});
+        if constexpr (n % 2 == 0) return rest;
+        else return add_node<tags>(rest, std::get<n - 1>(tup));
+    }
+}
+} // namespace detail
+
+template <typename... Levels, detail::RealScalar T0, detail::RealScalar T1, detail::RealScalar... Ts>
+auto Qreduce(const T0& q0, const T1& q1, const Ts&... qs)
+{
+    using list = typename detail::as_list<Levels...>::type;
+    static_assert(detail::levels_of<list>::all_real, "Qreduce of real scalars needs real level types");
+    return detail::reduce_variadic<0, list>(q0, q1, qs...);
 }
 
 } // namespace QuBLAS_amd

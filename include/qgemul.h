@@ -55,7 +55,9 @@ enum {
     QG_SAT_ZERO = 1,
     QG_SAT_SMGN = 2,
     QG_WRP_TCPL = 3,
-    QG_WRP_TCPL_SAT = 4 /* a stub in the reference (QuBLAS.h:2336-2344): rejected, QG_EUNSUPPORTED */
+    QG_WRP_TCPL_SAT = 4 /* a stub in the reference: intConvert returns its input (QuBLAS.h:2336-2344) and the target's storage word
+                           (int32_t / int64_t) keeps what fits.  Runs where the value provably stays in its format (a no-op) and
+                           as C's OfMode (the root lands in C's host word unclamped); elsewhere QG_EUNSUPPORTED */
 };
 
 /* complex multiply algorithm — BasicComplexMul QuBLAS.h:3426-3445, TFComplexMul :3510-3534 */

@@ -14,7 +14,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
-JOBS = {"ref_cases_real": range(8), "ref_cases_cplx": range(4), "ref_cases_scalar": range(9), "ref_cases_eltwise": range(3),
+JOBS = {"ref_cases_real": range(9), "ref_cases_cplx": range(4), "ref_cases_scalar": range(11), "ref_cases_eltwise": range(3),
         "ref_cases_cplx_eltwise": range(3), "ref_cases_bitstream": range(1),
         "ref_cases_cplx_bitstream": range(1), "ref_cases_wide": range(6)}
 OUT = {"ref_cases_real": "ref_gemm_real", "ref_cases_cplx": "ref_gemm_cplx", "ref_cases_scalar": "ref_scalar",

@@ -119,7 +119,12 @@ static qi qo_overflow_n(qi x, qfmt f, int nin)
         }
         return x & (qo_pow2(W) - 1);
     default:
-        return x; /* WRP::TCPL_SAT: stub returning its input, :2336-2344 (callers reject it) */
+        /* WRP::TCPL_SAT<N>: a stub returning its input (:2336-2344); the assignment into the target's storage narrows it to the
+         * storage WORD — ArbiInt<M <= 32> keeps an int32_t, <= 64 an int64_t, never masked to M bits (:353, :431-441; pinned by
+         * tests/golden/ref_scalar_9, ref_gemm_real_8) */
+        if (1 + W <= 32) return (qi)(int32_t)(uint32_t)(qu)x;
+        if (1 + W <= 64) return (qi)(int64_t)(uint64_t)(qu)x;
+        return x;
     }
 }
 static qi qo_overflow(qi x, qfmt f) { return qo_overflow_n(x, f, 0); }

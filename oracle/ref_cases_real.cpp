@@ -142,6 +142,14 @@ int main(int argc, char** argv)
         run_case<e88z, e88z, e88z, TypeList<>, TypeList<t2, t1>, false, 2, 2, 1000>("e88z_K1000_levels2_small", syn(1), out);
         break;
     }
+    case 8: {   // C with WRP::TCPL_SAT<N> (the stub: the root goes into C's storage word unclamped)
+        using csat = Qu<intBits<4>, fracBits<3>, OfMode<WRP::TCPL_SAT<2>>>;
+        using csat2 = Qu<intBits<6>, fracBits<2>, QuMode<RND::CONV>, OfMode<WRP::TCPL_SAT<1>>>;
+        run_case<e43, e43, csat, L2mul, L2add, false, 8, 8, 64>("e43_L_8x8x64_tcplsatC", syn(0), out);
+        run_case<e43, e43, csat2, TypeList<>, TypeList<w16>, true, 9, 7, 37>("e43_T_tn_9x7x37_tcplsatC", syn(0), out);
+        run_case<e88z, e88z, Qu<intBits<8>, fracBits<8>, OfMode<WRP::TCPL_SAT<4>>>, L3mul, L3add, false, 6, 6, 256>("e88z_L_6x6x256_tcplsatC", syn(0), out);
+        break;
+    }
     default:
         return 2;
     }

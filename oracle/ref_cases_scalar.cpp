@@ -358,6 +358,59 @@ int main(int argc, char** argv)
         reduce_min_last_table<st, 5>(out, "tcpl_last_len5_default");
         break;
     }
+    case 9: {
+        // WRP::TCPL_SAT<N>: intConvert returns its input (QuBLAS.h:2336-2344), the assignment into the target's storage then narrows
+        // it to the storage word (ArbiInt<M <= 32> keeps an int32_t, <= 64 an int64_t, never masked to M bits: :353, :431-441)
+        using s400 = Qu<intBits<40>, fracBits<0>>;
+        using s123 = Qu<intBits<12>, fracBits<3>>;
+        using t43 = Qu<intBits<4>, fracBits<3>, OfMode<WRP::TCPL_SAT<2>>>;
+        using t43r = Qu<intBits<4>, fracBits<1>, QuMode<RND::POS_INF>, OfMode<WRP::TCPL_SAT<1>>>;
+        using t400 = Qu<intBits<40>, fracBits<2>, OfMode<WRP::TCPL_SAT<3>>>;
+        using u200 = Qu<intBits<20>, fracBits<0>, isSigned<false>, OfMode<WRP::TCPL_SAT<1>>>;
+        const int64_t lo = -(1ll << 36), hi = (1ll << 36), step = (1ll << 27) + 12345;
+        cvt_table<s400, t43>(out, lo, hi, step);
+        cvt_table<s400, t43>(out, -300, 300, 7);
+        cvt_table<s400, t43r>(out, lo, hi, step);
+        cvt_table<s400, u200>(out, lo, hi, step);
+        cvt_table<s123, t43>(out, -32768, 32767, 97);
+        cvt_table<s123, t43r>(out, -32768, 32767, 97);
+        cvt_table<s123, t400>(out, -32768, 32767, 97);
+        break;
+    }
+    case 10: {
+        // the VARIADIC overload, Qreduce<L...>(q1, q2, ...) (readme.md:62; QuBLAS.h:4924-4951): any number of scalars of any types;
+        // an odd leftover is added AFTER the recursion over the pair sums, at the current level's type
+        using t1 = Qu<intBits<4>, fracBits<3>>;
+        using t2 = Qu<intBits<6>, fracBits<1>, QuMode<RND::POS_INF>, OfMode<SAT::SMGN>>;
+        using nar = Qu<intBits<5>, fracBits<2>, QuMode<RND::CONV>, OfMode<SAT::SMGN>>;
+        using wide = Qu<intBits<12>, fracBits<5>, QuMode<RND::ZERO>>;
+        auto emit = [&](const char* name, auto r, std::initializer_list<int64_t> raws, std::initializer_list<std::string> fmts, const char* levels) {
+            using R = decltype(r);
+            std::fprintf(out, "{\"kind\":\"reduce_variadic\",\"name\":\"%s\",\"levels\":%s,\"x\":[", name, levels);
+            size_t i = 0;
+            for (int64_t v : raws) std::fprintf(out, "%s%lld", i++ ? "," : "", (long long)v);
+            std::fprintf(out, "],\"fx\":[");
+            i = 0;
+            for (const auto& f : fmts) std::fprintf(out, "%s%s", i++ ? "," : "", f.c_str());
+            std::fprintf(out, "],\"y\":%lld,\"fr\":%s}\n", (long long)r.data.data, fmt_json<R>().c_str());
+        };
+        const std::string f1 = fmt_json<t1>(), f2 = fmt_json<t2>(), lv1 = "[" + fmt_json<nar>() + "]", lv2 = "[" + fmt_json<nar>() + "," + fmt_json<wide>() + "]";
+        for (int seed = 0; seed < 6; ++seed) {
+            t1 a, c, e, g; t2 b, d, f;
+            int64_t va = synth<t1>(seed + 1, 0, 0, 0), vb = synth<t2>(seed + 1, 0, 1, 0), vc = synth<t1>(seed + 1, 0, 2, 0), vd = synth<t2>(seed + 1, 0, 3, 0),
+                    ve = synth<t1>(seed + 1, 0, 4, 0), vf = synth<t2>(seed + 1, 0, 5, 0), vg = synth<t1>(seed + 1, 0, 6, 0);
+            a.data.data = va; b.data.data = vb; c.data.data = vc; d.data.data = vd; e.data.data = ve; f.data.data = vf; g.data.data = vg;
+            emit("var4_readme", Qreduce<t1>(a, b, a, b), {va, vb, va, vb}, {f1, f2, f1, f2}, ("[" + f1 + "]").c_str());
+            emit("var3_default", Qreduce<>(a, b, c), {va, vb, vc}, {f1, f2, f1}, "[]");
+            emit("var3_nar_wide", Qreduce<nar, wide>(a, b, c), {va, vb, vc}, {f1, f2, f1}, lv2.c_str());
+            emit("var5_nar_wide", Qreduce<nar, wide>(a, b, c, d, e), {va, vb, vc, vd, ve}, {f1, f2, f1, f2, f1}, lv2.c_str());
+            emit("var6_nar_wide", Qreduce<nar, wide>(a, b, c, d, e, f), {va, vb, vc, vd, ve, vf}, {f1, f2, f1, f2, f1, f2}, lv2.c_str());
+            emit("var7_nar_wide", Qreduce<nar, wide>(a, b, c, d, e, f, g), {va, vb, vc, vd, ve, vf, vg}, {f1, f2, f1, f2, f1, f2, f1}, lv2.c_str());
+            emit("var7_nar", Qreduce<nar>(a, b, c, d, e, f, g), {va, vb, vc, vd, ve, vf, vg}, {f1, f2, f1, f2, f1, f2, f1}, lv1.c_str());
+            emit("var5_list", Qreduce<TypeList<wide, nar>>(a, b, c, d, e), {va, vb, vc, vd, ve}, {f1, f2, f1, f2, f1}, ("[" + fmt_json<wide>() + "," + fmt_json<nar>() + "]").c_str());
+        }
+        break;
+    }
     default:
         return 2;
     }

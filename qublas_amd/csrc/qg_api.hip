@@ -261,7 +261,7 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
         }
         const int mn = LA < LB ? LA : LB;
         cfg = qg_mfma_pick(LA, LB, d->M * parts, d->N * parts, (ep ? QG_OPT_LOCKSTEP_TILES : 0u) | flags);   // (the fused / unfused element-wise chain keeps the kernel it was measured on)
-        if (cfg.variant && (int64_t)mn * d->K <= (1ll << 17) - 1 && !an->wide)   // (wide plans: the kernels' own epilogues are 64-bit; the composite plan's combine pass is not)
+        if (cfg.variant && (int64_t)mn * d->K <= (1ll << 17) - 1 && !an->wide && !an->generic_only)   // (wide plans: the kernels' own epilogues are 64-bit; the composite plan's combine pass is not)
             kernel = d->is_complex ? QG_KERNEL_MFMA_CPLX : ((LA == 1 && LB == 1) ? QG_KERNEL_MFMA_I8 : QG_KERNEL_MFMA_I8_LIMB);
         // (one output column whose tree the one-column kernels can walk: those stream A once at HBM rate; a composite plan would read
         // it once per limb group and write slabs — the batched Qreduce of 32-bit words with exact level types stays there)

@@ -30,6 +30,8 @@ struct Ctx {
     int max_fmt_bits = 1;   // widest storage (1 + W) of any format on the path
     bool raw_product = false;
     bool band = false;      // a multi-word value in [2^63, 2^64) / [-2^64, -2^63) can reach a one-word target (through())
+    bool final_step = false; // the conversion into C is being analysed (nothing follows it)
+    bool raw_c = false;     // C's WRP::TCPL_SAT lets the root through unclamped: host-word containers, general kernels
     void fail(int st, const char* why)
     {
         if (out->status == QG_OK) {
@@ -53,8 +55,7 @@ bool fmt_ok(Ctx& c, qfmt f)
     int W = (int)f.I + (int)f.F;
     if (W < 0) { c.fail(QG_EINVAL, "intBits + fracBits < 0"); return false; }
     if (f.Q > QG_TRN_SMGN) { c.fail(QG_EINVAL, "unknown QuMode code"); return false; }
-    if (f.O == QG_WRP_TCPL_SAT) { c.fail(QG_EUNSUPPORTED, "WRP::TCPL_SAT is a stub in the reference"); return false; }
-    if (f.O > QG_WRP_TCPL_SAT) { c.fail(QG_EINVAL, "unknown OfMode code"); return false; }
+    if (f.O > QG_WRP_TCPL_SAT) { c.fail(QG_EINVAL, "unknown OfMode code"); return false; }   // (WRP::TCPL_SAT: see through())
     if (W > 119) { c.fail(QG_EUNSUPPORTED, "format wider than 120 storage bits"); return false; }
     // ArbiInt<65>::maximum() is -1 (oneBits = 65 % 64 - 1 = 0 selects ~0 for the top word, QuBLAS.h:594-603): every saturating
     // conversion INTO a format of exactly 65 storage bits is an artefact in the reference (tests/golden/ref_wide_1: Qu<32,32>, Qu<64,0>)
@@ -142,6 +143,21 @@ Rng through(Ctx& c, Rng in, int fromF, qfmt to, bool identity, int nin = 0, QSte
     Rng R = fmt_range(to);
     Rng Re = R;
     if (to.O == QG_SAT_SMGN) Re.lo = to.S ? -R.hi : 0;
+    if (to.O == QG_WRP_TCPL_SAT) {
+        // WRP::TCPL_SAT<N> is a stub in the reference: intConvert returns its input (QuBLAS.h:2336-2344) and the assignment into the
+        // target's storage narrows it to the storage WORD (int32_t / int64_t, never masked to the format's bits: :353, :431-441;
+        // tests/golden/ref_scalar_9, ref_gemm_real_8).  In range that is the identity; out of range the value leaves its format,
+        // and what the reference's next operation would make of it (int32_t arithmetic on a word that holds more bits than its
+        // type says) is not something to build on: accepted only where nothing follows — the conversion into C.
+        if (r.lo >= R.lo && r.hi <= R.hi) { if (st) st->O = QG_SAT_TCPL; return r; }   // (any in-range overflow mode: a clamp that never fires)
+        if (!c.final_step) { c.fail(QG_EUNSUPPORTED, "WRP::TCPL_SAT (a stub in the reference) whose value can leave its format before the last conversion"); return r; }
+        c.exact = false;
+        c.raw_c = true;
+        const I128 full = mbits <= 32 ? ((I128)1 << 31) : mbits <= 64 ? ((I128)1 << 63) : ((I128)1 << 126);
+        if (r.lo < -full) r.lo = -full;
+        if (r.hi > full - 1) r.hi = full - 1;
+        return r;
+    }
     if (nr > 64 && mbits <= 64 && to.O <= QG_SAT_SMGN) {
         // a multi-word value compared with one-word bounds: the reference reads the low word as a signed number (operator<=>,
         // QuBLAS.h:1781-1793) and narrows by keeping the low word (:436-441).  Identical to the arithmetic definition unless the
@@ -481,7 +497,9 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
             len = (len + 1) / 2;
         }
         bool tree_exact = c.exact;
+        c.final_step = true;
         do_cvt(c, cur, d->c[p], &T.c_cvt[p]);
+        c.final_step = false;
         c.exact = tree_exact; // the epilogue is allowed (and expected) to quantise
         if (!cx) {
             // linear-class epilogue: D = sum a*b at frac Fa+Fb, one round+overflow into C.
@@ -490,6 +508,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
             int fp = (int)d->a[0].F + (int)d->b[0].F;
             out->lin.to_c[0] = make_step(fp, d->c[0], false);
             out->lin.to_c[0].refcmp = T.c_cvt[0].refcmp;   // (the root's type width decides how the reference compares with C's bounds)
+            if (d->c[0].O == QG_WRP_TCPL_SAT && !T.c_cvt[0].identity) out->lin.to_c[0].O = T.c_cvt[0].O;   // (in range: a clamp that never fires)
             out->lin.to_c[1] = out->lin.to_c[0];
             if (out->lin.to_c[0].d > 100 || out->lin.to_c[0].d < -100) c.exact = false;
         }
@@ -532,8 +551,9 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     // general tree kernel's 128-bit instantiation, or, for the linear class, the composite MFMA plan with a 128-bit combine pass.
     if (c.max_bits_np > 120 || c.max_bits > 127) { c.fail(QG_EUNSUPPORTED, "an intermediate needs more than 120 bits"); return; }
     out->wide = (c.max_bits_np > 62 || c.max_bits > 64 || g_fmt_bits_seen > 62) ? 1 : 0;
-    out->band = c.band ? 1 : 0;
-    if (out->wide && cx) c.exact = false;   // (complex linear class: 62-bit combine only)
+    out->band = (c.band || c.raw_c) ? 1 : 0;
+    out->generic_only = c.raw_c ? 1 : 0;
+    if ((out->wide || out->generic_only) && cx) c.exact = false;   // (complex linear class: its own 62-bit combine only)
     if (!out->wide && (out->lin.to_c[0].d > 61 || out->lin.to_c[0].d < -61)) c.exact = false;
     out->linear_ok = c.exact ? 1 : 0;
     out->cls = out->linear_ok ? QG_CLASS_LINEAR : QG_CLASS_TREE;
@@ -543,7 +563,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     out->tree_fast_ok = 0;
     // (any K with 5..16 levels: the packed operands are zero-padded to 2^n_levels leaves — a node whose right child is a
     // zero is the reference's converting copy of an odd leftover, QuBLAS.h:4977-4980)
-    if (!cx && !out->wide && d->n_levels <= 16 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) {
+    if (!cx && !out->wide && !out->generic_only && d->n_levels <= 16 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) {
         const int bitsA = 1 + (int)d->a[0].I + (int)d->a[0].F, bitsB = 1 + (int)d->b[0].I + (int)d->b[0].F;
         const int sh = T.mul[0].q.d;
         int bh = bitsB - sh;
@@ -569,9 +589,9 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         if (one && W + 1 + T.mul[0].q.d <= 30) out->fast_mode = pf.O == QG_SAT_ZERO ? 1 : 2;
     }
     // one-column kernel (qg_gemv.hip): products are formed in 64 bits, everything else in 32
-    out->gemv_ok = (!cx && !out->wide && d->N == 1 && d->n_levels <= 30 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
+    out->gemv_ok = (!cx && !out->wide && !out->generic_only && d->N == 1 && d->n_levels <= 30 && c.max_bits_np <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     // ... with 64-bit tree values when only the ELEMENTS fit 32 storage bits (sums of 32-bit words, wide level types)
-    out->gemv_wide_ok = (!cx && !out->wide && !out->gemv_ok && d->N == 1 && d->n_levels <= 30 &&
+    out->gemv_wide_ok = (!cx && !out->wide && !out->generic_only && !out->gemv_ok && d->N == 1 && d->n_levels <= 30 &&
                          1 + (int)d->a[0].I + (int)d->a[0].F <= 32 && 1 + (int)d->b[0].I + (int)d->b[0].F <= 32) ? 1 : 0;
     // fast_mode 3: per-level formats, but every step "add a constant, shift right, clamp" (QFix, qg_plan.h): TRN::TCPL /
     // RND::POS_INF / RND::NEG_INF rounding; SAT::TCPL / SAT::SMGN (one clamp), SAT::ZERO (range test + select) or WRP::TCPL
@@ -679,7 +699,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
             }
         }
     }
-    out->tree64_ok = (!cx && !out->wide && d->n_levels <= 16) ? 1 : 0;   // (64-bit values: not a wide plan)
+    out->tree64_ok = (!cx && !out->wide && !out->generic_only && d->n_levels <= 16) ? 1 : 0;   // (64-bit values: not a wide plan)
     // QG_DESC_LEFTOVER0_COPY with an odd K: the zero-padded kernels would form the leftover as x + 0 in level 0's type — a
     // conversion, where the reference copies — so only the general kernel, which has the leftover step itself, may run it
     const bool copy0 = (d->flags & QG_DESC_LEFTOVER0_COPY) && (d->K & 1) && d->K > 1;
@@ -703,7 +723,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         if (one) out->gemv_fixed = lf.O == QG_SAT_ZERO ? 1 : 2;
         else if (rec_form) out->gemv_fixed = rec_form;   // per-level formats in compact records (3: every level clamps, 5: kinds)
     }
-    out->cplx_fast_ok = (cx && !out->wide && !copy0 && d->n_levels <= 16 && c.max_bits <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
+    out->cplx_fast_ok = (cx && !out->wide && !out->generic_only && !copy0 && d->n_levels <= 16 && c.max_bits <= 31 && c.max_fmt_bits <= 31) ? 1 : 0;
     // fixed-mode variant of the complex kernel (BASELINE configuration 5's "RND + SAT"): every sub-operation and every tree
     // step either the identity, or an exact left shift / a rounding shift with RND::POS_INF, followed by SAT::TCPL, so a
     // step is (v + 2^(d-1)) >> d (or v << -d) and one clamp

@@ -70,7 +70,8 @@ struct QAnalysis {
     int gemv_fixed;          // 1 / 2: every tree level has one format, no rounding shift, SAT::ZERO / SAT::TCPL (fixed-mode nodes); 3 / 5: per-level formats in compact records
     int gemv_b_bit;          // ... and B is a 0/1 vector whose product with a is a itself (the Qreduce lowering)
     int wide;                // an intermediate, a level / product format or C needs more than 62 bits: 128-bit kernels (qg_ops.h: qg_step_w)
-    int band;                // ... and a multi-word value in [2^63, 2^64) / [-2^64, -2^63) can reach a one-word target (QStep::refcmp)
+    int generic_only;        // C's WRP::TCPL_SAT can let the root through unclamped: the general kernels / the composite plan's combine pass only
+    int band;                // C may hold a value outside its format (host-word containers): WRP::TCPL_SAT, or a multi-word value in [2^63, 2^64) / [-2^64, -2^63) can reach a one-word target (QStep::refcmp)
     char reason[96];
     QTreeTable tree;
     QLinearEpilogue lin;

@@ -426,6 +426,37 @@ def lower_reduce(e: Qu, rows: int, length: int, levels=None) -> qgemul_desc:
     return lower(e, ONE, ec, rows, 1, length, add_args=levels, mul_args=e, transposed_a=True)
 
 
+# ---- the VARIADIC Qreduce<L...>(q1, q2, ...) (readme.md:62; QuBLAS.h:4924-4951): any number of scalars of any types.  Level l adds
+# neighbours with Qadd<T_l> (T_l = L[min(l, n-1)], no L: default merge); an odd leftover is added AFTER the recursion over the
+# pair sums, with the CURRENT level's type (the vector overload copies it into the next level instead).  Every Qadd<T>(x, y) of two
+# scalars of different types is one two-term Qgemul on the engine: both operands written exactly in a common super-format (the
+# alignment shifts Qadd performs itself, QuBLAS.h:3190), times 1, level 0 = the node's result type.
+def add_node(fx: Qu, fy: Qu, tags: TagLike = None):
+    """(descriptor of the K = 2 Qgemul that computes Qadd<tags>(x, y), super-format, (shift of x, shift of y), result type)"""
+    fr = add_merge(fx, fy, tags)
+    F = max(fx.fracBits, fy.fracBits)
+    sup = Qu(max(fx.intBits, fy.intBits), F, fx.isSigned or fy.isSigned)
+    d = lower(sup, ONE, fr, 1, 1, 2, add_args=[fr], mul_args=sup, transposed_a=True)
+    return d, sup, (F - fx.fracBits, F - fy.fracBits), fr
+
+
+def reduce_variadic(values: Sequence[int], fmts: Sequence[Qu], levels: Sequence[Qu], node, layer: int = 0):
+    """The reference's variadic reduction order and types; node(x, fx, y, fy, tags) -> (value, format) performs one Qadd."""
+    n = len(values)
+    if n == 1:
+        return values[0], fmts[0]
+    tags = levels[min(layer, len(levels) - 1)] if levels else None
+    pv, pf = [], []
+    for i in range(n // 2):
+        v, f = node(values[2 * i], fmts[2 * i], values[2 * i + 1], fmts[2 * i + 1], tags)
+        pv.append(v)
+        pf.append(f)
+    rv, rf = reduce_variadic(pv, pf, levels, node, layer + 1)
+    if n % 2:
+        return node(rv, rf, values[-1], fmts[-1], tags)
+    return rv, rf
+
+
 # ---- element-wise epilogue (SURVEY.md 8-f #2): the lazy tensor operators after a Qgemul ----
 
 @dataclass(frozen=True)

@@ -46,6 +46,26 @@ int main()
         auto r1 = Qreduce<Qu<intBits<4>, fracBits<6>, OfMode<SAT::ZERO>>>(w);
         auto r2 = Qreduce<>(w);
         std::printf("{\"name\":\"qreduce_smgn\",\"C\":[%lld,%lld]}\n", (long long)r1.data, (long long)r2.data);
+        // the VARIADIC overload (readme.md:62): scalars of two types, the reference tables' inputs of seed 1 (tests/golden/ref_scalar_10)
+        {
+            using t1 = Qu<intBits<4>, fracBits<3>>;
+            using t2 = Qu<intBits<6>, fracBits<1>, QuMode<RND::POS_INF>, OfMode<SAT::SMGN>>;
+            using nar = Qu<intBits<5>, fracBits<2>, QuMode<RND::CONV>, OfMode<SAT::SMGN>>;
+            using wide = Qu<intBits<12>, fracBits<5>, QuMode<RND::ZERO>>;
+            t1 a, c, e, g; t2 b, d, f;
+            a.fill(17); b.fill(120); c.fill(-15); d.fill(96); e.fill(-55);
+            f.fill(-25); g.fill(-12);
+            auto v4 = Qreduce<t1>(a, b, a, b);
+            auto v3 = Qreduce<>(a, b, c);
+            auto v5 = Qreduce<nar, wide>(a, b, c, d, e);
+            auto v6 = Qreduce<nar, wide>(a, b, c, d, e, f);
+            auto v7 = Qreduce<nar, wide>(a, b, c, d, e, f, g);
+            auto v7n = Qreduce<nar>(a, b, c, d, e, f, g);
+            auto v5l = Qreduce<TypeList<wide, nar>>(a, b, c, d, e);
+            std::printf("{\"name\":\"qreduce_variadic\",\"C\":[%lld,%lld,%lld,%lld,%lld,%lld,%lld],\"F\":[%d,%d,%d,%d,%d,%d,%d]}\n", (long long)v4.data, (long long)v3.data,
+                        (long long)v5.data, (long long)v6.data, (long long)v7.data, (long long)v7n.data, (long long)v5l.data, decltype(v4)::fracB, decltype(v3)::fracB,
+                        decltype(v5)::fracB, decltype(v6)::fracB, decltype(v7)::fracB, decltype(v7n)::fracB, decltype(v5l)::fracB);
+        }
     } catch (const std::exception& e) {
         std::printf("{\"error\":\"%s\"}\n", e.what());
         return 3;

@@ -89,10 +89,20 @@ def test_classify_limbs_and_kernel():
 
 def test_rejections():
     e = Qu(4, 3)
-    # WRP::TCPL_SAT is a stub in the reference (QuBLAS.h:2336-2344)
-    d = lower(e, e, Qu(4, 3, OfMode=4), 4, 4, 4)
-    st, _ = capi.classify_status(d)
-    assert st == capi.QG_EUNSUPPORTED
+    # WRP::TCPL_SAT is a stub in the reference (QuBLAS.h:2336-2344: the value goes into the storage word unclamped).  As C's OfMode it
+    # runs (general kernels, host-word containers: tests/golden/ref_gemm_real_8); where the value provably stays in its format it is
+    # a no-op; as the mode of a level whose sums can leave the format it is refused
+    st, info = capi.classify_status(lower(e, e, Qu(4, 3, OfMode=4), 4, 4, 4))            # default tags: the root is already inside (4,3)
+    assert st == capi.QG_OK and capi.KERNEL_NAMES[info.kernel] == "tree_i32", info.reason
+    st, info = capi.classify_status(lower(e, e, Qu(4, 3, OfMode=4), 4, 4, 4, add_args=[Qu(12, 3)]))   # a wide root into C's 32-bit word
+    assert st == capi.QG_OK and capi.KERNEL_NAMES[info.kernel] == "tree_i64" and info.packed_bytes[2] == 4 * 4 * 4, info.reason
+    from qublas_amd.desc import Tags
+    st, info = capi.classify_status(lower(e, e, Qu(4, 3, OfMode=4), 300, 300, 64, mul_args=Tags(9, 6), add_args=[Qu(19, 6)]))
+    assert st == capi.QG_OK and capi.KERNEL_NAMES[info.kernel] == "mfma_i8" and b"combine" in info.reason, info.reason
+    st, info = capi.classify_status(lower(e, e, e, 64, 64, 64, mul_args=Qu(9, 6, OfMode=4), add_args=[Qu(19, 6, OfMode=4)]))
+    assert st == capi.QG_OK and capi.KERNEL_NAMES[info.kernel] == "mfma_i8", info.reason
+    st, info = capi.classify_status(lower(e, e, e, 64, 64, 64, add_args=[Qu(5, 3, OfMode=4)]))
+    assert st == capi.QG_EUNSUPPORTED and b"TCPL_SAT" in info.reason
     # a 32-bit rounding shift with an RND mode is a reference width artefact (tests/test_oracle_golden.py)
     d = lower(Qu(30, 30), Qu(1, 0), Qu(6, -2, QuMode=4), 4, 4, 4, mul_args=Qu(31, 30))
     st, info = capi.classify_status(d)

@@ -77,6 +77,11 @@ def test_standalone_header_runs_on_gpu(tmp_path):
         exp.append(int(oracle.gemm(lower_reduce(sm, 1, 16, levels), w, np.ones(16, dtype=np.int32), ec)[0]))
     qs = [json.loads(l) for l in lines if '"qreduce_smgn"' in l]
     assert qs and qs[0]["C"] == exp
+    # the variadic overload Qreduce<L...>(q1, q2, ...) on the reference tables' inputs of seed 1 (tests/golden/ref_scalar_10)
+    var = {t["name"]: t for t in G.scalar_tables(10) if t["x"][:2] == [17, 120]}
+    names = ["var4_readme", "var3_default", "var5_nar_wide", "var6_nar_wide", "var7_nar_wide", "var7_nar", "var5_list"]
+    qv = [json.loads(l) for l in lines if '"qreduce_variadic"' in l]
+    assert qv and qv[0]["C"] == [var[n]["y"] for n in names] and qv[0]["F"] == [var[n]["fr"][1] for n in names]
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="needs AMD clang (C++23)")

@@ -33,6 +33,20 @@ def width_artefact(src: Qu, dst: Qu) -> bool:
     return (src.fracBits - dst.fracBits) in (32, 64) and dst.QuMode <= 4
 
 
+def test_tcpl_sat_stub_tables(oracle):
+    """tests/golden/ref_scalar_9: WRP::TCPL_SAT<N> targets — the reference's intConvert stub returns its input and the target's
+    storage word (int32_t / int64_t) keeps what fits"""
+    L = oracle.lib()
+    n = 0
+    for t in G.scalar_tables(9):
+        f, to = Qu.from_tuple(t["from"]).c(), Qu.from_tuple(t["to"]).c()
+        assert to.O == 4
+        for x, y in zip(range(t["lo"], t["hi"] + 1, t["step"]), t["y"]):
+            assert L.qoracle_convert(x, f, to) == y, (t["from"], t["to"], x)
+            n += 1
+    assert n > 3000
+
+
 @pytest.mark.parametrize("part", [0, 1, 2])
 def test_convert_truth_tables(oracle, part):
     L = oracle.lib()

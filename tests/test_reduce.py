@@ -65,3 +65,54 @@ def test_batched_reduce_large(oracle):
     got = capi.run(d, np.zeros(rows, np.int32), A, ones)
     exp = oracle.gemm(d, A, ones, ec, nthreads=8)
     assert np.array_equal(got, exp)
+
+
+# ---- the variadic overload Qreduce<L...>(q1, q2, ...): tests/golden/ref_scalar_10 (reference-generated: readme's 4-argument call,
+# lengths 3 / 5 / 6 / 7, mixed argument types, 0 / 1 / 2-entry level lists and a TypeList)
+def _variadic():
+    return [t for t in G.scalar_tables(10) if t["kind"] == "reduce_variadic"]
+
+
+def test_variadic_reduce_order_and_types(oracle):
+    """the reduction order and result-type rules of qublas_amd.desc.reduce_variadic, every Qadd by the oracle's scalar restatement"""
+    from qublas_amd.desc import add_merge, reduce_variadic
+    L = oracle.lib()
+
+    def node(x, fx, y, fy, tags):
+        fr = add_merge(fx, fy, tags)
+        return L.qoracle_add(x, fx.c(), y, fy.c(), fr.c(), 0), fr
+
+    ts = _variadic()
+    assert len(ts) == 48
+    for t in ts:
+        v, f = reduce_variadic(t["x"], [Qu.from_tuple(q) for q in t["fx"]], [Qu.from_tuple(q) for q in t["levels"]], node)
+        assert (v, list(f.as_tuple())) == (t["y"], t["fr"]), t["name"]
+
+
+def test_variadic_node_lowering(oracle):
+    """... and every Qadd as the two-term Qgemul the engine runs (desc.add_node), on the oracle's GEMM"""
+    from qublas_amd.desc import add_node, reduce_variadic
+
+    def node(x, fx, y, fy, tags):
+        d, sup, (sx, sy), fr = add_node(fx, fy, tags)
+        A = np.array([x << sx, y << sy], dtype=oracle.host_dtype(sup))
+        return int(oracle.gemm(d, A, np.ones(2, np.int32), fr)[0]), fr
+
+    for t in _variadic():
+        v, f = reduce_variadic(t["x"], [Qu.from_tuple(q) for q in t["fx"]], [Qu.from_tuple(q) for q in t["levels"]], node)
+        assert (v, list(f.as_tuple())) == (t["y"], t["fr"]), t["name"]
+
+
+@pytest.mark.gpu
+def test_variadic_reduce_on_gpu(oracle):
+    from qublas_amd import capi
+    from qublas_amd.desc import add_node, reduce_variadic
+
+    def node(x, fx, y, fy, tags):
+        d, sup, (sx, sy), fr = add_node(fx, fy, tags)
+        A = np.array([x << sx, y << sy], dtype=oracle.host_dtype(sup))
+        return int(capi.run(d, np.zeros(1, dtype=oracle.host_dtype(fr)), A, np.ones(2, np.int32))[0]), fr
+
+    for t in _variadic():
+        v, f = reduce_variadic(t["x"], [Qu.from_tuple(q) for q in t["fx"]], [Qu.from_tuple(q) for q in t["levels"]], node)
+        assert (v, list(f.as_tuple())) == (t["y"], t["fr"]), t["name"]
