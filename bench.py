@@ -352,14 +352,15 @@ def c4_leg(args, ctx, wls, capi, net, world, rank):
 
             def send(g, c):
                 if rank == 0:
-                    net.gather(tCs[g][c], cbytes if c < myc else 0, land[g][c], [cbytes if c < counts[r] else 0 for r in range(world)])
+                    net.gather(tCs[g][c], cbytes if c < myc else 0, land[g][c], [cbytes if c < counts[r] else 0 for r in range(world)], slot=g)
                 else:
-                    net.gather(tCs[g][c], cbytes if c < myc else 0)
+                    net.gather(tCs[g][c], cbytes if c < myc else 0, slot=g)
 
             def step(i):
                 g = i & 1
                 if gather:
-                    net.fence()                 # (device-side: generation g was handed to gathers two steps ago; they are done before it is rewritten)
+                    net.fence(g)                # (device-side: generation g was handed to gathers two steps ago; they are done before it is rewritten —
+                                                #  the gathers of the OTHER generation travel on while this step's GEMMs run)
                 for c in range(nchunks):
                     if c < myc:
                         plan.execute(tCs[g][c], tAs[c], tB)
@@ -482,13 +483,13 @@ def main(argv=None):
         g = (state["i"] & 1) if use_dist else 0
         state["i"] += 1
         if use_dist:
-            net.fence()                # device-side: the GEMM below is ordered behind the gather that still reads buffer g
+            net.fence(g)               # device-side: the GEMM below is ordered behind the gather that still reads buffer g (two steps ago)
         plan.execute(tCs[g], tA, tB)
         if use_dist:                   # the ONE collective of the path
             if rank == 0:
-                net.gather(tCs[g], cbytes, land[g], [cbytes] * world)
+                net.gather(tCs[g], cbytes, land[g], [cbytes] * world, slot=g)
             else:
-                net.gather(tCs[g], cbytes)
+                net.gather(tCs[g], cbytes, slot=g)
 
     def barrier():
         if use_dist:

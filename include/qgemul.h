@@ -388,21 +388,24 @@ int qgemul_run_sharded(const qgemul_desc* d, void* C, const void* A, const void*
  *   qgemul_gather_packed_c  asynchronous.  The band was produced on the context's stream; it travels on the communicator's own
  *                           stream (grouped ncclSend / ncclRecv of bytes), so the next GEMM may run meanwhile.  On the root,
  *                           recv[r] / recv_bytes[r] = where rank r's band lands (recv[root] may equal `send`: no copy);
- *                           elsewhere they are ignored.  A shard cut into row chunks = one call per chunk.
- *   qgemul_comm_fence       the context's stream waits (on the device) for the gathers issued so far: call it before work that
- *                           overwrites a buffer a gather still reads / before the root unpacks
+ *                           elsewhere they are ignored.  A shard cut into row chunks = one call per chunk.  `slot`
+ *                           (0 .. QG_COMM_SLOTS-1) names the buffer generation the call reads / writes: double-buffered
+ *                           callers alternate slots so that a fence waits only for the generation it is about to reuse.
+ *   qgemul_comm_fence       the context's stream waits (on the device) for the gathers issued under `slot` (-1: all of
+ *                           them): call it before work that overwrites a buffer a gather still reads / before the root unpacks
  *   qgemul_comm_sync        the host waits for them
  *   qgemul_comm_barrier / qgemul_comm_max_f64   every rank's streams drained / the maximum of one double over the ranks
  *                           (timing of a multi-rank run without any other communication library)
  * Errors: QG_ERCCL, qgemul_last_rccl_error() = the ncclResult_t (-1: no usable librccl). */
 typedef struct qgemul_comm qgemul_comm;
 #define QG_COMM_ID_BYTES 128
+#define QG_COMM_SLOTS 4
 int qgemul_comm_unique_id(void* id_out);
 int qgemul_comm_create(qgemul_ctx* c, int nranks, int rank, const void* unique_id, qgemul_comm** out);
 void qgemul_comm_destroy(qgemul_comm* m);
 int qgemul_comm_info(const qgemul_comm* m, int* nranks, int* rank, int* rccl_version);   /* ncclCommCount, ncclCommUserRank, ncclGetVersion */
-int qgemul_gather_packed_c(qgemul_comm* m, const void* send, size_t send_bytes, void* const* recv, const size_t* recv_bytes, int root);
-int qgemul_comm_fence(qgemul_comm* m);
+int qgemul_gather_packed_c(qgemul_comm* m, const void* send, size_t send_bytes, void* const* recv, const size_t* recv_bytes, int root, int slot);
+int qgemul_comm_fence(qgemul_comm* m, int slot);
 int qgemul_comm_sync(qgemul_comm* m);
 int qgemul_comm_barrier(qgemul_comm* m);
 int qgemul_comm_max_f64(qgemul_comm* m, double* inout);

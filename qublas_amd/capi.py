@@ -114,8 +114,8 @@ def lib() -> C.CDLL:
         L.qgemul_comm_destroy.restype = None
         pi = C.POINTER(C.c_int)
         L.qgemul_comm_info.argtypes = [vp, pi, pi, pi]
-        L.qgemul_gather_packed_c.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_int]
-        L.qgemul_comm_fence.argtypes = [vp]
+        L.qgemul_gather_packed_c.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_int, C.c_int]
+        L.qgemul_comm_fence.argtypes = [vp, C.c_int]
         L.qgemul_comm_sync.argtypes = [vp]
         L.qgemul_comm_barrier.argtypes = [vp]
         L.qgemul_comm_max_f64.argtypes = [vp, C.POINTER(C.c_double)]
@@ -257,15 +257,15 @@ class Comm:
         _chk_rccl(lib().qgemul_comm_info(self.h, C.byref(n), C.byref(r), C.byref(v)), "qgemul_comm_info")
         return n.value, r.value, v.value
 
-    def gather(self, send_ptr: int, send_bytes: int, recv_ptrs=None, recv_bytes=None, root: int = 0):
+    def gather(self, send_ptr: int, send_bytes: int, recv_ptrs=None, recv_bytes=None, root: int = 0, slot: int = 0):
         rp = rb = None
         if recv_ptrs is not None:
             rp = (C.c_void_p * self.nranks)(*[p or None for p in recv_ptrs])
             rb = (C.c_size_t * self.nranks)(*recv_bytes)
-        _chk_rccl(lib().qgemul_gather_packed_c(self.h, C.c_void_p(send_ptr), send_bytes, rp, rb, root), "qgemul_gather_packed_c")
+        _chk_rccl(lib().qgemul_gather_packed_c(self.h, C.c_void_p(send_ptr), send_bytes, rp, rb, root, slot), "qgemul_gather_packed_c")
 
-    def fence(self):
-        _chk_rccl(lib().qgemul_comm_fence(self.h), "qgemul_comm_fence")
+    def fence(self, slot: int = -1):
+        _chk_rccl(lib().qgemul_comm_fence(self.h, slot), "qgemul_comm_fence")
 
     def sync(self):
         _chk_rccl(lib().qgemul_comm_sync(self.h), "qgemul_comm_sync")

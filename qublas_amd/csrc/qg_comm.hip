@@ -106,7 +106,7 @@ struct qgemul_comm {
     int nranks, rank;
     hipStream_t stream;     // the gathers' own stream: a band travels while the next GEMM runs on the context's stream
     hipEvent_t produced;    // context stream -> comm stream: the band to send is complete
-    hipEvent_t sent;        // comm stream -> context stream: the send buffers may be overwritten
+    hipEvent_t sent[QG_COMM_SLOTS];   // comm stream -> context stream: the buffers of the gathers issued under slot s may be reused
     double* scratch;        // 16 bytes on the device (barrier / max)
 };
 
@@ -147,8 +147,13 @@ int qgemul_comm_create(qgemul_ctx* c, int nranks, int rank, const void* unique_i
     memcpy(&id, unique_id, sizeof id);
     const ncclResult_t r = a.CommInitRank(&m->comm, nranks, id, rank);
     if (r != ncclSuccess) { g_last_rccl = (int)r; delete m; return QG_ERCCL; }
-    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->produced, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->sent, hipEventDisableTiming) != hipSuccess || hipMalloc((void**)&m->scratch, 16) != hipSuccess) {
+    bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&m->produced, hipEventDisableTiming) == hipSuccess &&
+              hipMalloc((void**)&m->scratch, 16) == hipSuccess;
+    for (int i = 0; ok && i < QG_COMM_SLOTS; ++i) {
+        ok = hipEventCreateWithFlags(&m->sent[i], hipEventDisableTiming) == hipSuccess;
+        if (ok) ok = hipEventRecord(m->sent[i], m->stream) == hipSuccess;   // (a slot nobody has used yet is "done")
+    }
+    if (!ok) {
         qgemul_comm_destroy(m);
         return QG_EHIP;
     }
@@ -164,7 +169,8 @@ void qgemul_comm_destroy(qgemul_comm* m)
     if (m->comm) rccl().CommDestroy(m->comm);
     if (m->scratch) hipFree(m->scratch);
     if (m->produced) hipEventDestroy(m->produced);
-    if (m->sent) hipEventDestroy(m->sent);
+    for (int i = 0; i < QG_COMM_SLOTS; ++i)
+        if (m->sent[i]) hipEventDestroy(m->sent[i]);
     if (m->stream) hipStreamDestroy(m->stream);
     delete m;
 }
@@ -179,9 +185,9 @@ int qgemul_comm_info(const qgemul_comm* m, int* nranks, int* rank, int* rccl_ver
     return QG_OK;
 }
 
-int qgemul_gather_packed_c(qgemul_comm* m, const void* send, size_t send_bytes, void* const* recv, const size_t* recv_bytes, int root)
+int qgemul_gather_packed_c(qgemul_comm* m, const void* send, size_t send_bytes, void* const* recv, const size_t* recv_bytes, int root, int slot)
 {
-    if (!m || root < 0 || root >= m->nranks || (send_bytes && !send)) return QG_EINVAL;
+    if (!m || root < 0 || root >= m->nranks || (send_bytes && !send) || slot < 0 || slot >= QG_COMM_SLOTS) return QG_EINVAL;
     if (m->rank == root && (!recv || !recv_bytes)) return QG_EINVAL;
     RcclApi& a = rccl();
     DevScope scope(m->device);
@@ -205,15 +211,17 @@ int qgemul_gather_packed_c(qgemul_comm* m, const void* send, size_t send_bytes, 
     } else if (send_bytes) {
         QG_RCCL(a.Send(send, send_bytes, ncclChar, root, m->comm, m->stream));
     }
-    QG_HIPC(hipEventRecord(m->sent, m->stream));
+    QG_HIPC(hipEventRecord(m->sent[slot], m->stream));
     return QG_OK;
 }
 
-int qgemul_comm_fence(qgemul_comm* m)
+int qgemul_comm_fence(qgemul_comm* m, int slot)
 {
-    if (!m) return QG_EINVAL;
+    if (!m || slot < -1 || slot >= QG_COMM_SLOTS) return QG_EINVAL;
     DevScope scope(m->device);
-    QG_HIPC(hipStreamWaitEvent((hipStream_t)qgemul_ctx_stream(m->ctx), m->sent, 0));
+    hipStream_t cs = (hipStream_t)qgemul_ctx_stream(m->ctx);
+    for (int i = 0; i < QG_COMM_SLOTS; ++i)
+        if (slot < 0 || slot == i) QG_HIPC(hipStreamWaitEvent(cs, m->sent[i], 0));
     return QG_OK;
 }
 

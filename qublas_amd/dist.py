@@ -179,11 +179,11 @@ class RcclTransport:
         self.ctx, self.comm = ctx, comm     # (the communicator orders its gathers behind THIS context's stream)
         self.world, self.rank = comm.nranks, comm.rank
 
-    def gather(self, send_ptr, send_bytes, recv_ptrs=None, recv_bytes=None):
-        self.comm.gather(send_ptr, send_bytes, recv_ptrs, recv_bytes, 0)
+    def gather(self, send_ptr, send_bytes, recv_ptrs=None, recv_bytes=None, slot=0):
+        self.comm.gather(send_ptr, send_bytes, recv_ptrs, recv_bytes, 0, slot)
 
-    def fence(self):
-        self.comm.fence()
+    def fence(self, slot=-1):
+        self.comm.fence(slot)
 
     def barrier(self):
         self.comm.barrier()
@@ -203,7 +203,7 @@ class HostTransport:
         self.ctx, self.ch = ctx, channel
         self.world, self.rank = channel.world, channel.rank
 
-    def gather(self, send_ptr, send_bytes, recv_ptrs=None, recv_bytes=None):
+    def gather(self, send_ptr, send_bytes, recv_ptrs=None, recv_bytes=None, slot=0):
         buf = np.empty(send_bytes, np.uint8)
         if send_bytes:
             self.ctx.d2h(buf, send_ptr)
@@ -214,7 +214,7 @@ class HostTransport:
                     assert len(b) == recv_bytes[r], (r, len(b), recv_bytes[r])
                     self.ctx.h2d(recv_ptrs[r], np.frombuffer(b, np.uint8))
 
-    def fence(self):
+    def fence(self, slot=-1):
         pass
 
     def barrier(self):

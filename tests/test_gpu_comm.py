@@ -29,10 +29,10 @@ def test_world_of_one_rank(oracle):
         hc = ctx.alloc(M * N * 4)
         p.fill(capi.OPERAND_A, 1, 0, pa)
         p.fill(capi.OPERAND_B, 2, 0, pb)
-        for _ in range(3):                                     # (repeated: the events are re-recorded per call)
+        for i in range(3):                                     # (repeated: the events are re-recorded per call; alternating slots)
             p.execute(pc, pa, pb)
-            comm.gather(pc, b[2], [land], [b[2]], 0)           # the band lands in the root's buffer
-            comm.fence()                                       # the context's stream waits for it
+            comm.gather(pc, b[2], [land], [b[2]], 0, slot=i & 1)   # the band lands in the root's buffer
+            comm.fence(i & 1)                                  # the context's stream waits for that generation
             p.unpack_c(land, hc)
         got = np.zeros(M * N, np.int32)
         ctx.d2h(got, hc)
@@ -47,4 +47,4 @@ def test_world_of_one_rank(oracle):
     B = oracle.fill(e, K * N, 2)
     assert np.array_equal(got, oracle.gemm(d, A, B, ec, nthreads=8))
     # argument errors do not reach RCCL
-    assert capi.lib().qgemul_comm_fence(None) == capi.QG_EINVAL
+    assert capi.lib().qgemul_comm_fence(None, 0) == capi.QG_EINVAL
