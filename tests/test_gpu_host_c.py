@@ -1,7 +1,9 @@
 """qgemul_execute_host_c: the result in the REFERENCE layout on the device.  On the two-group MFMA kernels with a 4- or 8-byte
 C element the epilogue stores its runs of rows straight into that layout (no packed C, no unpack pass); every other plan runs
 execute + unpack behind the same call.  Either way the bytes must equal qgemul_execute followed by qgemul_unpack_c — ragged M
-and N (rows / columns of the last tiles are masked), padded and odd leading dimensions (vector and scalar stores)."""
+and N (rows / columns of the last tiles are masked), padded and odd leading dimensions (vector and scalar stores) — AND a block
+of rows of the result must equal the CPU oracle on the same synthetic operands (comparing the engine with itself
+proves no parity by itself)."""
 import numpy as np
 import pytest
 
@@ -29,7 +31,7 @@ CASES = [
 
 @pytest.mark.parametrize("pad", [0, 4, 3])    # tight, padded keeping 16-byte alignment, odd (scalar stores)
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[3]}x{c[4]}x{c[5]}_{c[1].intBits}_{c[1].fracBits}")
-def test_host_layout_c_equals_execute_plus_unpack(case, pad):
+def test_host_layout_c_equals_execute_plus_unpack(oracle, case, pad):
     ea, ec, kw, M, N, K, direct = case
     d = lower(ea, ea, ec, M, N, K, **kw)
     with capi.Context() as ctx:
@@ -60,3 +62,9 @@ def test_host_layout_c_equals_execute_plus_unpack(case, pad):
     assert np.count_nonzero(v[:, :M]) > 0.5 * M * N
     if pad:
         assert (a.reshape(N, ldc * eb)[:, M * eb:] == 0x5a).all()     # the padding between columns is never written
+    # a block of rows against the oracle (the engine's fill kernel and oracle.fill share the generator: seeds 3 / 4)
+    rows = (max(0, M - 24), M)
+    A = oracle.fill(ea, M * K, 3)
+    B = oracle.fill(ea, K * N, 4)
+    exp = oracle.gemm(d, A, B, ec, rows=rows, nthreads=8).reshape(N, M)
+    assert np.array_equal(v[:, rows[0]:rows[1]], exp[:, rows[0]:rows[1]])

@@ -20,6 +20,10 @@ CASES = [
     ("int<12,12> 4096^3 (2x2 groups of 2 limbs)", lower(E1212, E1212, Qu(37, 24), 4096, 4096, 4096, mul_args=Tags(25, 24), add_args=[Qu(37, 24)])),
     ("int<12,12> x int<4,3> 4096^3 (2x1 groups)", lower(E1212, E43, Qu(29, 15), 4096, 4096, 4096, mul_args=Tags(17, 15), add_args=[Qu(29, 15)])),
     ("int<12,12> 2048^3", lower(E1212, E1212, Qu(36, 24), 2048, 2048, 2048, mul_args=Tags(25, 24), add_args=[Qu(36, 24)])),
+    # beyond 64 bits: Q15.16 words, exact 64-bit products, exact 76-bit sums (5 balanced limbs per word: groups 3 + 2; 128-bit combine)
+    ("Q15.16 2048^3 exact accumulation, C Qu<43,32> (wide)", lower(Q1516, Q1516, Qu(43, 32), 2048, 2048, 2048, mul_args=Tags(31, 32), add_args=[Qu(43, 32)])),
+    ("Q15.16 2048^3 exact accumulation, C Q15.16", lower(Q1516, Q1516, Q1516, 2048, 2048, 2048, mul_args=Tags(31, 32), add_args=[Qu(43, 32)])),
+    ("Q15.16 4096^3 exact accumulation, C Q15.16", lower(Q1516, Q1516, Q1516, 4096, 4096, 4096, mul_args=Tags(31, 32), add_args=[Qu(43, 32)])),
 ]
 only = os.environ.get("ONLY", "")
 with capi.Context(0) as ctx:
@@ -28,7 +32,7 @@ with capi.Context(0) as ctx:
             continue
         rec = {"case": name, "M": d.M, "N": d.N, "K": d.K}
         for arm, fl, iters in (("mfma", 0, 10), ("tree", capi.OPT_FORCE_TREE, 1)):
-            if arm == "tree" and (os.environ.get("TREE", "1") == "0" or d.K > 65536):   # (beyond 16 levels only the general kernel applies: tens of seconds)
+            if arm == "tree" and (os.environ.get("TREE", "1") == "0" or d.K > 65536 or (d.M > 2048 and "Q15.16" in name)):   # (beyond 16 levels only the general kernel applies: tens of seconds)
                 continue
             p = capi.Plan(ctx, d, fl)
             pb = p.info.packed_bytes
