@@ -133,7 +133,8 @@ __device__ __forceinline__ void fx_node(int (&v)[N], const int (&x)[N], const QF
     }
 }
 
-// MODE: 0 run-time modes, 1 fixed modes read from the step table, 2 fixed modes in the compact branch-free form, 3 the compact
+// MODE: 0 run-time modes, 1 fixed modes read from the step table, 2 fixed modes in the compact branch-free form, 4 the same with
+// ONE clamp range for the whole k loop held in registers (TFComplexMul; k_tree_cplx), 3 the compact
 // form with rounding / overflow kinds (SAT::ZERO, WRP::TCPL, RND::ZERO / INF / CONV, TRN::SMGN) behind a branch per step,
 // 8 + FEAT the same without the branch for the kinds of FEAT (qg_fix.h, fx_finish_feat)
 template <int MODE, int N>
@@ -215,6 +216,23 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
     const int64_t gsz = (tiles_m - first_m) < GMT ? (tiles_m - first_m) : GMT;
     const int64_t m0 = (first_m + (bid % (GMT * tiles_n)) % gsz) * TMB, n0 = ((bid % (GMT * tiles_n)) / gsz) * TNB;
     const int nl = tab->n_levels_k;   // (a tree shorter than 5 levels is continued with identity levels: qg_plan.h)
+    // MODE 4 (TFComplexMul, "uniform clamp", qg_plan.cpp): ONE range for every value of the k loop and no shift / rounding at the
+    // differences and the tree nodes: the bounds and the three products' (addend, shift) live in registers for the whole launch;
+    // the products' exact left shifts (factors) are applied to the planes (a+b), (c+d), (b-a) while the tile is staged
+    int u_lo = 0, u_hi = 0, u_t[3] = {0, 0, 0}, u_d[3] = {0, 0, 0}, u_k[3] = {1, 1, 1};
+    if constexpr (MODE == 4) {
+        static_assert(MODE != 4 || TF, "the uniform-clamp form exists for TFComplexMul");
+        const QFix r = tab->fmul[QG_T_RE];
+        u_lo = r.lo;
+        u_hi = fx_vgpr(r.hi);
+        const int slot[3] = {QG_T_A, QG_T_B, QG_T_C};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { u_t[i] = tab->fmul[slot[i]].t; u_d[i] = tab->fmul[slot[i]].d; u_k[i] = tab->fmul[slot[i]].ka; }
+    }
+    auto uclamp4 = [&](int (&x)[4]) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) asm("v_med3_i32 %0, %0, %1, %2" : "+v"(x[o]) : "s"(u_lo), "v"(u_hi));
+    };
 
     int low[2][4][4];
     int up[2][MAXL - 4][4];
@@ -241,9 +259,14 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
                 const int ar4[4] = {x[0].x, x[0].y, x[0].z, x[0].w}, ai4[4] = {x[1].x, x[1].y, x[1].z, x[1].w};
                 const int br4[4] = {y[0].x, y[0].y, y[0].z, y[0].w}, bi4[4] = {y[1].x, y[1].y, y[1].z, y[1].w};
                 int ab[4], ba[4], cd[4];
-                op_addsub<MODE, 4>(ab, ar4, ai4, tab, QG_T_AB, false);  // (a+b), per A element
-                op_addsub<MODE, 4>(ba, ai4, ar4, tab, QG_T_BA, true);   // (b-a), per A element
-                op_addsub<MODE, 4>(cd, br4, bi4, tab, QG_T_CD, false);  // (c+d), per B element
+                constexpr int SM = MODE == 4 ? 2 : MODE;               // (the staged sums keep their own compact records)
+                op_addsub<SM, 4>(ab, ar4, ai4, tab, QG_T_AB, false);  // (a+b), per A element
+                op_addsub<SM, 4>(ba, ai4, ar4, tab, QG_T_BA, true);   // (b-a), per A element
+                op_addsub<SM, 4>(cd, br4, bi4, tab, QG_T_CD, false);  // (c+d), per B element
+                if constexpr (MODE == 4) {   // the products' exact left shifts, once per element: A = (a+b) c, B = (c+d) b, C = (b-a) d
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ab[e] = __mul24(ab[e], u_k[0]); cd[e] = __mul24(cd[e], u_k[1]); ba[e] = __mul24(ba[e], u_k[2]); }
+                }
                 *(int4*)&sA[0][r][q * 4] = make_int4(ab[0], ab[1], ab[2], ab[3]);
                 *(int4*)&sA[1][r][q * 4] = x[1];
                 *(int4*)&sA[2][r][q * 4] = make_int4(ba[0], ba[1], ba[2], ba[3]);
@@ -299,7 +322,19 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
                                 ab[i * 2 + j] = a0[i]; xi[i * 2 + j] = a1[i]; ba[i * 2 + j] = a2[i];
                                 yr[i * 2 + j] = b0[j]; cd[i * 2 + j] = b1[j]; yi[i * 2 + j] = b2[j];
                             }
-                        if constexpr (MODE >= 2) {   // records of steps that follow each other share a wait (qg_fix.h)
+                        if constexpr (MODE == 4) {
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) { PA[o] = mad24_vvs(ab[o], yr[o], u_t[0]); PB[o] = mad24_vvs(cd[o], xi[o], u_t[1]); PC[o] = mad24_vvs(ba[o], yi[o], u_t[2]); }
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) { PA[o] >>= u_d[0]; PB[o] >>= u_d[1]; PC[o] >>= u_d[2]; }   // (a shift by 0 costs less than a select around it)
+                            uclamp4(PA);
+                            uclamp4(PB);
+                            uclamp4(PC);
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) { v[0][o] = PA[o] - PB[o]; v[1][o] = PB[o] - PC[o]; }
+                            uclamp4(v[0]);
+                            uclamp4(v[1]);
+                        } else if constexpr (MODE >= 2) {   // records of steps that follow each other share a wait (qg_fix.h)
                             constexpr int KIND = MODE >= 8 ? MODE : MODE == 3;
                             QFix fA, fB, fC, fR, fI;
                             fx_at5(tab, FX_OFF_MUL(QG_T_A), FX_OFF_MUL(QG_T_B), FX_OFF_MUL(QG_T_C), FX_OFF_MUL(QG_T_RE), FX_OFF_MUL(QG_T_IM), fA, fB, fC, fR, fI);
@@ -358,6 +393,11 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
 #pragma unroll
                                         for (int o = 0; o < 4; ++o) low[p][l][o] = v[p][o];
                                     parked_low = true;
+                                } else if constexpr (MODE == 4) {
+#pragma unroll
+                                    for (int o = 0; o < 4; ++o) { v[0][o] += low[0][l][o]; v[1][o] += low[1][l][o]; }
+                                    uclamp4(v[0]);
+                                    uclamp4(v[1]);
                                 } else {
                                     op_node2<MODE, 4>(v[0], v[1], low[0][l], low[1][l], tab, l);
                                 }
@@ -377,6 +417,11 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
 #pragma unroll
                             for (int o = 0; o < 4; ++o) up[p][u][o] = v[p][o];
                         parked = true;
+                    } else if constexpr (MODE == 4) {
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) { v[0][o] += up[0][u][o]; v[1][o] += up[1][u][o]; }
+                        uclamp4(v[0]);
+                        uclamp4(v[1]);
                     } else {
                         op_node2<MODE, 4>(v[0], v[1], up[0][u], up[1][u], tab, 4 + u);
                     }
@@ -434,6 +479,14 @@ hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, i
     case 1: QG_CPLX_LAUNCH(1); break;
     case 2: QG_CPLX_LAUNCH(2); break;
     case 3: QG_CPLX_LAUNCH(3); break;
+    case 4: {   // uniform clamp: TFComplexMul only (qg_plan.cpp)
+        if (!tf) return hipErrorInvalidValue;
+        static const bool no_uniform = QG_DIAG_ENV("QG_NO_UNIFORM_CLAMP");   // A/B switch (diagnostic library): the compact form such a descriptor had before
+        if (no_uniform) { QG_CPLX_LAUNCH(2); break; }
+        if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12, 4, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_tree_cplx<16, 4, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+        break;
+    }
     case 9: QG_CPLX_LAUNCH(9); break;
     case 10: QG_CPLX_LAUNCH(10); break;
     case 11: QG_CPLX_LAUNCH(11); break;

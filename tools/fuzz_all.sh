@@ -17,4 +17,5 @@ run tests/extended_fuzz_eltwise.py 1200 $SEED
 run tests/extended_fuzz_cplx_eltwise.py 600 $SEED
 run tests/extended_fuzz_pingpong.py 600 $SEED
 run tests/extended_fuzz_misc.py 3 $SEED
+run tests/extended_fuzz_wide.py 900 $SEED
 cat $OUT
