@@ -832,24 +832,26 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                 if (!kinds || feat <= 0) break;   // plain compact records, or the branching form: the first packing stands
             }
             if (reg) out->cplx_fixed_ok = !kinds ? 2 : feat > 0 ? 8 + feat : 3;
-            // 4 ("uniform clamp", TFComplexMul): the plain compact form where, in addition, every value made in the k loop — the
-            // three products, A - B, B - C and every tree node of both parts — is clamped into ONE range, the differences and the
+            // 4 ("one clamp for the whole loop"): the plain compact form where, in addition, every value made in the k loop — the
+            // products, their sum / differences and every tree node of both parts — is clamped into ONE range, the sums and the
             // nodes neither shift nor round (equal fraction bits throughout), and the level buffers do not convert.  That is what
             // default tags give on operands whose parts merge into one format (BASELINE configuration 5: everything is int<6,3>
             // RND::POS_INF / SAT::TCPL inside the loop).  The kernel then keeps (lo, hi) and the products' (t, d) in registers for
             // the whole launch — no record loads, no moves of bounds — and the products' exact left shifts are folded into the
-            // staged operand planes: 15 vector instructions per complex MAC instead of 24.8.
-            if (reg && out->cplx_fixed_ok == 2 && tf) {
-                const QFix& r0 = T.fmul[QG_T_RE];
-                bool uni = true;
+            // staged operand planes: 18 vector instructions per complex MAC instead of 24.8 (TF), 21 instead of 27.4 (Basic).
+            if (reg && out->cplx_fixed_ok == 2) {
+                const int re = tf ? QG_T_RE : QG_B_RE, im = tf ? QG_T_IM : QG_B_IM;
+                const QFix& r0 = T.fmul[re];
+                bool uni = r0.lo > INT32_MIN && r0.hi < INT32_MAX;
                 auto same_clamp = [&](const QFix& f) { return f.lo == r0.lo && f.hi == r0.hi; };
-                for (int sl : {QG_T_A, QG_T_B, QG_T_C}) {
+                std::vector<int> prods = tf ? std::vector<int>{QG_T_A, QG_T_B, QG_T_C} : std::vector<int>{QG_B_AC, QG_B_BD, QG_B_AD, QG_B_BC};
+                for (int sl : prods) {
                     const QFix& f = T.fmul[sl];
-                    uni = uni && same_clamp(f) && !(f.skip & 1) && f.d >= 0 && f.ka >= 1 && f.ls == 0;
+                    uni = uni && same_clamp(f) && f.d >= 0 && f.ka >= 1;
                 }
-                for (int sl : {QG_T_RE, QG_T_IM}) {
+                for (int sl : {re, im}) {
                     const QFix& f = T.fmul[sl];
-                    uni = uni && same_clamp(f) && !(f.skip & 1) && f.ka == 1 && f.kb == 1 && f.t == 0 && f.d == 0 && f.ls == 0;
+                    uni = uni && same_clamp(f) && f.ka == 1 && f.kb == 1 && f.t == 0 && f.d == 0;
                 }
                 for (int p = 0; p < 2 && uni; ++p)
                     for (uint32_t l = 0; l < (uint32_t)T.n_levels_k && uni; ++l) {
@@ -859,8 +861,48 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                         const bool ident = (int)l >= T.n_levels && T.level_add[p][l].q.identity != 0;
                         uni = (fc.skip & 1) && (ident || (same_clamp(fa) && fa.t == 0 && fa.d == 0 && fa.ls == 0));
                     }
-                // the folded factor must keep the staged plane inside 24 bits (b24 was checked on the unscaled operands with the shift: reg)
-                if (uni && r0.lo > INT32_MIN && r0.hi < INT32_MAX) out->cplx_fixed_ok = 4;
+                if (uni) {
+                    memset(&T.uni, 0, sizeof T.uni);
+                    T.uni.lo = r0.lo;
+                    T.uni.hi = r0.hi;
+                    auto lg = [](int32_t k) { int n = 0; while ((1 << n) < k) ++n; return n; };
+                    if (tf) {   // every product owns one plane: the plane takes the product's left shift (checked against 24 bits above: b24(x, ls))
+                        for (int i = 0; i < 3; ++i) { const QFix& f = T.fmul[prods[i]]; T.uni.t[i] = f.t; T.uni.d[i] = f.d; T.uni.k[i] = f.ka; }
+                        T.uni.k[3] = 1;
+                    } else {
+                        // Basic: a plane serves two products (a: ac, ad; b: bd, bc; c: ac, bc; d: bd, ad).  Plane shifts la, lb, lc, ld with
+                        // lx + ly >= the product's left shift; what they exceed it by is shifted out again after the rounding addend (scaled
+                        // alike): (x y 2^(lx+ly) + t 2^e) >> (d + e) = (x y 2^ls + t) >> d.  The smallest total that keeps planes within
+                        // 24 bits and products within 31.
+                        const int px[4] = {0, 1, 0, 1}, py[4] = {2, 3, 3, 2};   // ac, bd, ad, bc over planes a b c d
+                        const qfmt pf[4] = {a, b, cc, dd};
+                        int w[4], ls[4], best[4] = {0, 0, 0, 0}, best_sum = -1;
+                        for (int i = 0; i < 4; ++i) { w[i] = 1 + (int)pf[i].I + (int)pf[i].F; ls[i] = lg(T.fmul[prods[i]].ka); }
+                        for (int la = 0; la <= 12; ++la)
+                            for (int lb = 0; lb <= 12; ++lb)
+                                for (int lc = 0; lc <= 12; ++lc)
+                                    for (int ld = 0; ld <= 12; ++ld) {
+                                        const int l[4] = {la, lb, lc, ld};
+                                        bool ok = true;
+                                        for (int i = 0; i < 4 && ok; ++i) ok = w[i] + l[i] <= 24;
+                                        for (int i = 0; i < 4 && ok; ++i) {
+                                            const int e = l[px[i]] + l[py[i]] - ls[i];
+                                            ok = e >= 0 && w[px[i]] + w[py[i]] + l[px[i]] + l[py[i]] <= 30 && T.fmul[prods[i]].d + e <= 30;
+                                        }
+                                        const int sum = la + lb + lc + ld;
+                                        if (ok && (best_sum < 0 || sum < best_sum)) { best_sum = sum; memcpy(best, l, sizeof best); }
+                                    }
+                        uni = best_sum >= 0;
+                        for (int i = 0; i < 4 && uni; ++i) {
+                            const QFix& f = T.fmul[prods[i]];
+                            const int e = best[px[i]] + best[py[i]] - ls[i];
+                            T.uni.t[i] = (int32_t)((uint32_t)f.t << e);
+                            T.uni.d[i] = f.d + e;
+                            T.uni.k[i] = (int32_t)1 << best[i];
+                        }
+                    }
+                }
+                if (uni) out->cplx_fixed_ok = 4;
             }
         }
     }

@@ -40,6 +40,10 @@ struct QTreeTable {
     QFix fmul[8];
     QFix fadd[2][QG_MAX_LEVELS];
     QFix fcvt[2][QG_MAX_LEVELS];
+    // ... its "one clamp for the whole loop" form (cplx_fixed_ok == 4): the common range, then per product (TF: A, B, C; Basic: ac,
+    // bd, ad, bc) the rounding addend and the right shift, then the factors (powers of two) the operand planes are staged with
+    // (TF: (a+b), (c+d), (b-a); Basic: a, b, c, d) — which carry the products' exact left shifts, the shifts growing to match
+    struct { int32_t lo, hi, t[4], d[4], k[4], pad_[2]; } uni;
 };
 
 // epilogue of the linear class: exact dot product at frac (Fa+Fb) -> C

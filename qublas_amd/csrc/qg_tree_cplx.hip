@@ -134,7 +134,7 @@ __device__ __forceinline__ void fx_node(int (&v)[N], const int (&x)[N], const QF
 }
 
 // MODE: 0 run-time modes, 1 fixed modes read from the step table, 2 fixed modes in the compact branch-free form, 4 the same with
-// ONE clamp range for the whole k loop held in registers (TFComplexMul; k_tree_cplx), 3 the compact
+// ONE clamp range for the whole k loop held in registers (k_tree_cplx), 3 the compact
 // form with rounding / overflow kinds (SAT::ZERO, WRP::TCPL, RND::ZERO / INF / CONV, TRN::SMGN) behind a branch per step,
 // 8 + FEAT the same without the branch for the kinds of FEAT (qg_fix.h, fx_finish_feat)
 template <int MODE, int N>
@@ -216,18 +216,15 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
     const int64_t gsz = (tiles_m - first_m) < GMT ? (tiles_m - first_m) : GMT;
     const int64_t m0 = (first_m + (bid % (GMT * tiles_n)) % gsz) * TMB, n0 = ((bid % (GMT * tiles_n)) / gsz) * TNB;
     const int nl = tab->n_levels_k;   // (a tree shorter than 5 levels is continued with identity levels: qg_plan.h)
-    // MODE 4 (TFComplexMul, "uniform clamp", qg_plan.cpp): ONE range for every value of the k loop and no shift / rounding at the
-    // differences and the tree nodes: the bounds and the three products' (addend, shift) live in registers for the whole launch;
-    // the products' exact left shifts (factors) are applied to the planes (a+b), (c+d), (b-a) while the tile is staged
-    int u_lo = 0, u_hi = 0, u_t[3] = {0, 0, 0}, u_d[3] = {0, 0, 0}, u_k[3] = {1, 1, 1};
+    // MODE 4 ("one clamp for the whole loop", qg_plan.cpp): ONE range for every value of the k loop and no shift / rounding at the
+    // sums and the tree nodes: the bounds and the products' (addend, shift) live in registers for the whole launch; the products'
+    // exact left shifts are factors of the operand planes, applied while the tile is staged (QTreeTable::uni)
+    int u_lo = 0, u_hi = 0, u_t[4] = {0, 0, 0, 0}, u_d[4] = {0, 0, 0, 0}, u_k[4] = {1, 1, 1, 1};
     if constexpr (MODE == 4) {
-        static_assert(MODE != 4 || TF, "the uniform-clamp form exists for TFComplexMul");
-        const QFix r = tab->fmul[QG_T_RE];
-        u_lo = r.lo;
-        u_hi = fx_vgpr(r.hi);
-        const int slot[3] = {QG_T_A, QG_T_B, QG_T_C};
+        u_lo = tab->uni.lo;
+        u_hi = fx_vgpr(tab->uni.hi);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { u_t[i] = tab->fmul[slot[i]].t; u_d[i] = tab->fmul[slot[i]].d; u_k[i] = tab->fmul[slot[i]].ka; }
+        for (int i = 0; i < 4; ++i) { u_t[i] = tab->uni.t[i]; u_d[i] = tab->uni.d[i]; u_k[i] = tab->uni.k[i]; }
     }
     auto uclamp4 = [&](int (&x)[4]) {
 #pragma unroll
@@ -274,6 +271,13 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
                 *(int4*)&sB[1][r][q * 4] = make_int4(cd[0], cd[1], cd[2], cd[3]);
                 *(int4*)&sB[2][r][q * 4] = y[1];
             } else {
+                if constexpr (MODE == 4) {   // planes a, b, c, d with their factors
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        x[p] = make_int4(__mul24(x[p].x, u_k[p]), __mul24(x[p].y, u_k[p]), __mul24(x[p].z, u_k[p]), __mul24(x[p].w, u_k[p]));
+                        y[p] = make_int4(__mul24(y[p].x, u_k[2 + p]), __mul24(y[p].y, u_k[2 + p]), __mul24(y[p].z, u_k[2 + p]), __mul24(y[p].w, u_k[2 + p]));
+                    }
+                }
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     *(int4*)&sA[p][r][q * 4] = x[p];
@@ -360,7 +364,23 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
                                 yr[i * 2 + j] = b0[j]; yi[i * 2 + j] = b1[j];
                             }
                         int ac[4], bd[4], ad[4], bc[4];
-                        if constexpr (MODE >= 2) {
+                        if constexpr (MODE == 4) {
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) {
+                                ac[o] = mad24_vvs(xr[o], yr[o], u_t[0]) >> u_d[0];
+                                bd[o] = mad24_vvs(xi[o], yi[o], u_t[1]) >> u_d[1];
+                                ad[o] = mad24_vvs(xr[o], yi[o], u_t[2]) >> u_d[2];
+                                bc[o] = mad24_vvs(xi[o], yr[o], u_t[3]) >> u_d[3];
+                            }
+                            uclamp4(ac);
+                            uclamp4(bd);
+                            uclamp4(ad);
+                            uclamp4(bc);
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) { v[0][o] = ac[o] - bd[o]; v[1][o] = ad[o] + bc[o]; }
+                            uclamp4(v[0]);
+                            uclamp4(v[1]);
+                        } else if constexpr (MODE >= 2) {
                             constexpr int KIND = MODE >= 8 ? MODE : MODE == 3;
                             QFix f0, f1, f2, f3;
                             fx_at2(tab, FX_OFF_MUL(QG_B_AC), FX_OFF_MUL(QG_B_BD), f0, f1);
@@ -479,12 +499,10 @@ hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, i
     case 1: QG_CPLX_LAUNCH(1); break;
     case 2: QG_CPLX_LAUNCH(2); break;
     case 3: QG_CPLX_LAUNCH(3); break;
-    case 4: {   // uniform clamp: TFComplexMul only (qg_plan.cpp)
-        if (!tf) return hipErrorInvalidValue;
+    case 4: {   // one clamp for the whole loop (qg_plan.cpp)
         static const bool no_uniform = QG_DIAG_ENV("QG_NO_UNIFORM_CLAMP");   // A/B switch (diagnostic library): the compact form such a descriptor had before
-        if (no_uniform) { QG_CPLX_LAUNCH(2); break; }
-        if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx<12, 4, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((k_tree_cplx<16, 4, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+        if (no_uniform) QG_CPLX_LAUNCH(2);
+        else QG_CPLX_LAUNCH(4);
         break;
     }
     case 9: QG_CPLX_LAUNCH(9); break;

@@ -67,10 +67,12 @@ def main():
             mul = BasicComplexMul(acT=rtag(rng, ea.real), bdT=rtag(rng, ea.imag), adT=rtag(rng, ea.real), bcT=rtag(rng, ea.imag),
                                   acbdT=rtag(rng, ea.real), adbcT=rtag(rng, ea.imag), loose=rtag(rng, ea.real))
         levels = [Qcomplex(rq(rng, rng.choice([10, 14, 18, 22])), rq(rng, rng.choice([10, 14, 18, 22]))) for _ in range(rng.choice([0, 0, 1, 1, 2]))]
-        if rng.random() < 0.2:   # one format for every value of the k loop (TF): the "one clamp for the whole loop" form, or just short of it
+        if rng.random() < 0.2:   # one format for every value of the k loop: the "one clamp for the whole loop" form, or just short of it
             u = rq(rng, rng.choice([6, 9, 10, 13, 16]))
             v = u if rng.random() < 0.8 else rq(rng, 12)
             mul = TFComplexMul(abT=rtag(rng, ea.real), cdT=rtag(rng, eb.real), abcT=u, cdbT=u, badT=u, ABT=u, BCT=v)
+            if rng.random() < 0.5:
+                mul = BasicComplexMul(acT=u, bdT=u, adT=u, bcT=u, acbdT=u, adbcT=v)
             levels = [Qcomplex(u, u) for _ in range(rng.choice([0, 1, 1, 2]))]
         ec = Qcomplex(rq(rng, rng.choice([7, 12, 18])), rq(rng, rng.choice([7, 12, 18])))
         M, N = rng.randint(1, 120), rng.randint(1, 120)

@@ -343,6 +343,10 @@ def test_complex_fixed_mode_step_forms(oracle):
                                                add_args=[Qcomplex(P(6, 3), P(6, 3))]),
          "fixed modes, one clamp for the whole loop"),                                            # products of different alignments into one format
         (c5, c5, dict(mul_args=TFComplexMul(ABT=Tags(7, 3))), "fixed modes, compact"),           # one wider difference: not uniform
+        (Qcomplex(P(6, 3), P(6, 3)), c5, dict(mul_args=BasicComplexMul()), "fixed modes, one clamp for the whole loop"),   # Basic with equal part formats
+        (Qcomplex(P(5, 4), P(7, 2)), c5, dict(mul_args=BasicComplexMul(acT=Tags(6, 9), bdT=Tags(6, 9), adT=Tags(6, 9), bcT=Tags(6, 9), acbdT=Tags(6, 9), adbcT=Tags(6, 9)),
+                                               add_args=[Qcomplex(P(6, 9), P(6, 9))]),
+         "fixed modes, one clamp for the whole loop"),                                            # Basic: products shift left by 1, 5, 3, 3 bits: plane factors
         (c5, c5, dict(mul_args=BasicComplexMul()), "fixed modes, compact"),
         (c5, Qcomplex(P(12, 4), P(10, 2)), dict(mul_args=TFComplexMul(abcT=Tags(9, 5), ABT=Tags(11, 2)), add_args=[Qcomplex(P(14, 0), P(12, -3))]),
          "fixed modes, compact"),                                                                 # tags, one level type (fewer fraction bits: rounding nodes)
