@@ -24,6 +24,32 @@ __device__ __forceinline__ int mad24_vvs(int a, int b, int c)
     return r;
 }
 
+// LEFT-JUSTIFIED values (a signed SAT::TCPL format of W + 1 bits held as x * 2^s, s = 32 - (W + 1)): the format's range is the
+// int32 range, so saturation is the VOP3 clamp bit of the add / subtract / multiply-add itself — tools/ubench/sat_semantics.hip
+// checks on the hardware that the clamp acts on the exact result (the product at full width) — and costs no instruction.  A
+// positive saturation leaves 2^31 - 1, whose low s bits are ones where hi * 2^s has zeros: read as floor(v / 2^s) the value is
+// right, and stays right through ONE further saturating add (ones + zeros never carry; two saturated values saturate again);
+// a second add could carry, and a subtrahend must be clean, so the low bits are cleared (v_and) after every second add and
+// after every product (whose low bits are the fraction the rounding drops: flooring them IS the rounding's shift).
+__device__ __forceinline__ int sat_add(int a, int b)
+{
+    int r;
+    asm("v_add_i32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int sat_sub(int a, int b)
+{
+    int r;
+    asm("v_sub_i32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int sat_mad24_vvs(int a, int b, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+
 template <int N>
 __device__ __forceinline__ void fx_finish(int (&v)[N], const QFix& f)
 {

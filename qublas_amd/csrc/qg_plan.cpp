@@ -699,6 +699,44 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
             }
         }
     }
+    // fast_mode 6, left-justified values (qg_fix.h): the product and every level clamp into ONE signed SAT::TCPL format of
+    // Wt = W + 1 bits, the product rounds by "add a constant, shift right by d" (TRN::TCPL, RND::POS_INF, RND::NEG_INF) and the
+    // nodes do not shift.  Values are held as x * 2^s, s = 32 - Wt: the operands are staged with factors 2^ea, 2^eb,
+    // ea + eb = s - d, so that a * b * 2^(s-d) + t * 2^(s-d), saturated by the multiply-add itself and its low s bits cleared,
+    // is the quantised product; a node is one saturating add.  fast_mode_base keeps the form such a descriptor had before.
+    out->fast_mode_base = out->fast_mode;
+    if (out->tree_fast_ok && (out->fast_mode == 2 || out->fast_mode == 3)) {
+        const QStep& pq = T.mul[0].q;
+        const int bitsA = 1 + (int)d->a[0].I + (int)d->a[0].F, bitsB = 1 + (int)d->b[0].I + (int)d->b[0].F;
+        bool lj = !pq.identity && pq.O == QG_SAT_TCPL && pq.S && pq.d >= 0 && pq.lo == -pq.hi - 1 && ((pq.hi + 1) & pq.hi) == 0 && pq.hi > 0 &&
+                  (pq.d == 0 || pq.Q == QG_TRN_TCPL || pq.Q == QG_RND_POS_INF || pq.Q == QG_RND_NEG_INF);
+        int Wt = 1;
+        while (lj && ((int64_t)1 << (Wt - 1)) <= pq.hi) ++Wt;   // hi = 2^(Wt-1) - 1
+        const int sj = 32 - Wt;
+        lj = lj && sj >= 1 && sj - pq.d >= 0;
+        for (uint32_t l = 0; l < (uint32_t)T.n_levels_k && lj; ++l) {
+            const QStep& q = T.level_add[0][l].q;
+            const bool pad = (int)l >= T.n_levels && q.identity;   // (x + 0 behind a short tree)
+            lj = T.level_cvt[0][l].identity && T.level_add[0][l].sa == 0 && T.level_add[0][l].sb == 0 &&
+                 (pad || (!q.identity && q.O == QG_SAT_TCPL && q.S && q.d == 0 && q.lo == pq.lo && q.hi == pq.hi));
+        }
+        if (lj) {
+            int ea = sj - pq.d;
+            if (ea > 24 - bitsA) ea = 24 - bitsA;
+            if (ea < 0) ea = 0;
+            const int eb = sj - pq.d - ea;
+            lj = bitsA + ea <= 24 && bitsB + eb <= 24 && eb >= 0;
+            if (lj) {
+                memset(&T.uni, 0, sizeof T.uni);
+                const int64_t t = pq.d == 0 ? 0 : pq.Q == QG_RND_POS_INF ? ((int64_t)1 << (pq.d - 1)) : pq.Q == QG_RND_NEG_INF ? ((int64_t)1 << (pq.d - 1)) - 1 : 0;
+                T.uni.t[0] = (int32_t)(t << (sj - pq.d));   // (< 2^(s-1))
+                T.uni.d[0] = sj;
+                T.uni.d[1] = ea;
+                T.uni.d[2] = eb;
+                out->fast_mode = 6;
+            }
+        }
+    }
     out->tree64_ok = (!cx && !out->wide && !out->generic_only && d->n_levels <= 16) ? 1 : 0;   // (64-bit values: not a wide plan)
     // QG_DESC_LEFTOVER0_COPY with an odd K: the zero-padded kernels would form the leftover as x + 0 in level 0's type — a
     // conversion, where the reference copies — so only the general kernel, which has the leftover step itself, may run it

@@ -67,7 +67,8 @@ struct QAnalysis {
     int mul24_ok;            // multiplies fit v_mul_i32_i24
     int cplx_fast_ok;        // the 32-bit complex tree kernel applies
     int cplx_fixed_ok;       // ... and every step on the path is RND::POS_INF (or exact) + SAT::TCPL: fixed-mode variant (2: compact records; 3: ... with rounding / overflow kinds; 8 + f: ... of the branch-free feature set f)
-    int fast_mode;           // 0 runtime modes; 1 one format everywhere, TCPL + SAT::ZERO; 2 TCPL + SAT::TCPL; 3 / 4 / 5 per-level formats, compact steps (QFix; 3: every step clamps, 4: biased values, 5: unbiased)
+    int fast_mode;           // 0 runtime modes; 1 one format everywhere, TCPL + SAT::ZERO; 2 TCPL + SAT::TCPL; 3 / 4 / 5 per-level formats, compact steps (QFix; 3: every step clamps, 4: biased values, 5: unbiased); 6 one signed SAT::TCPL format on left-justified values
+    int fast_mode_base;      // fast_mode 6 (one signed SAT::TCPL format, left-justified saturating steps): the form (2 / 3) the descriptor has without it
     int tree64_ok;           // the 2x2-outputs-per-lane 64-bit tree kernel applies (real, 5..16 levels)
     int gemv_ok;             // the one-column 32-bit tree kernel applies (N = 1, K = 2^p >= 16)
     int gemv_wide_ok;        // ... or its 64-bit-value form: elements of at most 32 storage bits, wider sums / level types

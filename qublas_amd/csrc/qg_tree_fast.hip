@@ -206,9 +206,16 @@ struct QTreeFastArgs {
 //   v_med3 (3: every step of the descriptor clamps), or — 4: SAT::ZERO / WRP::TCPL steps exist — values biased by -lo of their
 //   format and the overflow by the record's kind: one unsigned compare + select, med3(u, 0, span), or u & span (qg_fix.h);
 //   5: the same kinds on unbiased values (a subtraction more per range test) where a format is too wide for the biased form.
+// MODE 6: one signed SAT::TCPL format for the product and every level, held LEFT-JUSTIFIED (qg_fix.h): the product is one
+//   saturating v_mad_i32_i24 (operands staged with the factors that justify it, rounding addend included) + v_and, a node one
+//   saturating v_add_i32, + v_and at the odd levels: 3.3 instead of 5 vector instructions per MAC, and no split product
+//   (the hardware saturates from the full 48-bit product).
 #define NODE(X, L)                                                         \
     do {                                                                   \
-        if (MODE >= 3) { if ((L) < 4) node_fx_rec<MODE>(v, X, flow[(L) < 4 ? (L) : 0]); else node_fx<MODE>(v, X, tab, L); } \
+        if (MODE == 6) {                                                   \
+            _Pragma("unroll") for (int o_ = 0; o_ < NOUT; ++o_) v[o_] = sat_add(X[o_], v[o_]);                    \
+            if ((L) & 1) { _Pragma("unroll") for (int o_ = 0; o_ < NOUT; ++o_) v[o_] &= lj_mask; }               \
+        } else if (MODE >= 3) { if ((L) < 4) node_fx_rec<MODE>(v, X, flow[(L) < 4 ? (L) : 0]); else node_fx<MODE>(v, X, tab, L); } \
         else if (MODE != 0) node_fixed<MODE>(v, X, flo, fhi, bias, span);  \
         else node_all(v, X, tab, L);                                       \
     } while (0)
@@ -250,6 +257,9 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
     QFix flow[4];
 #pragma unroll
     for (int l = 0; l < 4; ++l) flow[l] = tab->fadd[0][l];
+    // MODE 6 (QTreeTable::uni): shift of the justified values, their mask, the product's scaled rounding addend, the operands' factors
+    const int lj_s = MODE == 6 ? tab->uni.d[0] : 0, lj_mask = MODE == 6 ? (int)(~0u << lj_s) : -1, lj_t = MODE == 6 ? tab->uni.t[0] : 0;
+    const int lj_ea = MODE == 6 ? tab->uni.d[1] : 0, lj_eb = MODE == 6 ? tab->uni.d[2] : 0;
 
     int low[4][NOUT];
     int up[MAXL - 4][NOUT];
@@ -265,12 +275,14 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
             const int ch = tid + 256 * c, r = ch >> 3, q = ch & 7;
             int4 x = make_int4(0, 0, 0, 0);
             if (m0 + r < g.M) x = *(const int4*)(g.A + (m0 + r) * g.K + k0 + q * 4);
+            if (MODE == 6) x = make_int4(x.x << lj_ea, x.y << lj_ea, x.z << lj_ea, x.w << lj_ea);
             *(int4*)&sA[r][q * 4] = x;
         }
         {
             const int r = tid >> 3, q = tid & 7;
             int4 x = make_int4(0, 0, 0, 0);
             if (n0 + r < g.N) x = *(const int4*)(g.B + (n0 + r) * g.K + k0 + q * 4);
+            if (MODE == 6) x = make_int4(x.x << lj_eb, x.y << lj_eb, x.z << lj_eb, x.w << lj_eb);
             if (SPLIT) {
                 *(int4*)&sBh[r][q * 4] = make_int4(x.x >> s, x.y >> s, x.z >> s, x.w >> s);
                 *(int4*)&sBl[r][q * 4] = make_int4(x.x & smask, x.y & smask, x.z & smask, x.w & smask);
@@ -306,7 +318,12 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
                         if (SPLIT) blv[j] = e == 0 ? bl4[j].x : e == 1 ? bl4[j].y : e == 2 ? bl4[j].z : bl4[j].w;
                     }
                     // ---- leaves: 8 quantised products
-                    if (MODE == 5 && fp.skip != 0) {
+                    if (MODE == 6) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) v[i * 2 + j] = sat_mad24_vvs(av[i], bhv[j], lj_t) & lj_mask;
+                    } else if (MODE == 5 && fp.skip != 0) {
                         // a product whose rounding looks at the value's sign or parity (RND::ZERO / INF / CONV, TRN::SMGN)
                         if (SPLIT) {
                             int lw[NOUT];
@@ -451,6 +468,10 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) v[o] -= fp.ka;
     }
+    if (MODE == 6) {   // floor(v / 2^s): the value
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) v[o] >>= lj_s;
+    }
     step_all(v, tab->c_cvt[0]);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -489,6 +510,10 @@ hipError_t qg_launch_tree_fast(const QTreeTable* dev_table, int n_levels, int sp
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks);
     if (mode != 0 && !mul24) mode = 0;  // the fixed-mode variants are built for 24-bit multiplies only
+    if (mode == 6) {   // left-justified saturating form: never split (the planner checked the scaled operands against 24 bits)
+        launch_tf<false, true, 6>(n_levels, grid, st, g);
+        return hipGetLastError();
+    }
     if (split_s > 0) {
         if (mode == 1) launch_tf<true, true, 1>(n_levels, grid, st, g);
         else if (mode == 2) launch_tf<true, true, 2>(n_levels, grid, st, g);

@@ -299,7 +299,11 @@ def test_real_tree_kernel_step_forms(oracle):
     e88 = Qu(8, 8)
     e88z = Qu(8, 8, True, TRN.TCPL, SAT.ZERO)
     cases = [
-        (e88, e88, dict(), "one format, SAT::TCPL"),
+        (e88, e88, dict(), "one format, SAT::TCPL, left-justified"),                                                  # saturating v_mad / v_add on x * 2^15
+        (Qu(4, 3), Qu(4, 3), dict(), "one format, SAT::TCPL, left-justified"),                                        # configuration 2 as literally configured
+        (e88, Qu(12, 8), dict(mul_args=Qu(8, 8, True, RND.POS_INF, SAT.TCPL), add_args=[Qu(8, 8)]), "one format, SAT::TCPL, left-justified"),   # the addend rides in the multiply-add
+        (Qu(6, 5), Qu(9, 2), dict(mul_args=Qu(7, 6, True, RND.NEG_INF, SAT.TCPL), add_args=[Qu(7, 6)]), "one format, SAT::TCPL, left-justified"),
+        (Qu(8, 8, False), Qu(8, 8, False), dict(), "one format, SAT::TCPL"),                                          # unsigned: [0, 2^W - 1] is not the int32 range
         (e88z, e88z, dict(), "one format, SAT::ZERO"),
         (e88, Qu(12, 8), dict(add_args=[Qu(12, 8)]), "per-level formats, compact (clamps)"),                          # a wider level type (split product)
         (e88z, Qu(12, 6, True, TRN.TCPL, SAT.ZERO), dict(add_args=[Qu(10, 8, True, TRN.TCPL, SAT.ZERO), Qu(12, 6, True, TRN.TCPL, SAT.ZERO)]),

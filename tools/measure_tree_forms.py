@@ -19,7 +19,7 @@ CC = Qcomplex(Qu(6, 3, True, RND.CONV), Qu(6, -3, True, RND.CONV))
 CW = Qcomplex(Qu(6, 3, True, TRN.TCPL, WRP.TCPL), Qu(6, -3, True, TRN.TCPL, WRP.TCPL))
 CI = Qcomplex(Qu(6, 3, True, RND.INF), Qu(6, -3, True, RND.INF))
 CASES = [
-    ("int<8,8> default tags (one format, SAT::TCPL)", lower(E, E, E, S, S, S), 0),
+    ("int<8,8> default tags (one format, SAT::TCPL: left-justified; QG_NO_LEFT_JUSTIFIED=1 in the diagnostic library: the v_med3 form)", lower(E, E, E, S, S, S), 0),
     ("same, run-time modes forced", lower(E, E, E, S, S, S), capi.OPT_RUNTIME_MODES),
     ("int<8,8>, level type Qu<12,8> (QgemulAddArgs)", lower(E, E, Qu(12, 8), S, S, S, add_args=[Qu(12, 8)]), 0),
     ("same, run-time modes forced", lower(E, E, Qu(12, 8), S, S, S, add_args=[Qu(12, 8)]), capi.OPT_RUNTIME_MODES),
