@@ -727,13 +727,29 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
             const int eb = sj - pq.d - ea;
             lj = bitsA + ea <= 24 && bitsB + eb <= 24 && eb >= 0;
             if (lj) {
-                memset(&T.uni, 0, sizeof T.uni);
+                memset(&T.lj, 0, sizeof T.lj);
                 const int64_t t = pq.d == 0 ? 0 : pq.Q == QG_RND_POS_INF ? ((int64_t)1 << (pq.d - 1)) : pq.Q == QG_RND_NEG_INF ? ((int64_t)1 << (pq.d - 1)) - 1 : 0;
-                T.uni.t[0] = (int32_t)(t << (sj - pq.d));   // (< 2^(s-1))
-                T.uni.d[0] = sj;
-                T.uni.d[1] = ea;
-                T.uni.d[2] = eb;
+                T.lj.t[0] = (int32_t)(t << (sj - pq.d));   // (< 2^(s-1))
+                T.lj.s = sj;
+                T.lj.e[0] = ea;
+                T.lj.e[1] = eb;
                 out->fast_mode = 6;
+                // 7: ... in 16-bit halves, two outputs per register (k_tree_pk16): the format has at most 16 bits and the justified
+                // operands fit int16.  lj.e[2] = the shift there, e[3] / e[4] the operands' shifts, t[1] the scaled addend.
+                const int s16 = 16 - Wt;
+                if (s16 >= 1 && s16 - pq.d >= 0) {
+                    int ea16 = s16 - pq.d;
+                    if (ea16 > 16 - bitsA) ea16 = 16 - bitsA;
+                    if (ea16 < 0) ea16 = 0;
+                    const int eb16 = s16 - pq.d - ea16;
+                    if (bitsA + ea16 <= 16 && bitsB + eb16 <= 16 && eb16 >= 0) {
+                        T.lj.e[2] = s16;
+                        T.lj.e[3] = ea16;
+                        T.lj.e[4] = eb16;
+                        T.lj.t[1] = (int32_t)(t << (s16 - pq.d));
+                        out->fast_mode = 7;
+                    }
+                }
             }
         }
     }
@@ -941,6 +957,54 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                     }
                 }
                 if (uni) out->cplx_fixed_ok = 4;
+                // 5: ... and that one range is a signed SAT::TCPL format: left-justified values (qg_fix.h).  The planes are staged with the
+                // left shifts that justify each product exactly (x y 2^(s + ls - d), the addend scaled alike), so a product is one
+                // saturating multiply-add + v_and, RE / IM one saturating add / subtract, a node one saturating add (+ v_and at the
+                // even levels): 12.5 instead of 18 vector instructions per complex MAC (TF).
+                if (uni && r0.lo == -r0.hi - 1 && ((r0.hi + 1) & r0.hi) == 0 && r0.hi > 0) {
+                    int Wt = 1;
+                    while (((int64_t)1 << (Wt - 1)) <= r0.hi) ++Wt;
+                    const int sj = 32 - Wt;
+                    auto lg = [](int32_t k) { int n = 0; while ((1 << n) < k) ++n; return n; };
+                    auto wd = [](qfmt f) { return 1 + (int)f.I + (int)f.F; };
+                    bool lj = sj >= 1;
+                    memset(&T.lj, 0, sizeof T.lj);
+                    T.lj.s = sj;
+                    int E[4] = {0, 0, 0, 0};
+                    for (size_t i = 0; i < prods.size() && lj; ++i) {
+                        const QFix& f = T.fmul[prods[i]];
+                        E[i] = sj + lg(f.ka) - f.d;
+                        lj = E[i] >= 0 && (f.d == 0 || sj - f.d >= 0);
+                        if (lj) T.lj.t[i] = f.d ? (int32_t)((uint32_t)f.t << (sj - f.d)) : 0;
+                    }
+                    if (lj && tf) {
+                        // products A = (a+b) c, B = (c+d) b, C = (b-a) d: every plane serves one product
+                        const qfmt fx[3] = {d->mul[QG_T_AB], d->mul[QG_T_CD], d->mul[QG_T_BA]}, fy[3] = {cc, b, dd};
+                        const int px[3] = {0, 4, 2}, py[3] = {3, 1, 5};   // planes (a+b), b, (b-a), c, (c+d), d
+                        for (int i = 0; i < 3 && lj; ++i) {
+                            int ex = E[i] < 24 - wd(fx[i]) ? E[i] : 24 - wd(fx[i]);
+                            if (ex < 0) ex = 0;
+                            const int ey = E[i] - ex;
+                            lj = wd(fx[i]) + ex <= 24 && wd(fy[i]) + ey <= 24;
+                            T.lj.e[px[i]] = ex;
+                            T.lj.e[py[i]] = ey;
+                        }
+                    } else if (lj) {
+                        const int px[4] = {0, 1, 0, 1}, py[4] = {2, 3, 3, 2};   // ac, bd, ad, bc over planes a b c d
+                        const qfmt pf[4] = {a, b, cc, dd};
+                        bool found = false;
+                        for (int la = 0; la <= 24 - wd(pf[0]) && !found; ++la) {
+                            const int lc = E[0] - la, ld = E[2] - la, lb = E[3] - lc;
+                            if (lc < 0 || ld < 0 || lb < 0 || lb + ld != E[1]) continue;
+                            if (wd(pf[1]) + lb > 24 || wd(pf[2]) + lc > 24 || wd(pf[3]) + ld > 24) continue;
+                            T.lj.e[0] = la; T.lj.e[1] = lb; T.lj.e[2] = lc; T.lj.e[3] = ld;
+                            found = true;
+                        }
+                        lj = found;
+                        (void)px; (void)py;
+                    }
+                    if (lj) out->cplx_fixed_ok = 5;
+                }
             }
         }
     }

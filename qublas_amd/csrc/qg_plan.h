@@ -44,6 +44,10 @@ struct QTreeTable {
     // bd, ad, bc) the rounding addend and the right shift, then the factors (powers of two) the operand planes are staged with
     // (TF: (a+b), (c+d), (b-a); Basic: a, b, c, d) — which carry the products' exact left shifts, the shifts growing to match
     struct { int32_t lo, hi, t[4], d[4], k[4], pad_[2]; } uni;
+    // LEFT-JUSTIFIED forms (qg_fix.h: one signed SAT::TCPL format held as x * 2^s; real fast_mode 6, complex cplx_fixed_ok 5): the
+    // shift s, per product the rounding addend scaled to the justified product, and the left shifts the operand planes are staged
+    // with (real: A, B; TF: (a+b), b, (b-a), c, (c+d), d; Basic: a, b, c, d), which justify the products; real, packed 16-bit form (fast_mode 7): e[2] the shift in a half, e[3], e[4] the operands' shifts, t[1] the addend
+    struct { int32_t s, t[4], e[6], pad_; } lj;
 };
 
 // epilogue of the linear class: exact dot product at frac (Fa+Fb) -> C
@@ -66,9 +70,9 @@ struct QAnalysis {
     int split_s;             // > 0: product evaluated split at its rounding shift
     int mul24_ok;            // multiplies fit v_mul_i32_i24
     int cplx_fast_ok;        // the 32-bit complex tree kernel applies
-    int cplx_fixed_ok;       // ... and every step on the path is RND::POS_INF (or exact) + SAT::TCPL: fixed-mode variant (2: compact records; 3: ... with rounding / overflow kinds; 8 + f: ... of the branch-free feature set f)
-    int fast_mode;           // 0 runtime modes; 1 one format everywhere, TCPL + SAT::ZERO; 2 TCPL + SAT::TCPL; 3 / 4 / 5 per-level formats, compact steps (QFix; 3: every step clamps, 4: biased values, 5: unbiased); 6 one signed SAT::TCPL format on left-justified values
-    int fast_mode_base;      // fast_mode 6 (one signed SAT::TCPL format, left-justified saturating steps): the form (2 / 3) the descriptor has without it
+    int cplx_fixed_ok;       // ... and every step on the path is RND::POS_INF (or exact) + SAT::TCPL: fixed-mode variant (2: compact records; 3: ... with rounding / overflow kinds; 8 + f: ... of the branch-free feature set f; 4: one clamp for the whole loop; 5: ... on left-justified values)
+    int fast_mode;           // 0 runtime modes; 1 one format everywhere, TCPL + SAT::ZERO; 2 TCPL + SAT::TCPL; 3 / 4 / 5 per-level formats, compact steps (QFix; 3: every step clamps, 4: biased values, 5: unbiased); 6 one signed SAT::TCPL format on left-justified values, 7 ... in packed 16-bit halves
+    int fast_mode_base;      // fast_mode 6 / 7 (one signed SAT::TCPL format, left-justified saturating steps): the form (2 / 3) the descriptor has without it
     int tree64_ok;           // the 2x2-outputs-per-lane 64-bit tree kernel applies (real, 5..16 levels)
     int gemv_ok;             // the one-column 32-bit tree kernel applies (N = 1, K = 2^p >= 16)
     int gemv_wide_ok;        // ... or its 64-bit-value form: elements of at most 32 storage bits, wider sums / level types

@@ -226,6 +226,21 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
 #pragma unroll
         for (int i = 0; i < 4; ++i) { u_t[i] = tab->uni.t[i]; u_d[i] = tab->uni.d[i]; u_k[i] = tab->uni.k[i]; }
     }
+    // MODE 5: ... and that range is a signed SAT::TCPL format: LEFT-JUSTIFIED values (qg_fix.h, QTreeTable::lj) — the planes are
+    // staged with the shifts that justify each product; the clamp bit of the multiply-add, the add and the subtract saturates
+    int j_s = 0, j_mask = -1, j_t[4] = {0, 0, 0, 0}, j_e[6] = {0, 0, 0, 0, 0, 0};
+    if constexpr (MODE == 5) {
+        j_s = tab->lj.s;
+        j_mask = (int)(~0u << j_s);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) j_t[i] = tab->lj.t[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) j_e[i] = tab->lj.e[i];
+    }
+    auto jmask4 = [&](int (&x)[4]) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) x[o] &= j_mask;
+    };
     auto uclamp4 = [&](int (&x)[4]) {
 #pragma unroll
         for (int o = 0; o < 4; ++o) asm("v_med3_i32 %0, %0, %1, %2" : "+v"(x[o]) : "s"(u_lo), "v"(u_hi));
@@ -256,13 +271,20 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
                 const int ar4[4] = {x[0].x, x[0].y, x[0].z, x[0].w}, ai4[4] = {x[1].x, x[1].y, x[1].z, x[1].w};
                 const int br4[4] = {y[0].x, y[0].y, y[0].z, y[0].w}, bi4[4] = {y[1].x, y[1].y, y[1].z, y[1].w};
                 int ab[4], ba[4], cd[4];
-                constexpr int SM = MODE == 4 ? 2 : MODE;               // (the staged sums keep their own compact records)
+                constexpr int SM = (MODE == 4 || MODE == 5) ? 2 : MODE;   // (the staged sums keep their own compact records)
                 op_addsub<SM, 4>(ab, ar4, ai4, tab, QG_T_AB, false);  // (a+b), per A element
                 op_addsub<SM, 4>(ba, ai4, ar4, tab, QG_T_BA, true);   // (b-a), per A element
                 op_addsub<SM, 4>(cd, br4, bi4, tab, QG_T_CD, false);  // (c+d), per B element
                 if constexpr (MODE == 4) {   // the products' exact left shifts, once per element: A = (a+b) c, B = (c+d) b, C = (b-a) d
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { ab[e] = __mul24(ab[e], u_k[0]); cd[e] = __mul24(cd[e], u_k[1]); ba[e] = __mul24(ba[e], u_k[2]); }
+                }
+                if constexpr (MODE == 5) {   // planes (a+b), b, (b-a) / c, (c+d), d with the shifts that justify A, B, C
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ab[e] <<= j_e[0]; ba[e] <<= j_e[2]; cd[e] <<= j_e[4]; }
+                    x[1] = make_int4(x[1].x << j_e[1], x[1].y << j_e[1], x[1].z << j_e[1], x[1].w << j_e[1]);
+                    y[0] = make_int4(y[0].x << j_e[3], y[0].y << j_e[3], y[0].z << j_e[3], y[0].w << j_e[3]);
+                    y[1] = make_int4(y[1].x << j_e[5], y[1].y << j_e[5], y[1].z << j_e[5], y[1].w << j_e[5]);
                 }
                 *(int4*)&sA[0][r][q * 4] = make_int4(ab[0], ab[1], ab[2], ab[3]);
                 *(int4*)&sA[1][r][q * 4] = x[1];
@@ -271,6 +293,13 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
                 *(int4*)&sB[1][r][q * 4] = make_int4(cd[0], cd[1], cd[2], cd[3]);
                 *(int4*)&sB[2][r][q * 4] = y[1];
             } else {
+                if constexpr (MODE == 5) {   // planes a, b, c, d with the shifts that justify ac, bd, ad, bc
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        x[p] = make_int4(x[p].x << j_e[p], x[p].y << j_e[p], x[p].z << j_e[p], x[p].w << j_e[p]);
+                        y[p] = make_int4(y[p].x << j_e[2 + p], y[p].y << j_e[2 + p], y[p].z << j_e[2 + p], y[p].w << j_e[2 + p]);
+                    }
+                }
                 if constexpr (MODE == 4) {   // planes a, b, c, d with their factors
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
@@ -326,7 +355,16 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
                                 ab[i * 2 + j] = a0[i]; xi[i * 2 + j] = a1[i]; ba[i * 2 + j] = a2[i];
                                 yr[i * 2 + j] = b0[j]; cd[i * 2 + j] = b1[j]; yi[i * 2 + j] = b2[j];
                             }
-                        if constexpr (MODE == 4) {
+                        if constexpr (MODE == 5) {
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) {
+                                PA[o] = sat_mad24_vvs(ab[o], yr[o], j_t[0]) & j_mask;
+                                PB[o] = sat_mad24_vvs(cd[o], xi[o], j_t[1]) & j_mask;
+                                PC[o] = sat_mad24_vvs(ba[o], yi[o], j_t[2]) & j_mask;
+                            }
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) { v[0][o] = sat_sub(PA[o], PB[o]); v[1][o] = sat_sub(PB[o], PC[o]); }   // (clean subtrahends)
+                        } else if constexpr (MODE == 4) {
 #pragma unroll
                             for (int o = 0; o < 4; ++o) { PA[o] = mad24_vvs(ab[o], yr[o], u_t[0]); PB[o] = mad24_vvs(cd[o], xi[o], u_t[1]); PC[o] = mad24_vvs(ba[o], yi[o], u_t[2]); }
 #pragma unroll
@@ -364,7 +402,17 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
                                 yr[i * 2 + j] = b0[j]; yi[i * 2 + j] = b1[j];
                             }
                         int ac[4], bd[4], ad[4], bc[4];
-                        if constexpr (MODE == 4) {
+                        if constexpr (MODE == 5) {
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) {
+                                ac[o] = sat_mad24_vvs(xr[o], yr[o], j_t[0]) & j_mask;
+                                bd[o] = sat_mad24_vvs(xi[o], yi[o], j_t[1]) & j_mask;
+                                ad[o] = sat_mad24_vvs(xr[o], yi[o], j_t[2]) & j_mask;
+                                bc[o] = sat_mad24_vvs(xi[o], yr[o], j_t[3]) & j_mask;
+                            }
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) { v[0][o] = sat_sub(ac[o], bd[o]); v[1][o] = sat_add(ad[o], bc[o]); }
+                        } else if constexpr (MODE == 4) {
 #pragma unroll
                             for (int o = 0; o < 4; ++o) {
                                 ac[o] = mad24_vvs(xr[o], yr[o], u_t[0]) >> u_d[0];
@@ -413,6 +461,12 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
 #pragma unroll
                                         for (int o = 0; o < 4; ++o) low[p][l][o] = v[p][o];
                                     parked_low = true;
+                                } else if constexpr (MODE == 5) {
+                                    // RE / IM come from one saturating operation on clean values: 2^31 - 1 or clean.  One more
+                                    // saturating add keeps floor(v / 2^s) right; before the next one the low bits are cleared
+#pragma unroll
+                                    for (int o = 0; o < 4; ++o) { v[0][o] = sat_add(low[0][l][o], v[0][o]); v[1][o] = sat_add(low[1][l][o], v[1][o]); }
+                                    if ((l & 1) == 0) { jmask4(v[0]); jmask4(v[1]); }
                                 } else if constexpr (MODE == 4) {
 #pragma unroll
                                     for (int o = 0; o < 4; ++o) { v[0][o] += low[0][l][o]; v[1][o] += low[1][l][o]; }
@@ -437,6 +491,10 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
 #pragma unroll
                             for (int o = 0; o < 4; ++o) up[p][u][o] = v[p][o];
                         parked = true;
+                    } else if constexpr (MODE == 5) {
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) { v[0][o] = sat_add(up[0][u][o], v[0][o]); v[1][o] = sat_add(up[1][u][o], v[1][o]); }
+                        if ((u & 1) == 0) { jmask4(v[0]); jmask4(v[1]); }   // (level 4 + u: the even ones)
                     } else if constexpr (MODE == 4) {
 #pragma unroll
                         for (int o = 0; o < 4; ++o) { v[0][o] += up[0][u][o]; v[1][o] += up[1][u][o]; }
@@ -448,6 +506,10 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
                 }
             }
         }
+    }
+    if constexpr (MODE == 5) {   // floor(v / 2^s): the value
+#pragma unroll
+        for (int o = 0; o < 4; ++o) { v[0][o] >>= j_s; v[1][o] >>= j_s; }
     }
     qg_step_all<int, 4>(v[0], tab->c_cvt[0]);
     qg_step_all<int, 4>(v[1], tab->c_cvt[1]);
@@ -499,9 +561,12 @@ hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, i
     case 1: QG_CPLX_LAUNCH(1); break;
     case 2: QG_CPLX_LAUNCH(2); break;
     case 3: QG_CPLX_LAUNCH(3); break;
+    case 5:     // ... on left-justified values
     case 4: {   // one clamp for the whole loop (qg_plan.cpp)
         static const bool no_uniform = QG_DIAG_ENV("QG_NO_UNIFORM_CLAMP");   // A/B switch (diagnostic library): the compact form such a descriptor had before
+        static const bool no_lj = QG_DIAG_ENV("QG_NO_LEFT_JUSTIFIED");
         if (no_uniform) QG_CPLX_LAUNCH(2);
+        else if (fixed == 5 && !no_lj) QG_CPLX_LAUNCH(5);
         else QG_CPLX_LAUNCH(4);
         break;
     }

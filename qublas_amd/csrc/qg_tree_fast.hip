@@ -257,9 +257,9 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
     QFix flow[4];
 #pragma unroll
     for (int l = 0; l < 4; ++l) flow[l] = tab->fadd[0][l];
-    // MODE 6 (QTreeTable::uni): shift of the justified values, their mask, the product's scaled rounding addend, the operands' factors
-    const int lj_s = MODE == 6 ? tab->uni.d[0] : 0, lj_mask = MODE == 6 ? (int)(~0u << lj_s) : -1, lj_t = MODE == 6 ? tab->uni.t[0] : 0;
-    const int lj_ea = MODE == 6 ? tab->uni.d[1] : 0, lj_eb = MODE == 6 ? tab->uni.d[2] : 0;
+    // MODE 6 (QTreeTable::lj): shift of the justified values, their mask, the product's scaled rounding addend, the operands' factors
+    const int lj_s = MODE == 6 ? tab->lj.s : 0, lj_mask = MODE == 6 ? (int)(~0u << lj_s) : -1, lj_t = MODE == 6 ? tab->lj.t[0] : 0;
+    const int lj_ea = MODE == 6 ? tab->lj.e[0] : 0, lj_eb = MODE == 6 ? tab->lj.e[1] : 0;
 
     int low[4][NOUT];
     int up[MAXL - 4][NOUT];
@@ -491,6 +491,165 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
         }
 }
 
+// ---- packed 16-bit form (fast_mode 7): the left-justified form of MODE 6 for formats of at most 16 bits, TWO outputs per
+// register.  A lane owns 4 rows x 2 columns (tx, tx + 16) as 4 registers (low half: column tx); a product pair is ONE
+// v_pk_mad_i16 ... clamp (the hardware saturates a * b + t from the exact product, tools/ubench/sat_semantics.hip) whose A
+// operand is broadcast to both halves by op_sel (A is staged as 16-bit values, two k per dword; B as (column tx, column
+// tx + 16) pairs per k), + v_and; a node pair is one v_pk_add_i16 ... clamp, + v_and at the odd levels: 1.9 vector
+// instructions per MAC where MODE 6 spends 3.8 and the v_med3 form 5.3 (BASELINE configuration 2 as literally configured).
+constexpr int PKP = 18;   // dwords per sA16 row (16 + 2: 8-byte reads stay aligned)
+template <int HALF>
+__device__ __forceinline__ int pk_mad_sat(int a2, int b2, int t2)
+{
+    int r;
+    if (HALF == 0) asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] clamp" : "=v"(r) : "v"(a2), "v"(b2), "s"(t2));
+    else asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] clamp" : "=v"(r) : "v"(a2), "v"(b2), "s"(t2));
+    return r;
+}
+__device__ __forceinline__ int pk_add_sat(int a, int b)
+{
+    int r;
+    asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int pk2(int lo, int hi) { return (int)(((unsigned)lo & 0xffffu) | ((unsigned)hi << 16)); }
+
+#define NODE16(X, L)                                                                                     \
+    do {                                                                                                 \
+        _Pragma("unroll") for (int o_ = 0; o_ < 4; ++o_) v[o_] = pk_add_sat(X[o_], v[o_]);               \
+        if ((L) & 1) { _Pragma("unroll") for (int o_ = 0; o_ < 4; ++o_) v[o_] &= mask2; }                \
+    } while (0)
+
+template <int MAXL>
+__global__ __launch_bounds__(256) void k_tree_pk16(QTreeFastArgs g)
+{
+    __shared__ __attribute__((aligned(16))) int sA[TMB][PKP];       // [row][k / 2]: (k even, k odd)
+    __shared__ __attribute__((aligned(16))) int sB[TNB / 2][PITCH]; // [column pair][k]: (column p, column p + 16)
+    const QTreeTable* __restrict__ tab = g.tab;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int64_t tiles_n = (g.N + TNB - 1) / TNB, tiles_m = (g.M + TMB - 1) / TMB;
+    int64_t bid = blockIdx.x;
+    {   // XCD-aware block order, as k_tree_fast
+        const int64_t nwg = tiles_m * tiles_n, q = nwg / 8, r = nwg % 8, x = bid % 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+    }
+    constexpr int64_t GMT = 16;
+    const int64_t grp = bid / (GMT * tiles_n), first_m = grp * GMT;
+    const int64_t gsz = (tiles_m - first_m) < GMT ? (tiles_m - first_m) : GMT;
+    const int64_t m0 = (first_m + (bid % (GMT * tiles_n)) % gsz) * TMB, n0 = ((bid % (GMT * tiles_n)) / gsz) * TNB;
+    const int nl = tab->n_levels_k;
+    const int s16 = tab->lj.e[2], ea = tab->lj.e[3], eb = tab->lj.e[4];
+    const int m1 = (0xffff << s16) & 0xffff, mask2 = m1 | (m1 << 16);
+    const int t2 = pk2(tab->lj.t[1], tab->lj.t[1]);
+
+    int low[4][4];
+    int up[MAXL - 4][4];
+    int v[4] = {0, 0, 0, 0};
+
+    for (int64_t k0 = 0; k0 < g.K; k0 += KC) {
+        __syncthreads();
+        // stage A: 64 rows x 32 k, 2 chunks of 4 k per thread, as 16-bit values; B: 16 column pairs x 32 k, threads 0..127
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ch = tid + 256 * c, r = ch >> 3, q = ch & 7;
+            int4 x = make_int4(0, 0, 0, 0);
+            if (m0 + r < g.M) x = *(const int4*)(g.A + (m0 + r) * g.K + k0 + q * 4);
+            *(int2*)&sA[r][q * 2] = make_int2(pk2(x.x << ea, x.y << ea), pk2(x.z << ea, x.w << ea));
+        }
+        if (tid < 128) {
+            const int p = tid >> 3, q = tid & 7;
+            int4 x = make_int4(0, 0, 0, 0), y = make_int4(0, 0, 0, 0);
+            if (n0 + p < g.N) x = *(const int4*)(g.B + (n0 + p) * g.K + k0 + q * 4);
+            if (n0 + p + 16 < g.N) y = *(const int4*)(g.B + (n0 + p + 16) * g.K + k0 + q * 4);
+            *(int4*)&sB[p][q * 4] = make_int4(pk2(x.x << eb, y.x << eb), pk2(x.y << eb, y.y << eb), pk2(x.z << eb, y.z << eb), pk2(x.w << eb, y.w << eb));
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int kb = 0; kb < KC / 16; ++kb) {
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                int2 a2[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a2[i] = *(const int2*)&sA[ty * 4 + i][kb * 8 + kq * 2];
+                const int4 b4 = *(const int4*)&sB[tx][kb * 16 + kq * 4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kk = kq * 4 + e;
+                    const int bv = e == 0 ? b4.x : e == 1 ? b4.y : e == 2 ? b4.z : b4.w;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int av = e < 2 ? a2[i].x : a2[i].y;
+                        v[i] = ((e & 1) ? pk_mad_sat<1>(av, bv, t2) : pk_mad_sat<0>(av, bv, t2)) & mask2;
+                    }
+                    if ((kk & 1) == 0) {
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) low[0][o] = v[o];
+                    } else {
+                        NODE16(low[0], 0);
+                        if ((kk & 2) == 0) {
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) low[1][o] = v[o];
+                        } else {
+                            NODE16(low[1], 1);
+                            if ((kk & 4) == 0) {
+#pragma unroll
+                                for (int o = 0; o < 4; ++o) low[2][o] = v[o];
+                            } else {
+                                NODE16(low[2], 2);
+                                if ((kk & 8) == 0) {
+#pragma unroll
+                                    for (int o = 0; o < 4; ++o) low[3][o] = v[o];
+                                } else {
+                                    NODE16(low[3], 3);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            const unsigned idx = (unsigned)((k0 >> 4) + kb);
+            bool parked = false;
+#pragma unroll
+            for (int u = 0; u < MAXL - 4; ++u) {
+                if (!parked && 4 + u < nl) {
+                    if (((idx >> u) & 1u) == 0) {
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) up[u][o] = v[o];
+                        parked = true;
+                    } else {
+                        NODE16(up[u], 4 + u);
+                    }
+                }
+            }
+        }
+    }
+    // the root: floor(half / 2^s) of each half, then the conversion into C
+    int r8[NOUT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r8[i * 2 + 0] = ((int)((unsigned)v[i] << 16) >> 16) >> s16;
+        r8[i * 2 + 1] = (v[i] >> 16) >> s16;
+    }
+    step_all(r8, tab->c_cvt[0]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t m = m0 + ty * 4 + i, n = n0 + tx + 16 * j;
+            if (m < g.M && n < g.N) {
+                const int64_t idx = m * g.N + n;
+                const int r = r8[i * 2 + j];
+                switch (g.cbytes) {
+                case 1: ((int8_t*)g.C)[idx] = (int8_t)r; break;
+                case 2: ((int16_t*)g.C)[idx] = (int16_t)r; break;
+                case 4: ((int32_t*)g.C)[idx] = r; break;
+                default: ((int64_t*)g.C)[idx] = (int64_t)r; break;
+                }
+            }
+        }
+}
+
 } // namespace
 
 template <bool SPLIT, bool MUL24, int MODE>
@@ -510,6 +669,11 @@ hipError_t qg_launch_tree_fast(const QTreeTable* dev_table, int n_levels, int sp
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks);
     if (mode != 0 && !mul24) mode = 0;  // the fixed-mode variants are built for 24-bit multiplies only
+    if (mode == 7) {   // ... in packed 16-bit halves
+        if (n_levels <= 12) hipLaunchKernelGGL((k_tree_pk16<12>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_tree_pk16<16>), grid, dim3(256), 0, st, g);
+        return hipGetLastError();
+    }
     if (mode == 6) {   // left-justified saturating form: never split (the planner checked the scaled operands against 24 bits)
         launch_tf<false, true, 6>(n_levels, grid, st, g);
         return hipGetLastError();

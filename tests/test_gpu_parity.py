@@ -300,7 +300,9 @@ def test_real_tree_kernel_step_forms(oracle):
     e88z = Qu(8, 8, True, TRN.TCPL, SAT.ZERO)
     cases = [
         (e88, e88, dict(), "one format, SAT::TCPL, left-justified"),                                                  # saturating v_mad / v_add on x * 2^15
-        (Qu(4, 3), Qu(4, 3), dict(), "one format, SAT::TCPL, left-justified"),                                        # configuration 2 as literally configured
+        (Qu(4, 3), Qu(4, 3), dict(), "one format, SAT::TCPL, left-justified, packed 16-bit"),                         # configuration 2 as literally configured: v_pk_mad_i16 / v_pk_add_i16 ... clamp
+        (Qu(4, 3), Qu(9, 2), dict(mul_args=Qu(5, 4, True, RND.POS_INF, SAT.TCPL), add_args=[Qu(5, 4)]), "one format, SAT::TCPL, left-justified, packed 16-bit"),
+        (Qu(3, 2, False), Qu(9, 2), dict(mul_args=Qu(4, 2, True, RND.NEG_INF, SAT.TCPL), add_args=[Qu(4, 2)]), "one format, SAT::TCPL, left-justified, packed 16-bit"),   # unsigned operands in a signed format
         (e88, Qu(12, 8), dict(mul_args=Qu(8, 8, True, RND.POS_INF, SAT.TCPL), add_args=[Qu(8, 8)]), "one format, SAT::TCPL, left-justified"),   # the addend rides in the multiply-add
         (Qu(6, 5), Qu(9, 2), dict(mul_args=Qu(7, 6, True, RND.NEG_INF, SAT.TCPL), add_args=[Qu(7, 6)]), "one format, SAT::TCPL, left-justified"),
         (Qu(8, 8, False), Qu(8, 8, False), dict(), "one format, SAT::TCPL"),                                          # unsigned: [0, 2^W - 1] is not the int32 range
@@ -341,16 +343,19 @@ def test_complex_fixed_mode_step_forms(oracle):
     c5 = Qcomplex(P(6, 3), P(6, -3))
     cases = [
         # (elements, C, lowering keywords, expected form)
-        (c5, c5, dict(mul_args=TFComplexMul()), "fixed modes, one clamp for the whole loop"),    # configuration 5 itself: every in-loop value is int<6,3>
-        (c5, Qcomplex(P(12, 4), P(10, 2)), dict(mul_args=TFComplexMul()), "fixed modes, one clamp for the whole loop"),   # ... whatever C is
+        (c5, c5, dict(mul_args=TFComplexMul()), "fixed modes, one clamp, left-justified"),    # configuration 5 itself: every in-loop value is int<6,3>
+        (c5, Qcomplex(P(12, 4), P(10, 2)), dict(mul_args=TFComplexMul()), "fixed modes, one clamp, left-justified"),   # ... whatever C is
         (Qcomplex(P(5, 4), P(7, 2)), c5, dict(mul_args=TFComplexMul(abT=Tags(7, 2), cdT=Tags(5, 4), abcT=Tags(6, 3), cdbT=Tags(6, 3), badT=Tags(6, 3), ABT=Tags(6, 3), BCT=Tags(6, 3)),
                                                add_args=[Qcomplex(P(6, 3), P(6, 3))]),
-         "fixed modes, one clamp for the whole loop"),                                            # products of different alignments into one format
+         "fixed modes, one clamp, left-justified"),                                            # products of different alignments into one format
         (c5, c5, dict(mul_args=TFComplexMul(ABT=Tags(7, 3))), "fixed modes, compact"),           # one wider difference: not uniform
-        (Qcomplex(P(6, 3), P(6, 3)), c5, dict(mul_args=BasicComplexMul()), "fixed modes, one clamp for the whole loop"),   # Basic with equal part formats
+        # SAT::SMGN everywhere: one range [-hi, hi], but not the range of a left-justified int32: v_med3 with the bounds in registers
+        (Qcomplex(Qu(6, 3, True, RND.NEG_INF, SAT.SMGN), Qu(6, 3, True, RND.NEG_INF, SAT.SMGN)), c5, dict(mul_args=TFComplexMul()), "fixed modes, one clamp for the whole loop"),
+        (Qcomplex(Qu(6, 3, True, RND.NEG_INF, SAT.SMGN), Qu(6, 3, True, RND.NEG_INF, SAT.SMGN)), c5, dict(mul_args=BasicComplexMul()), "fixed modes, one clamp for the whole loop"),
+        (Qcomplex(P(6, 3), P(6, 3)), c5, dict(mul_args=BasicComplexMul()), "fixed modes, one clamp, left-justified"),   # Basic with equal part formats
         (Qcomplex(P(5, 4), P(7, 2)), c5, dict(mul_args=BasicComplexMul(acT=Tags(6, 9), bdT=Tags(6, 9), adT=Tags(6, 9), bcT=Tags(6, 9), acbdT=Tags(6, 9), adbcT=Tags(6, 9)),
                                                add_args=[Qcomplex(P(6, 9), P(6, 9))]),
-         "fixed modes, one clamp for the whole loop"),                                            # Basic: products shift left by 1, 5, 3, 3 bits: plane factors
+         "fixed modes, one clamp, left-justified"),                                            # Basic: products shift left by 1, 5, 3, 3 bits: plane factors
         (c5, c5, dict(mul_args=BasicComplexMul()), "fixed modes, compact"),
         (c5, Qcomplex(P(12, 4), P(10, 2)), dict(mul_args=TFComplexMul(abcT=Tags(9, 5), ABT=Tags(11, 2)), add_args=[Qcomplex(P(14, 0), P(12, -3))]),
          "fixed modes, compact"),                                                                 # tags, one level type (fewer fraction bits: rounding nodes)
@@ -358,7 +363,7 @@ def test_complex_fixed_mode_step_forms(oracle):
          "fixed modes, compact"),                                                                 # level 1 has MORE fraction bits than level 0: a node shifts left
         (c5, Qcomplex(P(12, 4), P(10, 2)), dict(mul_args=BasicComplexMul(acT=Tags(20, 8))), "fixed modes, table"),   # a 29-bit product format: beyond v_mad_i32_i24's operands
         # the reference's DEFAULT modes (TRN::TCPL / SAT::TCPL), RND::NEG_INF and SAT::SMGN are compact too
-        (Qcomplex(Qu(6, 3), Qu(6, -3)), Qcomplex(Qu(9, 3), Qu(9, 1)), dict(mul_args=TFComplexMul()), "fixed modes, one clamp for the whole loop"),
+        (Qcomplex(Qu(6, 3), Qu(6, -3)), Qcomplex(Qu(9, 3), Qu(9, 1)), dict(mul_args=TFComplexMul()), "fixed modes, one clamp, left-justified"),
         (Qcomplex(Qu(5, 4, True, RND.NEG_INF, SAT.SMGN), Qu(6, 2, True, RND.NEG_INF, SAT.SMGN)), Qcomplex(Qu(8, 2, True, RND.NEG_INF, SAT.SMGN), Qu(8, 2, True, TRN.TCPL, SAT.TCPL)),
          dict(mul_args=BasicComplexMul(), add_args=[Qcomplex(Qu(12, 3, True, RND.NEG_INF, SAT.SMGN), Qu(12, 1, True, RND.NEG_INF, SAT.SMGN))]), "fixed modes, compact"),
         # value-dependent roundings (RND::ZERO / INF / CONV, TRN::SMGN) and SAT::ZERO / WRP::TCPL: rounding / overflow kinds of the compact form,

@@ -21,6 +21,9 @@ CI = Qcomplex(Qu(6, 3, True, RND.INF), Qu(6, -3, True, RND.INF))
 CASES = [
     ("int<8,8> default tags (one format, SAT::TCPL: left-justified; QG_NO_LEFT_JUSTIFIED=1 in the diagnostic library: the v_med3 form)", lower(E, E, E, S, S, S), 0),
     ("same, run-time modes forced", lower(E, E, E, S, S, S), capi.OPT_RUNTIME_MODES),
+    ("int<4,3> default tags at 1024^3 (configuration 2 as literally configured: packed 16-bit; QG_NO_PACKED16=1: left-justified 32-bit; QG_NO_LEFT_JUSTIFIED=1: v_med3)",
+     lower(Qu(4, 3), Qu(4, 3), Qu(4, 3), 1024, 1024, 1024), 0),
+    ("int<4,3> default tags at 4096^3", lower(Qu(4, 3), Qu(4, 3), Qu(4, 3), 4096, 4096, 4096), 0),
     ("int<8,8>, level type Qu<12,8> (QgemulAddArgs)", lower(E, E, Qu(12, 8), S, S, S, add_args=[Qu(12, 8)]), 0),
     ("same, run-time modes forced", lower(E, E, Qu(12, 8), S, S, S, add_args=[Qu(12, 8)]), capi.OPT_RUNTIME_MODES),
     ("int<8,8> SAT::ZERO, level types Qu<10,8>, Qu<12,6> SAT::ZERO", lower(EZ, EZ, Qu(12, 6, True, TRN.TCPL, SAT.ZERO), S, S, S,
@@ -56,7 +59,7 @@ def main():
             pA, pB, pC = ctx.alloc(pb[0]), ctx.alloc(pb[1]), ctx.alloc(pb[2])
             plan.fill(capi.OPERAND_A, 1, 0, pA)
             plan.fill(capi.OPERAND_B, 2, 0, pB)
-            ms = plan.time_execute(pC, pA, pB, 2, 5)
+            ms = plan.time_execute(pC, pA, pB, 3, 10)
             print(json.dumps({"case": name, "kernel": capi.KERNEL_NAMES[plan.info.kernel], "steps": plan.info.reason.decode().split("steps: ")[-1], "ms": ms}), flush=True)
             for p in (pA, pB, pC):
                 ctx.free(p)
