@@ -52,7 +52,9 @@ INT8_DENSE_PEAK_OPS = 5.0e15   # MI355X dense int8 MFMA, /opt/skills/guides/MI35
 HBM_PEAK = 8.0e12
 N_SIMD, LANES, CYCLES_PER_VALU_INSTR = 256 * 4, 64, 4.0
 # vector instructions per MAC that an exact leaf + node of the form cannot go below, counted on the ISA; None: no account
-ISA_FLOOR = {"c3T": 8.0, "c2T": 5.0}
+# (c2T: packed 16-bit halves, per MAC 1/2 multiply-add + 1/2 and + 1/2 add + 1/6 and; c3Td: the same steps unpacked; c5TF: per complex MAC
+#  (3 multiply-adds + 3 and + 2 subtracts + 2 adds + 4/3 and) / 2; c3T: SAT::ZERO, split product 5 + range test and select per leaf and node 3)
+ISA_FLOOR = {"c3T": 8.0, "c2T": 1.67, "c3Td": 3.33, "c5TF": 5.67}
 
 
 def parse_args(argv=None):

@@ -341,7 +341,7 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
         // which form of the complex kernel's steps this descriptor gets (tests assert their coverage through it)
         const int fx = (flags & QG_OPT_RUNTIME_MODES) ? 0 : an->cplx_fixed_ok;
         snprintf(info->reason, sizeof info->reason, "exact tree evaluation; complex kernel steps: %s",
-                 fx >= 8 ? "compact, branch-free rounding / overflow kinds" : fx == 5 ? "fixed modes, one clamp, left-justified" : fx == 4 ? "fixed modes, one clamp for the whole loop" : fx == 3 ? "compact, rounding / overflow kinds" : fx == 2 ? "fixed modes, compact" : fx == 1 ? "fixed modes, table" : "run-time modes");
+                 fx >= 8 ? "compact, branch-free rounding / overflow kinds" : fx == 6 ? "fixed modes, one clamp, packed 16-bit" : fx == 5 ? "fixed modes, one clamp, left-justified" : fx == 4 ? "fixed modes, one clamp for the whole loop" : fx == 3 ? "compact, rounding / overflow kinds" : fx == 2 ? "fixed modes, compact" : fx == 1 ? "fixed modes, table" : "run-time modes");
     }
     info->limbs[0] = LA;
     info->limbs[1] = LB;

@@ -50,6 +50,31 @@ __device__ __forceinline__ int sat_mad24_vvs(int a, int b, int c)
     return r;
 }
 
+// ... and in packed 16-bit halves (x * 2^(16 - width), two values per register).  The multiply-add's first operand is one half
+// (HALF) of its register for BOTH results: an A element against a pair of B columns.
+template <int HALF>
+__device__ __forceinline__ int pk_mad_sat(int a2, int b2, int t2)
+{
+    int r;
+    if (HALF == 0) asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] clamp" : "=v"(r) : "v"(a2), "v"(b2), "s"(t2));
+    else asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] clamp" : "=v"(r) : "v"(a2), "v"(b2), "s"(t2));
+    return r;
+}
+__device__ __forceinline__ int pk_add_sat(int a, int b)
+{
+    int r;
+    asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int pk_sub_sat(int a, int b)
+{
+    int r;
+    asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int pk2(int lo, int hi) { return (int)(((unsigned)lo & 0xffffu) | ((unsigned)hi << 16)); }
+
+
 template <int N>
 __device__ __forceinline__ void fx_finish(int (&v)[N], const QFix& f)
 {

@@ -735,7 +735,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                 T.lj.e[1] = eb;
                 out->fast_mode = 6;
                 // 7: ... in 16-bit halves, two outputs per register (k_tree_pk16): the format has at most 16 bits and the justified
-                // operands fit int16.  lj.e[2] = the shift there, e[3] / e[4] the operands' shifts, t[1] the scaled addend.
+                // operands fit int16 (QTreeTable::lj16).
                 const int s16 = 16 - Wt;
                 if (s16 >= 1 && s16 - pq.d >= 0) {
                     int ea16 = s16 - pq.d;
@@ -743,10 +743,11 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                     if (ea16 < 0) ea16 = 0;
                     const int eb16 = s16 - pq.d - ea16;
                     if (bitsA + ea16 <= 16 && bitsB + eb16 <= 16 && eb16 >= 0) {
-                        T.lj.e[2] = s16;
-                        T.lj.e[3] = ea16;
-                        T.lj.e[4] = eb16;
-                        T.lj.t[1] = (int32_t)(t << (s16 - pq.d));
+                        memset(&T.lj16, 0, sizeof T.lj16);
+                        T.lj16.s = s16;
+                        T.lj16.e[0] = ea16;
+                        T.lj16.e[1] = eb16;
+                        T.lj16.t[0] = (int32_t)(t << (s16 - pq.d));
                         out->fast_mode = 7;
                     }
                 }
@@ -964,46 +965,52 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                 if (uni && r0.lo == -r0.hi - 1 && ((r0.hi + 1) & r0.hi) == 0 && r0.hi > 0) {
                     int Wt = 1;
                     while (((int64_t)1 << (Wt - 1)) <= r0.hi) ++Wt;
-                    const int sj = 32 - Wt;
                     auto lg = [](int32_t k) { int n = 0; while ((1 << n) < k) ++n; return n; };
                     auto wd = [](qfmt f) { return 1 + (int)f.I + (int)f.F; };
-                    bool lj = sj >= 1;
-                    memset(&T.lj, 0, sizeof T.lj);
-                    T.lj.s = sj;
-                    int E[4] = {0, 0, 0, 0};
-                    for (size_t i = 0; i < prods.size() && lj; ++i) {
-                        const QFix& f = T.fmul[prods[i]];
-                        E[i] = sj + lg(f.ka) - f.d;
-                        lj = E[i] >= 0 && (f.d == 0 || sj - f.d >= 0);
-                        if (lj) T.lj.t[i] = f.d ? (int32_t)((uint32_t)f.t << (sj - f.d)) : 0;
-                    }
-                    if (lj && tf) {
-                        // products A = (a+b) c, B = (c+d) b, C = (b-a) d: every plane serves one product
-                        const qfmt fx[3] = {d->mul[QG_T_AB], d->mul[QG_T_CD], d->mul[QG_T_BA]}, fy[3] = {cc, b, dd};
-                        const int px[3] = {0, 4, 2}, py[3] = {3, 1, 5};   // planes (a+b), b, (b-a), c, (c+d), d
-                        for (int i = 0; i < 3 && lj; ++i) {
-                            int ex = E[i] < 24 - wd(fx[i]) ? E[i] : 24 - wd(fx[i]);
-                            if (ex < 0) ex = 0;
-                            const int ey = E[i] - ex;
-                            lj = wd(fx[i]) + ex <= 24 && wd(fy[i]) + ey <= 24;
-                            T.lj.e[px[i]] = ex;
-                            T.lj.e[py[i]] = ey;
+                    // word: 32 (operands of v_mad_i32_i24: 24 bits) or 16 (halves of v_pk_mad_i16: 16 bits)
+                    auto justify = [&](int word, int opbits, QJustify* J) {
+                        const int sj = word - Wt;
+                        bool lj = sj >= 1;
+                        memset(J, 0, sizeof *J);
+                        J->s = sj;
+                        int E[4] = {0, 0, 0, 0};
+                        for (size_t i = 0; i < prods.size() && lj; ++i) {
+                            const QFix& f = T.fmul[prods[i]];
+                            E[i] = sj + lg(f.ka) - f.d;
+                            lj = E[i] >= 0 && (f.d == 0 || sj - f.d >= 0);
+                            if (lj) J->t[i] = f.d ? (int32_t)((uint32_t)f.t << (sj - f.d)) : 0;
                         }
-                    } else if (lj) {
-                        const int px[4] = {0, 1, 0, 1}, py[4] = {2, 3, 3, 2};   // ac, bd, ad, bc over planes a b c d
-                        const qfmt pf[4] = {a, b, cc, dd};
-                        bool found = false;
-                        for (int la = 0; la <= 24 - wd(pf[0]) && !found; ++la) {
-                            const int lc = E[0] - la, ld = E[2] - la, lb = E[3] - lc;
-                            if (lc < 0 || ld < 0 || lb < 0 || lb + ld != E[1]) continue;
-                            if (wd(pf[1]) + lb > 24 || wd(pf[2]) + lc > 24 || wd(pf[3]) + ld > 24) continue;
-                            T.lj.e[0] = la; T.lj.e[1] = lb; T.lj.e[2] = lc; T.lj.e[3] = ld;
-                            found = true;
+                        if (lj && tf) {
+                            // products A = (a+b) c, B = (c+d) b, C = (b-a) d: every plane serves one product
+                            const qfmt fx[3] = {d->mul[QG_T_AB], d->mul[QG_T_CD], d->mul[QG_T_BA]}, fy[3] = {cc, b, dd};
+                            const int px[3] = {0, 4, 2}, py[3] = {3, 1, 5};   // planes (a+b), b, (b-a), c, (c+d), d
+                            for (int i = 0; i < 3 && lj; ++i) {
+                                int ex = E[i] < opbits - wd(fx[i]) ? E[i] : opbits - wd(fx[i]);
+                                if (ex < 0) ex = 0;
+                                const int ey = E[i] - ex;
+                                lj = wd(fx[i]) + ex <= opbits && wd(fy[i]) + ey <= opbits;
+                                J->e[px[i]] = ex;
+                                J->e[py[i]] = ey;
+                            }
+                        } else if (lj) {
+                            const qfmt pf[4] = {a, b, cc, dd};   // ac, bd, ad, bc over planes a b c d
+                            bool found = false;
+                            for (int la = 0; la <= opbits - wd(pf[0]) && !found; ++la) {
+                                const int lc = E[0] - la, ld = E[2] - la, lb = E[3] - lc;
+                                if (lc < 0 || ld < 0 || lb < 0 || lb + ld != E[1]) continue;
+                                if (wd(pf[1]) + lb > opbits || wd(pf[2]) + lc > opbits || wd(pf[3]) + ld > opbits) continue;
+                                J->e[0] = la; J->e[1] = lb; J->e[2] = lc; J->e[3] = ld;
+                                found = true;
+                            }
+                            lj = found;
                         }
-                        lj = found;
-                        (void)px; (void)py;
+                        return lj;
+                    };
+                    if (justify(32, 24, &T.lj)) {
+                        out->cplx_fixed_ok = 5;
+                        // 6: ... in packed 16-bit halves, two outputs per register (k_tree_cplx_pk16)
+                        if (justify(16, 16, &T.lj16)) out->cplx_fixed_ok = 6;
                     }
-                    if (lj) out->cplx_fixed_ok = 5;
                 }
             }
         }

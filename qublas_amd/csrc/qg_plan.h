@@ -23,6 +23,10 @@
 struct QFix {
     int32_t ka, kb, t, d, lo, hi, skip, ls;
 };
+// parameters of the LEFT-JUSTIFIED forms (QTreeTable::lj, lj16)
+struct QJustify {
+    int32_t s, t[4], e[6], pad_;
+};
 
 // everything a kernel needs about the arithmetic, laid out for device reads (plan-owned buffer)
 struct QTreeTable {
@@ -46,8 +50,10 @@ struct QTreeTable {
     struct { int32_t lo, hi, t[4], d[4], k[4], pad_[2]; } uni;
     // LEFT-JUSTIFIED forms (qg_fix.h: one signed SAT::TCPL format held as x * 2^s; real fast_mode 6, complex cplx_fixed_ok 5): the
     // shift s, per product the rounding addend scaled to the justified product, and the left shifts the operand planes are staged
-    // with (real: A, B; TF: (a+b), b, (b-a), c, (c+d), d; Basic: a, b, c, d), which justify the products; real, packed 16-bit form (fast_mode 7): e[2] the shift in a half, e[3], e[4] the operands' shifts, t[1] the addend
-    struct { int32_t s, t[4], e[6], pad_; } lj;
+    // with (real: A, B; TF: (a+b), b, (b-a), c, (c+d), d; Basic: a, b, c, d), which justify the products
+    QJustify lj;
+    // ... and in packed 16-bit halves (x * 2^s, s = 16 - width; real fast_mode 7, complex cplx_fixed_ok 6), the same fields
+    QJustify lj16;
 };
 
 // epilogue of the linear class: exact dot product at frac (Fa+Fb) -> C
@@ -70,7 +76,7 @@ struct QAnalysis {
     int split_s;             // > 0: product evaluated split at its rounding shift
     int mul24_ok;            // multiplies fit v_mul_i32_i24
     int cplx_fast_ok;        // the 32-bit complex tree kernel applies
-    int cplx_fixed_ok;       // ... and every step on the path is RND::POS_INF (or exact) + SAT::TCPL: fixed-mode variant (2: compact records; 3: ... with rounding / overflow kinds; 8 + f: ... of the branch-free feature set f; 4: one clamp for the whole loop; 5: ... on left-justified values)
+    int cplx_fixed_ok;       // ... and every step on the path is RND::POS_INF (or exact) + SAT::TCPL: fixed-mode variant (2: compact records; 3: ... with rounding / overflow kinds; 8 + f: ... of the branch-free feature set f; 4: one clamp for the whole loop; 5: ... on left-justified values; 6: ... in packed 16-bit halves)
     int fast_mode;           // 0 runtime modes; 1 one format everywhere, TCPL + SAT::ZERO; 2 TCPL + SAT::TCPL; 3 / 4 / 5 per-level formats, compact steps (QFix; 3: every step clamps, 4: biased values, 5: unbiased); 6 one signed SAT::TCPL format on left-justified values, 7 ... in packed 16-bit halves
     int fast_mode_base;      // fast_mode 6 / 7 (one signed SAT::TCPL format, left-justified saturating steps): the form (2 / 3) the descriptor has without it
     int tree64_ok;           // the 2x2-outputs-per-lane 64-bit tree kernel applies (real, 5..16 levels)

@@ -533,6 +533,218 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
             }
 }
 
+// ---- packed 16-bit form (cplx_fixed_ok 6): MODE 5's left-justified steps for a common format of at most 16 bits, TWO outputs
+// per register.  A lane owns 4 rows x 2 columns (tx, tx + 16; low half: column tx) of both parts; the A-side planes are staged
+// as 16-bit values (two k per dword), the B-side planes as (column tx, column tx + 16) pairs per k; a pair of products is one
+// v_pk_mad_i16 ... clamp whose A operand is broadcast by op_sel, + v_and; RE / IM one v_pk_sub_i16 / v_pk_add_i16 ... clamp; a
+// node pair one v_pk_add_i16 ... clamp, + v_and at the even levels: 6.3 vector instructions per complex MAC (TF) where MODE 5
+// spends 12.9 (BASELINE configuration 5 as literally configured).
+constexpr int TM16 = 64;    // rows of C per block (16 thread rows x 4)
+constexpr int PKP = 18;     // dwords per A-plane row: 16 + 2 (8-byte reads stay aligned)
+
+template <int MAXL, bool TF>
+__global__ __launch_bounds__(256, 3) void k_tree_cplx_pk16(QTreeCplxArgs g)
+{
+    constexpr int NP = TF ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) int sA[NP][TM16][PKP];       // [plane][row][k / 2]: (k even, k odd)
+    __shared__ __attribute__((aligned(16))) int sB[NP][TNB / 2][PITCH];  // [plane][column pair][k]: (column p, column p + 16)
+    const QTreeTable* __restrict__ tab = g.tab;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int64_t tiles_n = (g.N + TNB - 1) / TNB, tiles_m = (g.M + TM16 - 1) / TM16;
+    int64_t bid = blockIdx.x;
+    {   // XCD-aware block order, as k_tree_cplx
+        const int64_t nwg = tiles_m * tiles_n, q = nwg / 8, r = nwg % 8, x = bid % 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+    }
+    constexpr int64_t GMT = 16;
+    const int64_t grp = bid / (GMT * tiles_n), first_m = grp * GMT;
+    const int64_t gsz = (tiles_m - first_m) < GMT ? (tiles_m - first_m) : GMT;
+    const int64_t m0 = (first_m + (bid % (GMT * tiles_n)) % gsz) * TM16, n0 = ((bid % (GMT * tiles_n)) / gsz) * TNB;
+    const int nl = tab->n_levels_k;
+    const int s16 = tab->lj16.s;
+    const int m1 = (0xffff << s16) & 0xffff, mask2 = m1 | (m1 << 16);
+    int t2[4], je[6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t2[i] = pk2(tab->lj16.t[i], tab->lj16.t[i]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) je[i] = tab->lj16.e[i];
+
+    int low[2][4][4];
+    int up[2][MAXL - 4][4];
+    int v[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) v[p][o] = 0;
+#define NODE16C(X0, X1, L)                                                                                         \
+    do {                                                                                                           \
+        _Pragma("unroll") for (int o_ = 0; o_ < 4; ++o_) { v[0][o_] = pk_add_sat(X0[o_], v[0][o_]); v[1][o_] = pk_add_sat(X1[o_], v[1][o_]); } \
+        if (((L) & 1) == 0) { _Pragma("unroll") for (int o_ = 0; o_ < 4; ++o_) { v[0][o_] &= mask2; v[1][o_] &= mask2; } }                   \
+    } while (0)
+
+    for (int64_t k0 = 0; k0 < g.K; k0 += KC) {
+        __syncthreads();
+        // stage A: 64 rows x 32 k of both parts, 2 chunks of 4 k per thread
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ch = tid + 256 * c, r = ch >> 3, q = ch & 7;
+            int4 x[2] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
+            if (m0 + r < g.M) {
+                x[0] = *(const int4*)(g.A + ((int64_t)0 * g.M + m0 + r) * g.K + k0 + q * 4);
+                x[1] = *(const int4*)(g.A + ((int64_t)1 * g.M + m0 + r) * g.K + k0 + q * 4);
+            }
+            const int ar4[4] = {x[0].x, x[0].y, x[0].z, x[0].w}, ai4[4] = {x[1].x, x[1].y, x[1].z, x[1].w};
+            if constexpr (TF) {   // planes (a+b), b, (b-a)
+                int ab[4], ba[4];
+                op_addsub<2, 4>(ab, ar4, ai4, tab, QG_T_AB, false);
+                op_addsub<2, 4>(ba, ai4, ar4, tab, QG_T_BA, true);
+                *(int2*)&sA[0][r][q * 2] = make_int2(pk2(ab[0] << je[0], ab[1] << je[0]), pk2(ab[2] << je[0], ab[3] << je[0]));
+                *(int2*)&sA[1][r][q * 2] = make_int2(pk2(ai4[0] << je[1], ai4[1] << je[1]), pk2(ai4[2] << je[1], ai4[3] << je[1]));
+                *(int2*)&sA[2][r][q * 2] = make_int2(pk2(ba[0] << je[2], ba[1] << je[2]), pk2(ba[2] << je[2], ba[3] << je[2]));
+            } else {              // planes a, b
+                *(int2*)&sA[0][r][q * 2] = make_int2(pk2(ar4[0] << je[0], ar4[1] << je[0]), pk2(ar4[2] << je[0], ar4[3] << je[0]));
+                *(int2*)&sA[1][r][q * 2] = make_int2(pk2(ai4[0] << je[1], ai4[1] << je[1]), pk2(ai4[2] << je[1], ai4[3] << je[1]));
+            }
+        }
+        // stage B: 16 column pairs x 32 k of both parts, threads 0..127
+        if (tid < 128) {
+            const int p = tid >> 3, q = tid & 7;
+            int4 y[2][2];   // [column of the pair][part]
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int part = 0; part < 2; ++part) {
+                    y[c][part] = make_int4(0, 0, 0, 0);
+                    if (n0 + p + 16 * c < g.N) y[c][part] = *(const int4*)(g.B + ((int64_t)part * g.N + n0 + p + 16 * c) * g.K + k0 + q * 4);
+                }
+            int br[2][4], bi[2][4];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                br[c][0] = y[c][0].x; br[c][1] = y[c][0].y; br[c][2] = y[c][0].z; br[c][3] = y[c][0].w;
+                bi[c][0] = y[c][1].x; bi[c][1] = y[c][1].y; bi[c][2] = y[c][1].z; bi[c][3] = y[c][1].w;
+            }
+            if constexpr (TF) {   // planes c, (c+d), d
+                int cd[2][4];
+                op_addsub<2, 4>(cd[0], br[0], bi[0], tab, QG_T_CD, false);
+                op_addsub<2, 4>(cd[1], br[1], bi[1], tab, QG_T_CD, false);
+                *(int4*)&sB[0][p][q * 4] = make_int4(pk2(br[0][0] << je[3], br[1][0] << je[3]), pk2(br[0][1] << je[3], br[1][1] << je[3]),
+                                                     pk2(br[0][2] << je[3], br[1][2] << je[3]), pk2(br[0][3] << je[3], br[1][3] << je[3]));
+                *(int4*)&sB[1][p][q * 4] = make_int4(pk2(cd[0][0] << je[4], cd[1][0] << je[4]), pk2(cd[0][1] << je[4], cd[1][1] << je[4]),
+                                                     pk2(cd[0][2] << je[4], cd[1][2] << je[4]), pk2(cd[0][3] << je[4], cd[1][3] << je[4]));
+                *(int4*)&sB[2][p][q * 4] = make_int4(pk2(bi[0][0] << je[5], bi[1][0] << je[5]), pk2(bi[0][1] << je[5], bi[1][1] << je[5]),
+                                                     pk2(bi[0][2] << je[5], bi[1][2] << je[5]), pk2(bi[0][3] << je[5], bi[1][3] << je[5]));
+            } else {              // planes c, d
+                *(int4*)&sB[0][p][q * 4] = make_int4(pk2(br[0][0] << je[2], br[1][0] << je[2]), pk2(br[0][1] << je[2], br[1][1] << je[2]),
+                                                     pk2(br[0][2] << je[2], br[1][2] << je[2]), pk2(br[0][3] << je[2], br[1][3] << je[2]));
+                *(int4*)&sB[1][p][q * 4] = make_int4(pk2(bi[0][0] << je[3], bi[1][0] << je[3]), pk2(bi[0][1] << je[3], bi[1][1] << je[3]),
+                                                     pk2(bi[0][2] << je[3], bi[1][2] << je[3]), pk2(bi[0][3] << je[3], bi[1][3] << je[3]));
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int kb = 0; kb < KC / 16; ++kb) {
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                int2 a2[NP][4];
+                int4 b4[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a2[p][i] = *(const int2*)&sA[p][ty * 4 + i][kb * 8 + kq * 2];
+                    b4[p] = *(const int4*)&sB[p][tx][kb * 16 + kq * 4];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kk = kq * 4 + e;
+                    int bv[NP];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) bv[p] = e == 0 ? b4[p].x : e == 1 ? b4[p].y : e == 2 ? b4[p].z : b4[p].w;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        int av[NP];
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) av[p] = e < 2 ? a2[p][i].x : a2[p][i].y;
+                        if constexpr (TF) {   // A = (a+b) c, B = (c+d) b, C = (b-a) d; re = A - B, im = B - C
+                            const int PA = ((e & 1) ? pk_mad_sat<1>(av[0], bv[0], t2[0]) : pk_mad_sat<0>(av[0], bv[0], t2[0])) & mask2;
+                            const int PB = ((e & 1) ? pk_mad_sat<1>(av[1], bv[1], t2[1]) : pk_mad_sat<0>(av[1], bv[1], t2[1])) & mask2;
+                            const int PC = ((e & 1) ? pk_mad_sat<1>(av[2], bv[2], t2[2]) : pk_mad_sat<0>(av[2], bv[2], t2[2])) & mask2;
+                            v[0][i] = pk_sub_sat(PA, PB);
+                            v[1][i] = pk_sub_sat(PB, PC);
+                        } else {              // re = ac - bd, im = ad + bc
+                            const int ac = ((e & 1) ? pk_mad_sat<1>(av[0], bv[0], t2[0]) : pk_mad_sat<0>(av[0], bv[0], t2[0])) & mask2;
+                            const int bd = ((e & 1) ? pk_mad_sat<1>(av[1], bv[1], t2[1]) : pk_mad_sat<0>(av[1], bv[1], t2[1])) & mask2;
+                            const int ad = ((e & 1) ? pk_mad_sat<1>(av[0], bv[1], t2[2]) : pk_mad_sat<0>(av[0], bv[1], t2[2])) & mask2;
+                            const int bc = ((e & 1) ? pk_mad_sat<1>(av[1], bv[0], t2[3]) : pk_mad_sat<0>(av[1], bv[0], t2[3])) & mask2;
+                            v[0][i] = pk_sub_sat(ac, bd);
+                            v[1][i] = pk_add_sat(ad, bc);
+                        }
+                    }
+                    bool parked_low = false;
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) {
+                        if (!parked_low) {
+                            if (((kk >> l) & 1) == 0) {
+#pragma unroll
+                                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                                    for (int o = 0; o < 4; ++o) low[p][l][o] = v[p][o];
+                                parked_low = true;
+                            } else {
+                                NODE16C(low[0][l], low[1][l], l);
+                            }
+                        }
+                    }
+                }
+            }
+            const unsigned idx = (unsigned)((k0 >> 4) + kb);
+            bool parked = false;
+#pragma unroll
+            for (int u = 0; u < MAXL - 4; ++u) {
+                if (!parked && 4 + u < nl) {
+                    if (((idx >> u) & 1u) == 0) {
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) up[p][u][o] = v[p][o];
+                        parked = true;
+                    } else {
+                        NODE16C(up[0][u], up[1][u], 4 + u);
+                    }
+                }
+            }
+        }
+    }
+#undef NODE16C
+    // the roots: floor(half / 2^s) of each half, then the conversion into C
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        int r8[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r8[i * 2 + 0] = ((int)((unsigned)v[p][i] << 16) >> 16) >> s16;
+            r8[i * 2 + 1] = (v[p][i] >> 16) >> s16;
+        }
+        qg_step_all<int, 8>(r8, tab->c_cvt[p]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int64_t m = m0 + ty * 4 + i, n = n0 + tx + 16 * j;
+                if (m < g.M && n < g.N) {
+                    const int64_t idx = ((int64_t)p * g.M + m) * g.N + n;
+                    const int r = r8[i * 2 + j];
+                    switch (g.cbytes) {
+                    case 1: ((int8_t*)g.C)[idx] = (int8_t)r; break;
+                    case 2: ((int16_t*)g.C)[idx] = (int16_t)r; break;
+                    case 4: ((int32_t*)g.C)[idx] = r; break;
+                    default: ((int64_t*)g.C)[idx] = (int64_t)r; break;
+                    }
+                }
+            }
+    }
+}
+
 } // namespace
 
 hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, int fixed, int tf, const void* A, const void* B, void* C, int64_t M,
@@ -561,12 +773,23 @@ hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, i
     case 1: QG_CPLX_LAUNCH(1); break;
     case 2: QG_CPLX_LAUNCH(2); break;
     case 3: QG_CPLX_LAUNCH(3); break;
+    case 6:     // ... in packed 16-bit halves
     case 5:     // ... on left-justified values
     case 4: {   // one clamp for the whole loop (qg_plan.cpp)
         static const bool no_uniform = QG_DIAG_ENV("QG_NO_UNIFORM_CLAMP");   // A/B switch (diagnostic library): the compact form such a descriptor had before
         static const bool no_lj = QG_DIAG_ENV("QG_NO_LEFT_JUSTIFIED");
+        static const bool no_pk = QG_DIAG_ENV("QG_NO_PACKED16");
         if (no_uniform) QG_CPLX_LAUNCH(2);
-        else if (fixed == 5 && !no_lj) QG_CPLX_LAUNCH(5);
+        else if (fixed == 6 && !no_lj && !no_pk) {
+            const int64_t blocks16 = ((M + TM16 - 1) / TM16) * ((N + TNB - 1) / TNB);
+            if (tf) {
+                if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx_pk16<12, true>), dim3((unsigned)blocks16), dim3(256), 0, st, g);
+                else hipLaunchKernelGGL((k_tree_cplx_pk16<16, true>), dim3((unsigned)blocks16), dim3(256), 0, st, g);
+            } else {
+                if (n_levels <= 12) hipLaunchKernelGGL((k_tree_cplx_pk16<12, false>), dim3((unsigned)blocks16), dim3(256), 0, st, g);
+                else hipLaunchKernelGGL((k_tree_cplx_pk16<16, false>), dim3((unsigned)blocks16), dim3(256), 0, st, g);
+            }
+        } else if (fixed >= 5 && !no_lj) QG_CPLX_LAUNCH(5);
         else QG_CPLX_LAUNCH(4);
         break;
     }

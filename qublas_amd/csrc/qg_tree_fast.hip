@@ -498,22 +498,6 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
 // tx + 16) pairs per k), + v_and; a node pair is one v_pk_add_i16 ... clamp, + v_and at the odd levels: 1.9 vector
 // instructions per MAC where MODE 6 spends 3.8 and the v_med3 form 5.3 (BASELINE configuration 2 as literally configured).
 constexpr int PKP = 18;   // dwords per sA16 row (16 + 2: 8-byte reads stay aligned)
-template <int HALF>
-__device__ __forceinline__ int pk_mad_sat(int a2, int b2, int t2)
-{
-    int r;
-    if (HALF == 0) asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] clamp" : "=v"(r) : "v"(a2), "v"(b2), "s"(t2));
-    else asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] clamp" : "=v"(r) : "v"(a2), "v"(b2), "s"(t2));
-    return r;
-}
-__device__ __forceinline__ int pk_add_sat(int a, int b)
-{
-    int r;
-    asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ int pk2(int lo, int hi) { return (int)(((unsigned)lo & 0xffffu) | ((unsigned)hi << 16)); }
-
 #define NODE16(X, L)                                                                                     \
     do {                                                                                                 \
         _Pragma("unroll") for (int o_ = 0; o_ < 4; ++o_) v[o_] = pk_add_sat(X[o_], v[o_]);               \
@@ -539,9 +523,9 @@ __global__ __launch_bounds__(256) void k_tree_pk16(QTreeFastArgs g)
     const int64_t gsz = (tiles_m - first_m) < GMT ? (tiles_m - first_m) : GMT;
     const int64_t m0 = (first_m + (bid % (GMT * tiles_n)) % gsz) * TMB, n0 = ((bid % (GMT * tiles_n)) / gsz) * TNB;
     const int nl = tab->n_levels_k;
-    const int s16 = tab->lj.e[2], ea = tab->lj.e[3], eb = tab->lj.e[4];
+    const int s16 = tab->lj16.s, ea = tab->lj16.e[0], eb = tab->lj16.e[1];
     const int m1 = (0xffff << s16) & 0xffff, mask2 = m1 | (m1 << 16);
-    const int t2 = pk2(tab->lj.t[1], tab->lj.t[1]);
+    const int t2 = pk2(tab->lj16.t[0], tab->lj16.t[0]);
 
     int low[4][4];
     int up[MAXL - 4][4];

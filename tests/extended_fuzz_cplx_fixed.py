@@ -69,6 +69,10 @@ def main():
         levels = [Qcomplex(rq(rng, rng.choice([10, 14, 18, 22])), rq(rng, rng.choice([10, 14, 18, 22]))) for _ in range(rng.choice([0, 0, 1, 1, 2]))]
         if rng.random() < 0.2:   # one format for every value of the k loop: the "one clamp for the whole loop" form, or just short of it
             u = rq(rng, rng.choice([6, 9, 10, 13, 16]))
+            if rng.random() < 0.5:   # narrow formats and operands: the packed 16-bit form needs the common format's bits + the products' shifts <= 16
+                u = rq(rng, rng.choice([5, 6, 7, 8, 9]))
+                ea = Qcomplex(rq(rng, rng.choice([3, 4, 5, 6])), rq(rng, rng.choice([3, 4, 5, 6])))
+                eb = ea if rng.random() < 0.5 else Qcomplex(rq(rng, rng.choice([3, 4, 5, 6])), rq(rng, rng.choice([3, 4, 5, 6])))
             v = u if rng.random() < 0.8 else rq(rng, 12)
             mul = TFComplexMul(abT=rtag(rng, ea.real), cdT=rtag(rng, eb.real), abcT=u, cdbT=u, badT=u, ABT=u, BCT=v)
             if rng.random() < 0.5:

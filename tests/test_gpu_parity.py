@@ -343,16 +343,17 @@ def test_complex_fixed_mode_step_forms(oracle):
     c5 = Qcomplex(P(6, 3), P(6, -3))
     cases = [
         # (elements, C, lowering keywords, expected form)
-        (c5, c5, dict(mul_args=TFComplexMul()), "fixed modes, one clamp, left-justified"),    # configuration 5 itself: every in-loop value is int<6,3>
-        (c5, Qcomplex(P(12, 4), P(10, 2)), dict(mul_args=TFComplexMul()), "fixed modes, one clamp, left-justified"),   # ... whatever C is
+        (c5, c5, dict(mul_args=TFComplexMul()), "fixed modes, one clamp, packed 16-bit"),    # configuration 5 itself: every in-loop value is int<6,3>
+        (c5, Qcomplex(P(12, 4), P(10, 2)), dict(mul_args=TFComplexMul()), "fixed modes, one clamp, packed 16-bit"),   # ... whatever C is
         (Qcomplex(P(5, 4), P(7, 2)), c5, dict(mul_args=TFComplexMul(abT=Tags(7, 2), cdT=Tags(5, 4), abcT=Tags(6, 3), cdbT=Tags(6, 3), badT=Tags(6, 3), ABT=Tags(6, 3), BCT=Tags(6, 3)),
                                                add_args=[Qcomplex(P(6, 3), P(6, 3))]),
-         "fixed modes, one clamp, left-justified"),                                            # products of different alignments into one format
+         "fixed modes, one clamp, packed 16-bit"),                                            # products of different alignments into one format
         (c5, c5, dict(mul_args=TFComplexMul(ABT=Tags(7, 3))), "fixed modes, compact"),           # one wider difference: not uniform
+        (Qcomplex(P(8, 4), P(8, 4)), c5, dict(mul_args=TFComplexMul()), "fixed modes, one clamp, left-justified"),   # 13 bits and a shift by 4: no room in 16-bit halves
         # SAT::SMGN everywhere: one range [-hi, hi], but not the range of a left-justified int32: v_med3 with the bounds in registers
         (Qcomplex(Qu(6, 3, True, RND.NEG_INF, SAT.SMGN), Qu(6, 3, True, RND.NEG_INF, SAT.SMGN)), c5, dict(mul_args=TFComplexMul()), "fixed modes, one clamp for the whole loop"),
         (Qcomplex(Qu(6, 3, True, RND.NEG_INF, SAT.SMGN), Qu(6, 3, True, RND.NEG_INF, SAT.SMGN)), c5, dict(mul_args=BasicComplexMul()), "fixed modes, one clamp for the whole loop"),
-        (Qcomplex(P(6, 3), P(6, 3)), c5, dict(mul_args=BasicComplexMul()), "fixed modes, one clamp, left-justified"),   # Basic with equal part formats
+        (Qcomplex(P(6, 3), P(6, 3)), c5, dict(mul_args=BasicComplexMul()), "fixed modes, one clamp, packed 16-bit"),   # Basic with equal part formats
         (Qcomplex(P(5, 4), P(7, 2)), c5, dict(mul_args=BasicComplexMul(acT=Tags(6, 9), bdT=Tags(6, 9), adT=Tags(6, 9), bcT=Tags(6, 9), acbdT=Tags(6, 9), adbcT=Tags(6, 9)),
                                                add_args=[Qcomplex(P(6, 9), P(6, 9))]),
          "fixed modes, one clamp, left-justified"),                                            # Basic: products shift left by 1, 5, 3, 3 bits: plane factors
@@ -363,7 +364,7 @@ def test_complex_fixed_mode_step_forms(oracle):
          "fixed modes, compact"),                                                                 # level 1 has MORE fraction bits than level 0: a node shifts left
         (c5, Qcomplex(P(12, 4), P(10, 2)), dict(mul_args=BasicComplexMul(acT=Tags(20, 8))), "fixed modes, table"),   # a 29-bit product format: beyond v_mad_i32_i24's operands
         # the reference's DEFAULT modes (TRN::TCPL / SAT::TCPL), RND::NEG_INF and SAT::SMGN are compact too
-        (Qcomplex(Qu(6, 3), Qu(6, -3)), Qcomplex(Qu(9, 3), Qu(9, 1)), dict(mul_args=TFComplexMul()), "fixed modes, one clamp, left-justified"),
+        (Qcomplex(Qu(6, 3), Qu(6, -3)), Qcomplex(Qu(9, 3), Qu(9, 1)), dict(mul_args=TFComplexMul()), "fixed modes, one clamp, packed 16-bit"),
         (Qcomplex(Qu(5, 4, True, RND.NEG_INF, SAT.SMGN), Qu(6, 2, True, RND.NEG_INF, SAT.SMGN)), Qcomplex(Qu(8, 2, True, RND.NEG_INF, SAT.SMGN), Qu(8, 2, True, TRN.TCPL, SAT.TCPL)),
          dict(mul_args=BasicComplexMul(), add_args=[Qcomplex(Qu(12, 3, True, RND.NEG_INF, SAT.SMGN), Qu(12, 1, True, RND.NEG_INF, SAT.SMGN))]), "fixed modes, compact"),
         # value-dependent roundings (RND::ZERO / INF / CONV, TRN::SMGN) and SAT::ZERO / WRP::TCPL: rounding / overflow kinds of the compact form,

@@ -3,6 +3,7 @@
 per-step-record form the same descriptors had before, at BASELINE configuration 5 (2048^3 Qcomplex<int<6,3>, int<6,-3>>
 RND::POS_INF + SAT::TCPL, TFComplexMul) and with the reference's default modes.  Run with the diagnostic library:
     QUBLAS_AMD_DIAG=1 python tools/measure_cplx_uniform.py                       # the new form
+    QUBLAS_AMD_DIAG=1 QG_NO_PACKED16=1 python tools/measure_cplx_uniform.py        # 32-bit left-justified values instead of packed 16-bit halves
     QUBLAS_AMD_DIAG=1 QG_NO_LEFT_JUSTIFIED=1 python tools/measure_cplx_uniform.py  # v_med3 with the bounds in registers instead of saturating instructions
     QUBLAS_AMD_DIAG=1 QG_NO_UNIFORM_CLAMP=1 python tools/measure_cplx_uniform.py   # the compact per-step-record form
 One JSON line per case."""
@@ -34,7 +35,7 @@ def main():
             plan.fill(capi.OPERAND_B, 2, 0, pB)
             plan.time_execute(pC, pA, pB, 2, 5)
             ms = [plan.time_execute(pC, pA, pB, 1, 5) for _ in range(3)]
-            print(json.dumps({"case": name, "switches": [k for k in ("QG_NO_UNIFORM_CLAMP", "QG_NO_LEFT_JUSTIFIED") if os.environ.get(k)], "steps": plan.info.reason.decode().split("steps: ")[-1],
+            print(json.dumps({"case": name, "switches": [k for k in ("QG_NO_UNIFORM_CLAMP", "QG_NO_LEFT_JUSTIFIED", "QG_NO_PACKED16") if os.environ.get(k)], "steps": plan.info.reason.decode().split("steps: ")[-1],
                               "ms": [round(m, 4) for m in ms]}), flush=True)
             for p in (pA, pB, pC):
                 ctx.free(p)
