@@ -439,6 +439,7 @@ def c4_leg(args, ctx, wls, capi, net, world, rank):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (this pool's driver: dmabuf IPC only — RCCL's peer mappings need it)
     env_world = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and env_world is None:
         sys.exit(launch_ranks(args, argv))
@@ -456,7 +457,16 @@ def main(argv=None):
         local = 0                       # rehearsal: the ranks share the first card
     use_dist = world > 1 or args.force_dist
     ctx = capi.Context(local)           # (fails with QG_EINVAL when there is no such device: one rank per GPU)
-    net = make_transport(ctx, args.backend) if use_dist else None
+    net, backend_note = None, None
+    if use_dist:
+        try:
+            net = make_transport(ctx, args.backend)
+        except Exception as e:   # e.g. no loadable librccl on this node: say so in the line and move the bands through host memory instead
+            if args.backend != "rccl" or world == 1:
+                raise
+            backend_note = f"rccl unavailable on this node ({type(e).__name__}: {e}); the gather went through host memory + TCP (backend host)"
+            print(f"[bench rank {rank}] {backend_note}", file=sys.stderr, flush=True)
+            net = make_transport(ctx, "host")
 
     wls = workloads()
     S = args.size
@@ -544,6 +554,8 @@ def main(argv=None):
             out["gather_bytes_per_step_per_rank"] = cbytes
             out["rccl_world_size"] = net.reported_world()    # rccl: ncclCommCount of the library's communicator
             out["backend"] = net.name
+            if backend_note:
+                out["backend_note"] = backend_note
             if net.name == "rccl":
                 out["rccl_version"] = net.comm.info()[2]
             ms_step = dt / args.steps * 1e3

@@ -157,11 +157,7 @@ def share_comm_id(rank: int, world: int, make_id: Callable[[], bytes], channel: 
     if world == 1:
         return make_id()
     if os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True" and channel is None:
-        from datetime import timedelta
-
-        from torch.distributed import TCPStore
-        _, _, _, host, port = env_rendezvous()
-        store = TCPStore(host, port, world, False, timedelta(seconds=300))
+        store = _agent_store()
         key = "qugemm_rccl_id_" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
         if rank == 0:
             store.set(key, make_id())
@@ -228,12 +224,39 @@ class HostTransport:
         return self.world
 
 
+def _agent_store():
+    """torch.distributed.run's agent store (it owns MASTER_PORT; the workers are its clients), or None without that launcher"""
+    if os.environ.get("TORCHELASTIC_USE_AGENT_STORE") != "True":
+        return None
+    from datetime import timedelta
+
+    from torch.distributed import TCPStore
+    _, world, _, host, port = env_rendezvous()
+    return TCPStore(host, port, world, False, timedelta(seconds=300))
+
+
+def channel_from_env(rank: int, world: int, host: str, port: int) -> HostChannel:
+    """The TCP star of this job.  Under torch.distributed.run MASTER_PORT belongs to the agent: rank 0 then listens on a free port
+    of its own and tells the others through the agent's store."""
+    store = _agent_store() if world > 1 else None
+    if store is not None:
+        key = "qugemm_host_channel_" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+        if rank == 0:
+            probe = socket.socket()
+            probe.bind((host, 0))
+            free = probe.getsockname()[1]
+            probe.close()
+            store.set(key, str(free))
+        port = int(bytes(store.get(key)).decode())
+    return HostChannel(rank, world, host, port)
+
+
 def make_transport(ctx, backend: str = "rccl", channel: Optional[HostChannel] = None):
     """The transport of this rank from the launcher's environment.  backend "rccl" (product) or "host" (rehearsal)."""
     from . import capi
     rank, world, _, host, port = env_rendezvous()
     if backend == "host":
-        return HostTransport(ctx, channel or HostChannel(rank, world, host, port))
+        return HostTransport(ctx, channel or channel_from_env(rank, world, host, port))
     if backend != "rccl":
         raise ValueError(f"unknown backend {backend!r}: rccl | host")
     ch = channel

@@ -46,6 +46,24 @@ def test_self_launcher_two_ranks_host_transport():
     assert c4["value_one_gather"] > 0 and c4["chunks"] >= 2 and c4["value_chunked_gather"] > 0
 
 
+def test_two_ranks_under_torch_distributed_run_as_the_driver_launches_them():
+    """The driver's N > 1 command line: torch.distributed.run starts the ranks, its agent owns MASTER_PORT (the workers are clients
+    of its TCPStore), rank 0 prints the line.  The RCCL id / the host channel's port travel through that store (qublas_amd/dist.py)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "host", "--steps", "3",
+                        "--warmup", "1", "--prewarm", "10", "--no-cpu", "--no-extra"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["backend"] == "host" and j["rccl_world_size"] == 2 and j["value"] > 1e12
+    assert j["gather_bytes_per_step_per_rank"] == 4096 * 4096 * 4
+
+
 def test_self_launcher_three_ranks_ragged_partition():
     """16384 rows over 3 ranks: 64 blocks of 256 rows do not divide — bands of 22 / 21 / 21 blocks; the gather pads to the largest."""
     j = run_bench("--gpus", "3", "--backend", "host", "--steps", "3", "--warmup", "1", "--prewarm", "10", "--no-cpu", "--c4-steps", "2")
