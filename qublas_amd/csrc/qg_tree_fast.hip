@@ -531,23 +531,39 @@ __global__ __launch_bounds__(256) void k_tree_pk16(QTreeFastArgs g)
     int up[MAXL - 4][4];
     int v[4] = {0, 0, 0, 0};
 
+    // the next k-chunk's operands travel in registers while the current one is computed: a small problem (configuration 2: two
+    // workgroups per CU) has no other waves to cover the load latency with
+    int4 ra[2], rb[2];
+    auto fetch = [&](int64_t k0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ch = tid + 256 * c, r = ch >> 3, q = ch & 7;
+            ra[c] = make_int4(0, 0, 0, 0);
+            if (m0 + r < g.M) ra[c] = *(const int4*)(g.A + (m0 + r) * g.K + k0 + q * 4);
+        }
+        rb[0] = rb[1] = make_int4(0, 0, 0, 0);
+        if (tid < 128) {
+            const int p = tid >> 3, q = tid & 7;
+            if (n0 + p < g.N) rb[0] = *(const int4*)(g.B + (n0 + p) * g.K + k0 + q * 4);
+            if (n0 + p + 16 < g.N) rb[1] = *(const int4*)(g.B + (n0 + p + 16) * g.K + k0 + q * 4);
+        }
+    };
+    fetch(0);
     for (int64_t k0 = 0; k0 < g.K; k0 += KC) {
         __syncthreads();
         // stage A: 64 rows x 32 k, 2 chunks of 4 k per thread, as 16-bit values; B: 16 column pairs x 32 k, threads 0..127
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int ch = tid + 256 * c, r = ch >> 3, q = ch & 7;
-            int4 x = make_int4(0, 0, 0, 0);
-            if (m0 + r < g.M) x = *(const int4*)(g.A + (m0 + r) * g.K + k0 + q * 4);
+            const int4 x = ra[c];
             *(int2*)&sA[r][q * 2] = make_int2(pk2(x.x << ea, x.y << ea), pk2(x.z << ea, x.w << ea));
         }
         if (tid < 128) {
             const int p = tid >> 3, q = tid & 7;
-            int4 x = make_int4(0, 0, 0, 0), y = make_int4(0, 0, 0, 0);
-            if (n0 + p < g.N) x = *(const int4*)(g.B + (n0 + p) * g.K + k0 + q * 4);
-            if (n0 + p + 16 < g.N) y = *(const int4*)(g.B + (n0 + p + 16) * g.K + k0 + q * 4);
+            const int4 x = rb[0], y = rb[1];
             *(int4*)&sB[p][q * 4] = make_int4(pk2(x.x << eb, y.x << eb), pk2(x.y << eb, y.y << eb), pk2(x.z << eb, y.z << eb), pk2(x.w << eb, y.w << eb));
         }
+        if (k0 + KC < g.K) fetch(k0 + KC);
         __syncthreads();
 #pragma unroll 1
         for (int kb = 0; kb < KC / 16; ++kb) {
