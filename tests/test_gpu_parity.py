@@ -334,6 +334,29 @@ def test_real_tree_kernel_step_forms(oracle):
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("K", [1, 2, 3, 5, 16, 17, 31, 32, 33, 100, 1000])
+def test_justified_forms_edge_shapes(oracle, K):
+    """The left-justified and packed 16-bit forms (real and complex) on the shapes the fuzzers do not draw: K below one k-chunk and
+    below two leaves (trees of 0 ... 10 levels, padded to 32 leaves), single rows and columns, a second column of the lane's pair
+    that does not exist (N = 17: column 16 alone in its pair), both distributions (dist 1 saturates most nodes)."""
+    P = lambda i, f: Qu(i, f, True, RND.POS_INF, SAT.TCPL)
+    c5 = Qcomplex(P(6, 3), P(6, -3))
+    cases = [(Qu(4, 3), Qu(4, 3), {}, "tree_i32", "packed 16-bit"),
+             (Qu(8, 8), Qu(8, 8), {}, "tree_i32", "left-justified"),
+             (c5, c5, dict(mul_args=TFComplexMul()), "tree_cplx_i32", "packed 16-bit"),
+             (Qcomplex(P(6, 3), P(6, 3)), c5, dict(mul_args=BasicComplexMul()), "tree_cplx_i32", "packed 16-bit"),
+             (Qcomplex(P(8, 4), P(8, 4)), c5, dict(mul_args=TFComplexMul()), "tree_cplx_i32", "left-justified")]
+    for e, ec, kw, kernel, form in cases:
+        for M, N in ((1, 1), (1, 17), (33, 1), (65, 17), (4, 48)):
+            if N == 1 and kernel == "tree_i32":
+                continue                                   # (one column: the gemv kernel's shapes, tests/test_gpu_gemv.py)
+            d = lower(e, e, ec, M, N, K, **kw)
+            info = capi.classify(d)
+            assert capi.KERNEL_NAMES[info.kernel] == kernel and info.reason.decode().endswith(form), (M, N, K, info.reason)
+            for dist in (0, 1):
+                _vs_oracle(oracle, e, e, ec, M, N, K, dist=dist, **kw)
+
+
 def test_complex_fixed_mode_step_forms(oracle):
     """RND::POS_INF + SAT::TCPL everywhere (BASELINE configuration 5's modes): the complex kernel runs its steps in the
     compact branch-free form (one scalar load per step, alignment and exact left shifts folded into 24-bit multiply-adds,
