@@ -1143,7 +1143,9 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
                               pcg.cbytes, st));
         return QG_OK;
     case QG_KERNEL_TREE_CPLX_I32:
-        QG_HIP(qg_launch_tree_cplx_fast(p->dev_table, p->an.tree.n_levels_k, (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : p->an.cplx_fixed_ok,
+        // (the justified forms carry, in the second byte, the form the descriptor has without them: the diagnostic library's A/B switches)
+        QG_HIP(qg_launch_tree_cplx_fast(p->dev_table, p->an.tree.n_levels_k,
+                                        (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : p->an.cplx_fixed_ok >= 5 ? (p->an.cplx_fixed_ok | p->an.cplx_fixed_base << 8) : p->an.cplx_fixed_ok,
                                         p->desc.cmul == QG_CMUL_TF ? 1 : 0, packedA, packedB, packedC, p->desc.M, p->desc.N,
                                         p->pa.K_p, pcg.cbytes, st));
         return QG_OK;

@@ -958,11 +958,38 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                     }
                 }
                 if (uni) out->cplx_fixed_ok = 4;
+                // The justified forms below also take products with FEWER fraction bits than the common format but the same integer
+                // bits (BasicComplexMul on Qcomplex<int<6,3>, int<6,-3>>: b d lives in int<6,-3>, RE = ac - 64 bd): left-justified, such
+                // a product's range ends where the common range does, its alignment factor in RE / IM is implicit, and only its mask
+                // (which floors to ITS unit) differs.  g[i] = log2 of that factor.
+                int gfac[4] = {0, 0, 0, 0};
+                bool ru = r0.lo > INT32_MIN && r0.hi < INT32_MAX;
+                {
+                    auto lg2 = [](int32_t k) { int n = 0; while (n < 31 && ((int32_t)1 << n) < k) ++n; return ((int32_t)1 << n) == k ? n : -1; };
+                    const QFix &fr = T.fmul[re], &fi = T.fmul[im];
+                    // the factor each product is aligned with: TF re = A - B, im = B - C; Basic re = ac - bd, im = ad + bc
+                    const int32_t kf[4] = {fr.ka, fr.kb, tf ? fi.kb : fi.ka, tf ? 0 : fi.kb};
+                    if (tf) ru = ru && fi.ka == fr.kb;   // (B enters both with one factor)
+                    for (size_t i = 0; i < prods.size() && ru; ++i) {
+                        const QFix& f = T.fmul[prods[i]];
+                        gfac[i] = lg2(kf[i]);
+                        ru = gfac[i] >= 0 && gfac[i] <= 16 && f.d >= 0 && f.ka >= 1 && f.lo > INT32_MIN && f.hi < INT32_MAX &&
+                             (int64_t)f.lo * kf[i] == r0.lo && ((int64_t)f.hi + 1) * kf[i] == (int64_t)r0.hi + 1;
+                    }
+                    for (const QFix* f : {&fr, &fi}) ru = ru && same_clamp(*f) && f->t == 0 && f->d == 0;
+                    for (int p = 0; p < 2 && ru; ++p)
+                        for (uint32_t l = 0; l < (uint32_t)T.n_levels_k && ru; ++l) {
+                            const QFix &fa = T.fadd[p][l], &fc = T.fcvt[p][l];
+                            const bool ident = (int)l >= T.n_levels && T.level_add[p][l].q.identity != 0;
+                            ru = (fc.skip & 1) && (ident || (same_clamp(fa) && fa.t == 0 && fa.d == 0 && fa.ls == 0));
+                        }
+                }
+                out->cplx_fixed_base = uni ? 4 : 2;
                 // 5: ... and that one range is a signed SAT::TCPL format: left-justified values (qg_fix.h).  The planes are staged with the
                 // left shifts that justify each product exactly (x y 2^(s + ls - d), the addend scaled alike), so a product is one
                 // saturating multiply-add + v_and, RE / IM one saturating add / subtract, a node one saturating add (+ v_and at the
                 // even levels): 12.5 instead of 18 vector instructions per complex MAC (TF).
-                if (uni && r0.lo == -r0.hi - 1 && ((r0.hi + 1) & r0.hi) == 0 && r0.hi > 0) {
+                if (ru && r0.lo == -r0.hi - 1 && ((r0.hi + 1) & r0.hi) == 0 && r0.hi > 0) {
                     int Wt = 1;
                     while (((int64_t)1 << (Wt - 1)) <= r0.hi) ++Wt;
                     auto lg = [](int32_t k) { int n = 0; while ((1 << n) < k) ++n; return n; };
@@ -976,9 +1003,10 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                         int E[4] = {0, 0, 0, 0};
                         for (size_t i = 0; i < prods.size() && lj; ++i) {
                             const QFix& f = T.fmul[prods[i]];
-                            E[i] = sj + lg(f.ka) - f.d;
-                            lj = E[i] >= 0 && (f.d == 0 || sj - f.d >= 0);
-                            if (lj) J->t[i] = f.d ? (int32_t)((uint32_t)f.t << (sj - f.d)) : 0;
+                            E[i] = sj + gfac[i] + lg(f.ka) - f.d;
+                            lj = E[i] >= 0 && (f.d == 0 || sj + gfac[i] - f.d >= 0);
+                            if (lj) J->t[i] = f.d ? (int32_t)((uint32_t)f.t << (sj + gfac[i] - f.d)) : 0;
+                            J->g[i] = gfac[i];
                         }
                         if (lj && tf) {
                             // products A = (a+b) c, B = (c+d) b, C = (b-a) d: every plane serves one product

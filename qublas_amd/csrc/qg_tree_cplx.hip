@@ -228,10 +228,12 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
     }
     // MODE 5: ... and that range is a signed SAT::TCPL format: LEFT-JUSTIFIED values (qg_fix.h, QTreeTable::lj) — the planes are
     // staged with the shifts that justify each product; the clamp bit of the multiply-add, the add and the subtract saturates
-    int j_s = 0, j_mask = -1, j_t[4] = {0, 0, 0, 0}, j_e[6] = {0, 0, 0, 0, 0, 0};
+    int j_s = 0, j_mask = -1, j_t[4] = {0, 0, 0, 0}, j_e[6] = {0, 0, 0, 0, 0, 0}, j_pm[4] = {-1, -1, -1, -1};   // j_pm: a product's own mask (QJustify::g)
     if constexpr (MODE == 5) {
         j_s = tab->lj.s;
         j_mask = (int)(~0u << j_s);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) j_pm[i] = (int)(~0u << (j_s + tab->lj.g[i]));
 #pragma unroll
         for (int i = 0; i < 4; ++i) j_t[i] = tab->lj.t[i];
 #pragma unroll
@@ -358,9 +360,9 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
                         if constexpr (MODE == 5) {
 #pragma unroll
                             for (int o = 0; o < 4; ++o) {
-                                PA[o] = sat_mad24_vvs(ab[o], yr[o], j_t[0]) & j_mask;
-                                PB[o] = sat_mad24_vvs(cd[o], xi[o], j_t[1]) & j_mask;
-                                PC[o] = sat_mad24_vvs(ba[o], yi[o], j_t[2]) & j_mask;
+                                PA[o] = sat_mad24_vvs(ab[o], yr[o], j_t[0]) & j_pm[0];
+                                PB[o] = sat_mad24_vvs(cd[o], xi[o], j_t[1]) & j_pm[1];
+                                PC[o] = sat_mad24_vvs(ba[o], yi[o], j_t[2]) & j_pm[2];
                             }
 #pragma unroll
                             for (int o = 0; o < 4; ++o) { v[0][o] = sat_sub(PA[o], PB[o]); v[1][o] = sat_sub(PB[o], PC[o]); }   // (clean subtrahends)
@@ -405,10 +407,10 @@ __global__ __launch_bounds__(256, ((cplx_dense_waves<MODE, TF>) ? (MAXL == 12 ? 
                         if constexpr (MODE == 5) {
 #pragma unroll
                             for (int o = 0; o < 4; ++o) {
-                                ac[o] = sat_mad24_vvs(xr[o], yr[o], j_t[0]) & j_mask;
-                                bd[o] = sat_mad24_vvs(xi[o], yi[o], j_t[1]) & j_mask;
-                                ad[o] = sat_mad24_vvs(xr[o], yi[o], j_t[2]) & j_mask;
-                                bc[o] = sat_mad24_vvs(xi[o], yr[o], j_t[3]) & j_mask;
+                                ac[o] = sat_mad24_vvs(xr[o], yr[o], j_t[0]) & j_pm[0];
+                                bd[o] = sat_mad24_vvs(xi[o], yi[o], j_t[1]) & j_pm[1];
+                                ad[o] = sat_mad24_vvs(xr[o], yi[o], j_t[2]) & j_pm[2];
+                                bc[o] = sat_mad24_vvs(xi[o], yr[o], j_t[3]) & j_pm[3];
                             }
 #pragma unroll
                             for (int o = 0; o < 4; ++o) { v[0][o] = sat_sub(ac[o], bd[o]); v[1][o] = sat_add(ad[o], bc[o]); }
@@ -564,9 +566,13 @@ __global__ __launch_bounds__(256, 3) void k_tree_cplx_pk16(QTreeCplxArgs g)
     const int nl = tab->n_levels_k;
     const int s16 = tab->lj16.s;
     const int m1 = (0xffff << s16) & 0xffff, mask2 = m1 | (m1 << 16);
-    int t2[4], je[6];
+    int t2[4], je[6], pm2[4];   // pm2: a product's own mask (QJustify::g)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) t2[i] = pk2(tab->lj16.t[i], tab->lj16.t[i]);
+    for (int i = 0; i < 4; ++i) {
+        t2[i] = pk2(tab->lj16.t[i], tab->lj16.t[i]);
+        const int mi = (0xffff << (s16 + tab->lj16.g[i])) & 0xffff;
+        pm2[i] = mi | (mi << 16);
+    }
 #pragma unroll
     for (int i = 0; i < 6; ++i) je[i] = tab->lj16.e[i];
 
@@ -666,16 +672,16 @@ __global__ __launch_bounds__(256, 3) void k_tree_cplx_pk16(QTreeCplxArgs g)
 #pragma unroll
                         for (int p = 0; p < NP; ++p) av[p] = e < 2 ? a2[p][i].x : a2[p][i].y;
                         if constexpr (TF) {   // A = (a+b) c, B = (c+d) b, C = (b-a) d; re = A - B, im = B - C
-                            const int PA = ((e & 1) ? pk_mad_sat<1>(av[0], bv[0], t2[0]) : pk_mad_sat<0>(av[0], bv[0], t2[0])) & mask2;
-                            const int PB = ((e & 1) ? pk_mad_sat<1>(av[1], bv[1], t2[1]) : pk_mad_sat<0>(av[1], bv[1], t2[1])) & mask2;
-                            const int PC = ((e & 1) ? pk_mad_sat<1>(av[2], bv[2], t2[2]) : pk_mad_sat<0>(av[2], bv[2], t2[2])) & mask2;
+                            const int PA = ((e & 1) ? pk_mad_sat<1>(av[0], bv[0], t2[0]) : pk_mad_sat<0>(av[0], bv[0], t2[0])) & pm2[0];
+                            const int PB = ((e & 1) ? pk_mad_sat<1>(av[1], bv[1], t2[1]) : pk_mad_sat<0>(av[1], bv[1], t2[1])) & pm2[1];
+                            const int PC = ((e & 1) ? pk_mad_sat<1>(av[2], bv[2], t2[2]) : pk_mad_sat<0>(av[2], bv[2], t2[2])) & pm2[2];
                             v[0][i] = pk_sub_sat(PA, PB);
                             v[1][i] = pk_sub_sat(PB, PC);
                         } else {              // re = ac - bd, im = ad + bc
-                            const int ac = ((e & 1) ? pk_mad_sat<1>(av[0], bv[0], t2[0]) : pk_mad_sat<0>(av[0], bv[0], t2[0])) & mask2;
-                            const int bd = ((e & 1) ? pk_mad_sat<1>(av[1], bv[1], t2[1]) : pk_mad_sat<0>(av[1], bv[1], t2[1])) & mask2;
-                            const int ad = ((e & 1) ? pk_mad_sat<1>(av[0], bv[1], t2[2]) : pk_mad_sat<0>(av[0], bv[1], t2[2])) & mask2;
-                            const int bc = ((e & 1) ? pk_mad_sat<1>(av[1], bv[0], t2[3]) : pk_mad_sat<0>(av[1], bv[0], t2[3])) & mask2;
+                            const int ac = ((e & 1) ? pk_mad_sat<1>(av[0], bv[0], t2[0]) : pk_mad_sat<0>(av[0], bv[0], t2[0])) & pm2[0];
+                            const int bd = ((e & 1) ? pk_mad_sat<1>(av[1], bv[1], t2[1]) : pk_mad_sat<0>(av[1], bv[1], t2[1])) & pm2[1];
+                            const int ad = ((e & 1) ? pk_mad_sat<1>(av[0], bv[1], t2[2]) : pk_mad_sat<0>(av[0], bv[1], t2[2])) & pm2[2];
+                            const int bc = ((e & 1) ? pk_mad_sat<1>(av[1], bv[0], t2[3]) : pk_mad_sat<0>(av[1], bv[0], t2[3])) & pm2[3];
                             v[0][i] = pk_sub_sat(ac, bd);
                             v[1][i] = pk_add_sat(ad, bc);
                         }
@@ -768,6 +774,8 @@ hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, i
             else hipLaunchKernelGGL((k_tree_cplx<16, MODE, false>), dim3((unsigned)blocks), dim3(256), 0, st, g);                 \
         }                                                                                                                         \
     } while (0)
+    const int base = fixed >> 8;   // (forms 5 / 6: 4 when the strict one-clamp form holds as well, else 2)
+    fixed &= 255;
     switch (fixed) {
     case 0: QG_CPLX_LAUNCH(0); break;
     case 1: QG_CPLX_LAUNCH(1); break;
@@ -790,6 +798,7 @@ hipError_t qg_launch_tree_cplx_fast(const QTreeTable* dev_table, int n_levels, i
                 else hipLaunchKernelGGL((k_tree_cplx_pk16<16, false>), dim3((unsigned)blocks16), dim3(256), 0, st, g);
             }
         } else if (fixed >= 5 && !no_lj) QG_CPLX_LAUNCH(5);
+        else if (fixed >= 5 && base != 4) QG_CPLX_LAUNCH(2);
         else QG_CPLX_LAUNCH(4);
         break;
     }

@@ -75,8 +75,11 @@ def main():
                 eb = ea if rng.random() < 0.5 else Qcomplex(rq(rng, rng.choice([3, 4, 5, 6])), rq(rng, rng.choice([3, 4, 5, 6])))
             v = u if rng.random() < 0.8 else rq(rng, 12)
             mul = TFComplexMul(abT=rtag(rng, ea.real), cdT=rtag(rng, eb.real), abcT=u, cdbT=u, badT=u, ABT=u, BCT=v)
+            less = lambda: Qu(u.intBits, u.fracBits - rng.choice([0, 0, 1, 2, 6]), u.isSigned, u.QuMode, u.OfMode)   # same integer bits, fewer fraction bits: its own mask in the justified forms
+            if rng.random() < 0.3:
+                mul = TFComplexMul(abT=rtag(rng, ea.real), cdT=rtag(rng, eb.real), abcT=less(), cdbT=less(), badT=less(), ABT=u, BCT=v)
             if rng.random() < 0.5:
-                mul = BasicComplexMul(acT=u, bdT=u, adT=u, bcT=u, acbdT=u, adbcT=v)
+                mul = BasicComplexMul(acT=less(), bdT=less(), adT=less(), bcT=less(), acbdT=u, adbcT=v)
             levels = [Qcomplex(u, u) for _ in range(rng.choice([0, 1, 1, 2]))]
         ec = Qcomplex(rq(rng, rng.choice([7, 12, 18])), rq(rng, rng.choice([7, 12, 18])))
         M, N = rng.randint(1, 120), rng.randint(1, 120)

@@ -380,7 +380,9 @@ def test_complex_fixed_mode_step_forms(oracle):
         (Qcomplex(P(5, 4), P(7, 2)), c5, dict(mul_args=BasicComplexMul(acT=Tags(6, 9), bdT=Tags(6, 9), adT=Tags(6, 9), bcT=Tags(6, 9), acbdT=Tags(6, 9), adbcT=Tags(6, 9)),
                                                add_args=[Qcomplex(P(6, 9), P(6, 9))]),
          "fixed modes, one clamp, left-justified"),                                            # Basic: products shift left by 1, 5, 3, 3 bits: plane factors
-        (c5, c5, dict(mul_args=BasicComplexMul()), "fixed modes, compact"),
+        (c5, c5, dict(mul_args=BasicComplexMul()), "fixed modes, one clamp, packed 16-bit"),      # b d lives in int<6,-3>: same integer bits, its own mask
+        (Qcomplex(P(9, 4), P(9, -2)), c5, dict(mul_args=BasicComplexMul()), "fixed modes, one clamp, left-justified"),   # ... the same in 32-bit words
+        (Qcomplex(P(6, 3), P(5, 1)), c5, dict(mul_args=BasicComplexMul()), "fixed modes, compact"),  # different integer bits: per-step records
         (c5, Qcomplex(P(12, 4), P(10, 2)), dict(mul_args=TFComplexMul(abcT=Tags(9, 5), ABT=Tags(11, 2)), add_args=[Qcomplex(P(14, 0), P(12, -3))]),
          "fixed modes, compact"),                                                                 # tags, one level type (fewer fraction bits: rounding nodes)
         (c5, Qcomplex(P(12, 4), P(10, 2)), dict(mul_args=BasicComplexMul(), add_args=[Qcomplex(P(10, 2), P(10, 0)), Qcomplex(P(14, 5), P(12, 3))]),

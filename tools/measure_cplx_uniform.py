@@ -22,6 +22,7 @@ C5 = Qcomplex(P(6, 3), P(6, -3))
 CD = Qcomplex(Qu(6, 3), Qu(6, -3))
 CASES = [("configuration 5 (RND::POS_INF + SAT::TCPL), TFComplexMul", lower(C5, C5, C5, S, S, S, mul_args=TFComplexMul())),
          ("same widths, default modes, TFComplexMul", lower(CD, CD, CD, S, S, S, mul_args=TFComplexMul())),
+         ("configuration 5's formats, BasicComplexMul (b d in int<6,-3>: its own mask)", lower(C5, C5, C5, S, S, S, mul_args=BasicComplexMul())),
          ("Qcomplex<int<6,3>, int<6,3>> RND::POS_INF + SAT::TCPL, BasicComplexMul", lower(Qcomplex(P(6, 3), P(6, 3)), Qcomplex(P(6, 3), P(6, 3)), C5, S, S, S, mul_args=BasicComplexMul()))]
 
 
