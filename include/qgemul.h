@@ -115,7 +115,15 @@ typedef struct qfmt {
  * The Qreduce lowering of a signed SAT::SMGN element type names the element's SAT::TCPL twin as the leaf format (so that the
  * raw minimum -2^W, which Qu::fill() can produce, reaches the adders as it is); leaf and level 0 then differ in the descriptor
  * although they are one type in the reference, and this flag restores the identity copy.  Only odd K is affected. */
-enum { QG_DESC_LEFTOVER0_COPY = 1u };
+enum { QG_DESC_LEFTOVER0_COPY = 1u, QG_DESC_REFERENCE_ARTEFACTS = 2u };
+/* QG_DESC_REFERENCE_ARTEFACTS (opt-in; never set by the Qgemul lowerings themselves): reproduce, instead of refusing, a result of
+ * the reference that is an artefact of its implementation rather than of the arithmetic it documents.  One is covered: C of an
+ * UNSIGNED WRP::TCPL format with exactly 32 value bits.  The reference's mask for it is ArbiInt<32>::allOnes(), whose data is -1
+ * (QuBLAS.h:361-377), so `val & mask` (:2328-2331) masks nothing and the value lands in the 33-bit storage (an int64_t word)
+ * unwrapped: -7 -> -7, 2^33 + 5 -> 2^33 + 5 (tests/golden/ref_scalar_6).  With the flag such a C behaves as WRP::TCPL_SAT does
+ * (the value narrowed to the storage word, host-word containers); without it the descriptor is QG_EUNSUPPORTED when a value
+ * can leave the format.  The same format as a product / level type, and RND over a shift of exactly 32 or 64 bits (:361-377 via
+ * :2043-2160), stay refused with or without the flag. */
 
 typedef struct qgemul_desc {
     uint32_t abi;       /* QGEMUL_ABI_VERSION */

@@ -187,12 +187,21 @@ inline uint32_t& QgemulRunFlags()
     return flags;
 }
 inline void QgemulRelease() { qgemul_run_release(); }
+// Descriptor flags OR-ed into every lowered Qgemul of this translation unit.  QgemulDescFlags() |= QG_DESC_REFERENCE_ARTEFACTS asks
+// for the reference's own result where that is an implementation artefact the engine otherwise refuses (qgemul.h: C of an unsigned
+// WRP::TCPL format with exactly 32 value bits comes out unwrapped).
+inline uint8_t& QgemulDescFlags()
+{
+    static uint8_t flags = 0;
+    return flags;
+}
 
 // the README entry point: C = A' * B with per-product and per-tree-node quantisation
 template <typename... Tags, class TC, class TA, class TB>
 void Qgemul(TC& C, const TA& A, const TB& B)
 {
-    const qgemul_desc d = Qgemul_lower<Tags...>(C, A, B);
+    qgemul_desc d = Qgemul_lower<Tags...>(C, A, B);
+    d.flags |= QgemulDescFlags();
     qgemul_opts opts{};
     opts.device = -1;
     opts.flags = QgemulRunFlags();
@@ -318,7 +327,8 @@ void Qgemul(TD& D, const TA& A, const TB& B, const S0& s0, const Stages&... st)
 {
     using CT = typename qgemul_detail::pick_result<Tags...>::type;
     static_assert(!std::is_void_v<CT>, "Qgemul with element-wise operators needs QgemulResult<CT>");
-    const qgemul_desc d = Qgemul_lower_types<Tags...>(std::type_identity<Qu_s<typename TD::size, CT>>{}, std::type_identity<TA>{}, std::type_identity<TB>{});
+    qgemul_desc d = Qgemul_lower_types<Tags...>(std::type_identity<Qu_s<typename TD::size, CT>>{}, std::type_identity<TA>{}, std::type_identity<TB>{});
+    d.flags |= QgemulDescFlags();
     auto ptr = [](const auto& stage) -> const void* {
         // a scalar is one element as the tensors store them (ArbiInt<N>::data, QuBLAS.h:353; {real, imag} for a complex one, :2512-2513)
         if constexpr (std::remove_cvref_t<decltype(stage)>::scalar) return &stage.e;

@@ -352,6 +352,18 @@ int qoracle_gemm(const qgemul_desc* d, void* C, const void* A, const void* B, in
     int st = qo_check(d);
     if (st) return st;
     if (!C || !A || !B) return QG_EINVAL;
+    /* QG_DESC_REFERENCE_ARTEFACTS (include/qgemul.h): C of an unsigned WRP::TCPL format with exactly 32 value bits comes out of the
+       reference unwrapped (mask = ArbiInt<32>::allOnes() = -1, /root/reference/include/QuBLAS.h:361-377, :2328-2331;
+       tests/golden/ref_scalar_6) — the behaviour of its WRP::TCPL_SAT stub */
+    qgemul_desc with_artefacts;
+    if (d->flags & QG_DESC_REFERENCE_ARTEFACTS) {
+        with_artefacts = *d;
+        for (int p = 0; p < (d->is_complex ? 2 : 1); ++p) {
+            qfmt* f = &with_artefacts.c[p];
+            if (f->O == QG_WRP_TCPL && !f->S && (int)f->I + (int)f->F == 32) f->O = QG_WRP_TCPL_SAT;
+        }
+        d = &with_artefacts;
+    }
     if (row1 <= 0) row1 = d->M;
     if (col1 <= 0) col1 = d->N;
     if (row0 < 0 || row1 > d->M || col0 < 0 || col1 > d->N) return QG_EINVAL;

@@ -398,6 +398,17 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     Ctx c;
     c.out = out;
     if (!d || d->abi != QGEMUL_ABI_VERSION) { c.fail(QG_EINVAL, "null descriptor or ABI mismatch"); return; }
+    // QG_DESC_REFERENCE_ARTEFACTS: C of an unsigned WRP::TCPL format with exactly 32 value bits is stored unwrapped by the reference
+    // (include/qgemul.h) — which is what its WRP::TCPL_SAT stub does: analysed, and executed, as that
+    qgemul_desc with_artefacts;
+    if (d->flags & QG_DESC_REFERENCE_ARTEFACTS) {
+        with_artefacts = *d;
+        for (int p = 0; p < (d->is_complex ? 2 : 1); ++p) {
+            qfmt& f = with_artefacts.c[p];
+            if (f.O == QG_WRP_TCPL && !f.S && (int)f.I + (int)f.F == 32) f.O = QG_WRP_TCPL_SAT;
+        }
+        d = &with_artefacts;
+    }
     if (d->M < 0 || d->N < 0 || d->K < 1) { c.fail(QG_EINVAL, "bad M/N/K"); return; }
     if (d->M > (1ll << 31) || d->N > (1ll << 31) || d->K > (1ll << 31)) { c.fail(QG_EUNSUPPORTED, "dimension beyond 2^31"); return; }
     {

@@ -43,6 +43,7 @@ OF_MODES = {"SAT::TCPL": 0, "SAT::ZERO": 1, "SAT::SMGN": 2, "WRP::TCPL": 3}
 
 CMUL_NONE, CMUL_BASIC, CMUL_TF = 0, 1, 2
 DESC_LEFTOVER0_COPY = 1   # qgemul_desc.flags (include/qgemul.h)
+DESC_REFERENCE_ARTEFACTS = 2   # opt-in: C of an unsigned WRP::TCPL format with exactly 32 value bits comes out unwrapped, as in the reference
 CLASS_LINEAR, CLASS_TREE = 1, 2
 
 
@@ -275,7 +276,7 @@ def n_levels_for(K: int) -> int:
 
 def lower(A: Elem, B: Elem, Cc: Elem, M: int, N: int, K: int, *,
           add_args: Optional[Sequence[Elem]] = None, mul_args: MulArgs = None,
-          transposed_a: bool = False) -> qgemul_desc:
+          transposed_a: bool = False, reference_artefacts: bool = False) -> qgemul_desc:
     """Lower one Qgemul<QgemulAddArgs<add_args…>, QgemulMulArgs<mul_args>, QgemulTransposedA<t>>
     call on element types (A, B, C) and runtime sizes to the C-ABI descriptor."""
     cx = isinstance(A, Qcomplex)
@@ -287,6 +288,7 @@ def lower(A: Elem, B: Elem, Cc: Elem, M: int, N: int, K: int, *,
     d.abi = QGEMUL_ABI_VERSION
     d.transA = int(bool(transposed_a))
     d.is_complex = int(cx)
+    d.flags = DESC_REFERENCE_ARTEFACTS if reference_artefacts else 0   # (opt-in, include/qgemul.h)
     d.M, d.N, d.K = M, N, K
     nl = n_levels_for(K)
     if nl > QG_MAX_LEVELS:

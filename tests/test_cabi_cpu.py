@@ -87,6 +87,25 @@ def test_classify_limbs_and_kernel():
     assert i.cls == CLASS_TREE
 
 
+def test_reference_artefacts_flag_is_opt_in():
+    """C of an unsigned WRP::TCPL format with exactly 32 value bits: refused where a value can leave the format (the reference's own
+    result there is an artefact of ArbiInt<32>::allOnes() = -1), reproduced with QG_DESC_REFERENCE_ARTEFACTS (host-word containers,
+    like WRP::TCPL_SAT); as a LEVEL type it stays refused either way; a C that cannot leave the format runs without the flag."""
+    from qublas_amd.desc import Tags, WRP, TRN
+    u32 = Qu(32, 0, False, TRN.TCPL, WRP.TCPL)
+    e = Qu(12, 4)
+    kw = dict(mul_args=Tags(25, 8), add_args=[Qu(40, 8)])
+    st, info = capi.classify_status(lower(e, e, u32, 64, 64, 64, **kw))
+    assert st == capi.QG_EUNSUPPORTED and b"allOnes" in info.reason
+    st, info = capi.classify_status(lower(e, e, u32, 64, 64, 64, reference_artefacts=True, **kw))
+    assert st == capi.QG_OK and info.host_elem_bytes[2] == 8, info.reason
+    st, info = capi.classify_status(lower(e, e, Qu(40, 8), 64, 64, 64, mul_args=Tags(25, 8), add_args=[u32], reference_artefacts=True))
+    assert st == capi.QG_EUNSUPPORTED
+    ue = Qu(4, 3, False)
+    st, info = capi.classify_status(lower(ue, ue, u32, 64, 64, 64, mul_args=Tags(9, 6, False), add_args=[Qu(20, 6, False)]))
+    assert st == capi.QG_OK, info.reason        # (non-negative sums below 2^32: nothing to wrap)
+
+
 def test_rejections():
     e = Qu(4, 3)
     # WRP::TCPL_SAT is a stub in the reference (QuBLAS.h:2336-2344: the value goes into the storage word unclamped).  As C's OfMode it

@@ -334,6 +334,34 @@ def test_real_tree_kernel_step_forms(oracle):
             assert np.array_equal(a, b)
 
 
+def test_reference_artefacts_flag_on_the_device(oracle):
+    """QG_DESC_REFERENCE_ARTEFACTS: C of an unsigned WRP::TCPL format with exactly 32 value bits holds the unwrapped value, as the
+    reference stores it (tests/golden/ref_scalar_6: the reference's own outputs) — as a K = 1 Qgemul on the device, and as a
+    GEMM with a real reduction against the oracle."""
+    import golden_io as G
+    from qublas_amd.desc import ONE
+    seen = 0
+    for t in G.scalar_tables(6):
+        src, dst = Qu.from_tuple(t["from"]), Qu.from_tuple(t["to"])
+        if dst.isSigned or dst.intBits + dst.fracBits != 32:
+            continue
+        xs = np.arange(t["lo"], t["hi"] + 1, t["step"], dtype=np.int64)
+        d = lower(src, ONE, dst, len(xs), 1, 1, mul_args=src, reference_artefacts=True)
+        got = run_gpu(d, xs.astype(oracle.host_dtype(src)), np.ones(1, np.int32), dst, oracle)
+        assert [int(v) for v in got] == t["y"], (t["from"], t["to"])
+        seen += 1
+    assert seen >= 3
+    u32 = Qu(32, 0, False, TRN.TCPL, WRP.TCPL)
+    e = Qu(12, 4)
+    for M, N, K in ((33, 17, 64), (128, 128, 300)):
+        d = lower(e, e, u32, M, N, K, mul_args=Tags(25, 8), add_args=[Qu(40, 8)], reference_artefacts=True)
+        A, B = oracle.fill(e, M * K, 5), oracle.fill(e, K * N, 6)
+        got = run_gpu(d, A, B, u32, oracle)
+        exp = oracle.gemm(d, A, B, u32, nthreads=8)
+        assert np.array_equal(got, exp) and (exp < 0).any()       # (negative sums stay negative: unwrapped)
+        assert capi.classify_status(lower(e, e, u32, M, N, K, mul_args=Tags(25, 8), add_args=[Qu(40, 8)]))[0] == capi.QG_EUNSUPPORTED
+
+
 @pytest.mark.parametrize("K", [1, 2, 3, 5, 16, 17, 31, 32, 33, 100, 1000])
 def test_justified_forms_edge_shapes(oracle, K):
     """The left-justified and packed 16-bit forms (real and complex) on the shapes the fuzzers do not draw: K below one k-chunk and

@@ -88,6 +88,36 @@ def test_wrap_into_32_bits_is_a_reference_artefact_only_for_unsigned(oracle):
     assert seen_artefact > 100 and seen_plain > 1000
 
 
+def test_reference_artefacts_flag_reproduces_the_unwrapped_32_bit_results(oracle):
+    """QG_DESC_REFERENCE_ARTEFACTS (include/qgemul.h): with the flag, C of an unsigned WRP::TCPL format with exactly 32 value bits
+    is what the reference stores — the value unwrapped (tests/golden/ref_scalar_6, produced by the reference).  Run as a K = 1
+    Qgemul (x * 1 in x's own format, then the conversion into C) through the oracle; the planner admits the descriptor with the
+    flag and refuses it without; every other table of the file is untouched by the flag."""
+    from qublas_amd import capi
+    from qublas_amd.desc import ONE, lower
+    import numpy as np
+    seen = other = 0
+    for t in G.scalar_tables(6):
+        src, dst = Qu.from_tuple(t["from"]), Qu.from_tuple(t["to"])
+        xs = np.arange(t["lo"], t["hi"] + 1, t["step"], dtype=np.int64)
+        artefact = (not dst.isSigned) and dst.intBits + dst.fracBits == 32
+        d = lower(src, ONE, dst, len(xs), 1, 1, mul_args=src, reference_artefacts=True)
+        st, _ = capi.classify_status(d)
+        if st != capi.QG_OK:
+            assert not artefact, (t["from"], t["to"])
+            continue
+        A = xs.astype(oracle.host_dtype(src))
+        got = oracle.gemm(d, A, np.ones(1, np.int32), dst)
+        assert [int(v) for v in got] == t["y"], (t["from"], t["to"])
+        if artefact:
+            st0, info0 = capi.classify_status(lower(src, ONE, dst, len(xs), 1, 1, mul_args=src))
+            assert st0 == capi.QG_EUNSUPPORTED or max(t["y"]) < 1 << 32, info0.reason
+            seen += 1
+        else:
+            other += 1
+    assert seen >= 3 and other >= 3
+
+
 def test_mul_add_truth_tables(oracle):
     L = oracle.lib()
     kinds = set()

@@ -6,7 +6,7 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from qublas_amd import capi
 from qublas_amd.desc import Qu, SAT, TRN, Tags, lower
 
