@@ -167,6 +167,9 @@ enum {
     QG_OPT_ARITHMETIC_CONV = 256u,
     /* qgemul_run: shard the rows of C over every gfx950 device this process can see (qgemul_run_sharded with all of them) */
     QG_OPT_ALL_DEVICES = 512u,
+    QG_OPT_BALANCED_LIMBS = 1024u, /* linear class: never store an operand CENTRED (x - c in balanced int8 limbs, the centre taken back out
+                                      with row sums in the epilogue: one limb fewer for signed formats of 16 / 24 / 32 bits and for
+                                      unsigned formats) — the plain balanced limbs of every round before; result-identical (tests) */
     QG_OPT_LOCKSTEP_TILES = 128u   /* large single-limb problems: the 64-byte-k-tile kernel whose waves run in lock step
                                     * (k_mfma16) instead of the two-group kernel on 128-byte k-tiles (k_mfma_pp) */
 };

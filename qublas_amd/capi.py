@@ -24,6 +24,7 @@ LIB_PATH = os.path.join(_HERE, "libqugemm_diag.so" if os.environ.get("QUBLAS_AMD
 QG_OK, QG_EINVAL, QG_EUNSUPPORTED, QG_EHIP, QG_ERCCL, QG_ERANGE, QG_ENOGPU = 0, -1, -2, -3, -4, -5, -6
 OPT_FORCE_TREE, OPT_CHECK_RANGE, OPT_GENERIC_TREE, OPT_RUNTIME_MODES, OPT_FUSED_EPILOGUE, OPT_UNFUSED_EPILOGUE = 1, 2, 4, 8, 16, 32
 OPT_GENERIC_LAYOUT, OPT_LOCKSTEP_TILES, OPT_ARITHMETIC_CONV, OPT_ALL_DEVICES = 64, 128, 256, 512
+OPT_BALANCED_LIMBS = 1024   # never centre an operand (x - c in balanced limbs): the plain balanced limbs, result-identical
 OPERAND_A, OPERAND_B, OPERAND_C = 0, 1, 2
 BITS_ASCII, BITS_PACKED = 0, 1
 KERNEL_NAMES = {0: "none", 1: "mfma_i8", 2: "mfma_i8_limb", 3: "tree_i32", 4: "tree_i64", 5: "tree_cplx", 6: "tree_cplx_i32", 7: "mfma_cplx", 8: "gemv_i32", 9: "gemv_i64", 10: "tree_i128"}

@@ -146,6 +146,10 @@ static QPackedGeom comp_sub_geom(const QComposite& q, const QPackedGeom& base, i
     int64_t o = (int64_t)c * q.chunk_bytes[which];
     for (int h = 0; h < g && h < ng; ++h) o += comp_sub_bytes(L[h], base.rows_p, K_p);
     if (off) *off = o;
+    if (base.offs) {   // centred operand: ONE row-sum array behind all sub-operands; the groups that hold digit 0 add their k-chunk to it
+        s.offs = L0[g] == 0 ? 2 : 3;
+        s.rowsum_off = base.rowsum_off - o;
+    }
     return s;
 }
 // groups of 2-3 limbs, low limbs first
@@ -206,6 +210,14 @@ static hipError_t comp_for_each_sub(const qgemul_plan* p, int operand, const QOp
     return hipSuccess;
 }
 
+// composite plan on a centred operand: its one row-sum array is zeroed before the sub-operands' packs add to it
+static hipError_t comp_zero_rowsums(const qgemul_plan* p, int operand, void* packed_dev)
+{
+    const QPackedGeom& base = operand == QG_OPERAND_A ? p->pa : p->pb;
+    if (!p->comp.on || !base.offs) return hipSuccess;
+    return hipMemsetAsync((char*)packed_dev + base.rowsum_off, 0, (size_t)base.rows_p * 8, p->ctx->stream);
+}
+
 // fill info + geometry for a descriptor; no GPU access
 static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qgemul_info* info, int* pLA, int* pLB, QMfmaCfg* pVar,
                          QPackedGeom* pa, QPackedGeom* pb, QCGeom* pc, QHostElem* ha, QHostElem* hb, QHostElem* hc,
@@ -250,6 +262,8 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     info->ops = !d->is_complex ? 2.0 * mnk : (d->cmul == QG_CMUL_TF ? 6.0 * mnk : 8.0 * mnk);
 
     int LA = 0, LB = 0, kernel = QG_KERNEL_NONE;
+    int64_t centreA = 0, centreB = 0;
+    bool centred = false;
     QMfmaCfg cfg = {0, 0, 0, 0};
     if (an->linear_ok && !(flags & QG_OPT_FORCE_TREE)) {
         LA = qg_limbs_for(d->a[0]);
@@ -259,9 +273,21 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
             if (la2 > LA) LA = la2;
             if (lb2 > LB) LB = lb2;
         }
+        // CENTRED operands (qg_plan.h: qg_limbs_centred; QPackedGeom::offs): x - c in balanced limbs where that saves a limb — signed
+        // formats of 16 / 24 / 32 bits (3 -> 2, 4 -> 3, 5 -> 4 limbs), unsigned formats (uint8: 2 -> 1) — the centre taken back out
+        // with row sums after the dot product.  Real descriptors only (stacked complex parts have different centres).
+        if (!d->is_complex && !(flags & QG_OPT_BALANCED_LIMBS)) {
+            int64_t c = 0;
+            int l = qg_limbs_centred(d->a[0], &c);
+            if (l < LA) { LA = l; centreA = c; centred = true; }
+            l = qg_limbs_centred(d->b[0], &c);
+            if (l < LB) { LB = l; centreB = c; centred = true; }
+        }
         const int mn = LA < LB ? LA : LB;
         cfg = qg_mfma_pick(LA, LB, d->M * parts, d->N * parts, (ep ? QG_OPT_LOCKSTEP_TILES : 0u) | flags);   // (the fused / unfused element-wise chain keeps the kernel it was measured on)
-        if (cfg.variant && (int64_t)mn * d->K <= (1ll << 17) - 1 && !an->wide && !an->generic_only)   // (wide plans: the kernels' own epilogues are 64-bit; the composite plan's combine pass is not)
+        // (wide plans: the kernels' own epilogues are 64-bit; the composite plan's combine pass is not.  Centred single-limb pairs: the
+        //  single-limb kernels' epilogue is 32-bit, sum a b of two uint8 operands is not: raw int32 slab + combine pass)
+        if (cfg.variant && (int64_t)mn * d->K <= (1ll << 17) - 1 && !an->wide && !an->generic_only && !(centred && LA == 1 && LB == 1))
             kernel = d->is_complex ? QG_KERNEL_MFMA_CPLX : ((LA == 1 && LB == 1) ? QG_KERNEL_MFMA_I8 : QG_KERNEL_MFMA_I8_LIMB);
         // (one output column whose tree the one-column kernels can walk: those stream A once at HBM rate; a composite plan would read
         // it once per limb group and write slabs — the batched Qreduce of 32-bit words with exact level types stays there)
@@ -274,6 +300,7 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
                      comp.wide ? "128-bit" : "64-bit");
         } else {
             LA = LB = 0;
+            centred = false;
             snprintf(info->reason, sizeof info->reason, "linear class, but limbs/K outside the MFMA kernels' range: tree kernel");
         }
     }
@@ -369,9 +396,18 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
             return QG_EUNSUPPORTED;
         }
     }
+    if (centred && kernel != QG_KERNEL_NONE) {   // both operands carry row sums (an uncentred partner: bias 0), behind everything else
+        pa->offs = pb->offs = 1;
+        pa->bias = -centreA;
+        pb->bias = -centreB;
+        pa->rowsum_off = round_up(info->packed_bytes[0], 256);
+        pb->rowsum_off = round_up(info->packed_bytes[1], 256);
+        info->packed_bytes[0] = pa->rowsum_off + pa->rows_p * 8;
+        info->packed_bytes[1] = pb->rowsum_off + pb->rows_p * 8;
+    }
     // Karatsuba (qg_mfma.hip, KARA): two-limb operands whose biased values fit 12 bits are stored as two unsigned base-64
     // digits each, and the product takes 3 MFMAs per k-step instead of 4
-    if (!comp.on) {
+    if (!comp.on && !centred) {
         static const bool no_kara = QG_DIAG_ENV("QG_NO_KARA");   // A/B switch
         auto ubits = [](qfmt f) { return (int)f.I + (int)f.F + (f.S ? 1 : 0); };
         // (problems small enough for the 64x64 tiles are latency-bound: measured 9.5 vs 8.9 us at 1024^3, schoolbook kept there)
@@ -781,6 +817,7 @@ int qgemul_pack(qgemul_plan* p, int operand, const void* src_dev, int64_t ld, vo
     const int check = (p->flags & QG_OPT_CHECK_RANGE) ? 1 : 0;
     if (check) QG_HIP(hipMemsetAsync(p->ctx->flag_dev, 0, 4, p->ctx->stream));
     if (p->comp.on) {
+        QG_HIP(comp_zero_rowsums(p, operand, packed_dev));
         QG_HIP(comp_for_each_sub(p, operand, g, [&](const QOperandGeom& sg, const QPackedGeom& sp, int64_t off) {
             return qg_launch_pack(sg, sp, src_dev, (char*)packed_dev + off, check, p->ctx->flag_dev, p->ctx->stream, (p->flags & QG_OPT_GENERIC_LAYOUT) ? 1 : 0);
         }));
@@ -809,6 +846,7 @@ int qgemul_pack_f64(qgemul_plan* p, int operand, const double* src_dev, int64_t 
     QOperandGeom g = operand_geom(p, operand, ld);
     const QPackedGeom& pg = operand == QG_OPERAND_A ? p->pa : p->pb;
     if (p->comp.on) {
+        QG_HIP(comp_zero_rowsums(p, operand, packed_dev));
         QG_HIP(comp_for_each_sub(p, operand, g, [&](const QOperandGeom& sg, const QPackedGeom& sp, int64_t off) {
             return qg_launch_pack_f64(sg, sp, src_dev, (char*)packed_dev + off, p->ctx->stream, (p->flags & QG_OPT_GENERIC_LAYOUT) ? 1 : 0);
         }));
@@ -825,6 +863,7 @@ int qgemul_fill_packed(qgemul_plan* p, int operand, uint64_t seed, int dist, voi
     QOperandGeom g = operand_geom(p, operand, 0);
     const QPackedGeom& pg = operand == QG_OPERAND_A ? p->pa : p->pb;
     if (p->comp.on) {
+        QG_HIP(comp_zero_rowsums(p, operand, packed_dev));
         QG_HIP(comp_for_each_sub(p, operand, g, [&](const QOperandGeom& sg, const QPackedGeom& sp, int64_t off) {
             return qg_launch_fill(sg, sp, seed, dist, (char*)packed_dev + off, p->ctx->stream);
         }));
@@ -1026,6 +1065,16 @@ static int execute_composite(qgemul_plan* p, void* packedC, const void* packedA,
         cb.cbytes = pcg.cbytes;
         cb.wide = q.wide;
         cb.to_c = p->an.lin.to_c[0];
+        if (p->pa.offs) {   // centred operands: the last chunk's pass takes the centres back out
+            cb.rsA = (const int64_t*)((const char*)packedA + p->pa.rowsum_off);
+            cb.rsB = (const int64_t*)((const char*)packedB + p->pb.rowsum_off);
+            cb.biasA = p->pa.bias;
+            cb.biasB = p->pb.bias;
+            cb.corr = p->desc.K;
+            cb.tm = pcg.tm;
+            cb.tn = pcg.tn;
+            cb.tiles_n = pcg.tn ? pcg.Np / pcg.tn : 1;
+        }
         QG_HIP(qg_launch_lin_combine(cb, st));
     }
     return QG_OK;
@@ -1055,6 +1104,13 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
 #ifdef QG_DIAG
         a.dbg = g_diag_stamps;
 #endif
+        if (p->pa.offs && !p->comp.on) {   // centred operands: the epilogue takes the centres back out (QPackedGeom::offs)
+            a.rsA = (const int64_t*)((const char*)packedA + p->pa.rowsum_off);
+            a.rsB = (const int64_t*)((const char*)packedB + p->pb.rowsum_off);
+            a.biasA = p->pa.bias;
+            a.biasB = p->pb.bias;
+            a.corr = (int64_t)((uint64_t)p->desc.K * (uint64_t)p->pa.bias * (uint64_t)p->pb.bias);
+        }
         if (p->pa.digit6) {
             a.kara = 1;
             a.rsA = (const int64_t*)((const char*)packedA + p->pa.rowsum_off);

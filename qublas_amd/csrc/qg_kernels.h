@@ -47,6 +47,12 @@ struct QPackedGeom {
     // limb layout: the planes hold digits limb0 .. limb0 + limbs - 1 of the balanced base-256 expansion (a limb GROUP of an
     // operand of more than 3 limbs, composite linear plans; 0 otherwise)
     int32_t limb0;
+    // CENTRED operands (offs != 0; qg_plan.h: qg_limbs_centred): the planes hold the balanced digits of x + bias (bias = -centre;
+    // padding holds 0) and int64 row_sum[rows_p] = sum_k (x + bias) sits at rowsum_off — sum a b = sum a'b' - biasB rsA[i]
+    // - biasA rsB[j] + K biasA biasB, taken back out by the MFMA kernels' epilogues / the composite plan's combine pass.
+    // offs 1: this packed operand owns its row sums (the pack zeroes and fills them); 2: a sub-operand of a composite plan adding
+    // its k-chunk to the operand's one array (zeroed by the caller; only the groups with limb0 == 0 add); 3: ... a group that does not
+    int32_t offs, pad_;
     int64_t bias, rowsum_off;
 };
 enum { QG_TRAILER_BYTES = 256, QG_MASK_WORDS = 64 };
@@ -116,6 +122,13 @@ struct QLinCombine {
     void* out;                     // packed C (cbytes containers), written when acc_out == nullptr
     int32_t cbytes, wide;
     QStep to_c;
+    // centred operands (QPackedGeom::offs): the correction of the last chunk, per element of the tiled packed-C index space
+    // (element i: tile i / (tm tn), column (i / tm) % tn, row i % tm of that tile; tiles_n tiles per tile row)
+    const int64_t* rsA;
+    const int64_t* rsB;
+    int64_t biasA, biasB, corr;   // corr: the reduction length K (K biasA biasB is formed in the accumulator's width)
+    int32_t tm, tn;
+    int64_t tiles_n;
 };
 hipError_t qg_launch_lin_combine(const QLinCombine& g, hipStream_t st);
 

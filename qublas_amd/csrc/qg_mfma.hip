@@ -330,6 +330,14 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_mfma(QMfmaArgs g)
                     for (int w = NW - 2; w >= 0; --w) x = x * 256 + (S)acc[w][i][j][e];
                     s[e] = x;
                 }
+                if constexpr (NW > 1) {
+                    if (g.rsA) {   // centred operands (QPackedGeom::offs): sum a b = sum a'b' - biasB rsA[row] - biasA rsB[col] + K biasA biasB (wrapping)
+                        const uint64_t cj = (uint64_t)g.corr - (uint64_t)g.biasA * (uint64_t)g.rsB[(int64_t)tile_n * TN + (wn * TJ + j) * 32 + fr];
+                        const int64_t* ra = g.rsA + (int64_t)tile_m * TM + (wm * TI + i) * 32 + 4 * fh;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) s[e] = (S)((uint64_t)s[e] + cj - (uint64_t)g.biasB * (uint64_t)ra[(e & 3) + 8 * (e >> 2)]);
+                    }
+                }
             }
             qg_step_all<S, 16>(s, st);
             if (ABL == 5 && s[0] != (S)0x7ead1234) continue; // diagnostic: keep the arithmetic, drop the stores
@@ -657,6 +665,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
                 S x = (S)acc[NW - 1][i][j][e];
 #pragma unroll
                 for (int w = NW - 2; w >= 0; --w) x = x * 256 + (S)acc[w][i][j][e];
+                if constexpr (NW > 1) {
+                    if (g.rsA)   // centred operands (QPackedGeom::offs; k_mfma): the centres go out with the row sums (wrapping arithmetic)
+                        x = (S)((uint64_t)x + (uint64_t)g.corr - (uint64_t)g.biasA * (uint64_t)g.rsB[(int64_t)tile_n * TN + (wn * TJ + j) * 16 + fr] -
+                                (uint64_t)g.biasB * (uint64_t)g.rsA[(int64_t)tile_m * TM + (wm * TI + i) * 16 + 4 * fq + e]);
+                }
                 s[j * 4 + e] = x;
             }
         qg_step_all<S, 4 * TJ>(s, st);

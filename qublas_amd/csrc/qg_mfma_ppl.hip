@@ -242,6 +242,9 @@ __device__ __forceinline__ void ppl_body(const QMfmaArgs& g)
                     int64_t x = (int64_t)acc[NW - 1][i][j][e];
 #pragma unroll
                     for (int w = NW - 2; w >= 0; --w) x = x * 256 + (int64_t)acc[w][i][j][e];
+                    if (g.rsA)   // centred operands (QPackedGeom::offs; k_mfma): the centres go out with the row sums (wrapping arithmetic)
+                        x = (int64_t)((uint64_t)x + (uint64_t)g.corr - (uint64_t)g.biasA * (uint64_t)g.rsB[(int64_t)tile_n * TN + wn * 32 + j * 16 + fr] -
+                                      (uint64_t)g.biasB * (uint64_t)g.rsA[(int64_t)tile_m * TM + wm * 64 + i * 16 + 4 * fq + e]);
                     s[j * 4 + e] = x;
                 }
             if constexpr (FAST) {

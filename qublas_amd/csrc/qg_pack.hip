@@ -7,6 +7,8 @@
 // (operands are packed once and stay resident), so they are written for coalescing, not more.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "qg_kernels.h"
 
 namespace {
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(256) void k_pack(QOperandGeom g, QPackedGeom p, con
                 if (check && (v < lo || v > hi)) bad = true;
             }
             if (p.digit6) v = (v + p.bias) & ((((int64_t)1) << (6 * p.limbs)) - 1);   // padding stays 0
+            else if (p.offs) v = (int64_t)((uint64_t)v + (uint64_t)p.bias);          // centred operand: x - centre (padding stays 0)
         }
         if (r_fast) tile[i][tx] = v;  // tile[k_local][r_local]
         else tile[tx][i] = v;         // tile[k_local][r_local] with tx = k_local
@@ -265,6 +268,18 @@ __global__ __launch_bounds__(256) void k_pack(QOperandGeom g, QPackedGeom p, con
         for (int i = ty; i < 64; i += 4) {
             const int64_t r = tr * 64 + i, k = tk * 64 + tx;
             int sum = (r < p.rows_p && k < p.K_p) ? (int)tile[tx][i] : 0;
+#pragma unroll
+            for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
+            if (tx == 0 && r < p.rows_p && sum)
+                atomicAdd((unsigned long long*)(dst + p.rowsum_off) + (int64_t)part * p.rows_p + r, (unsigned long long)sum);
+        }
+    }
+    if (p.offs == 1 || p.offs == 2) {
+        // row sums of the centred values (whole values, before a limb group is peeled off): the 64 lanes of a wave hold 64 k's of
+        // one row per step
+        for (int i = ty; i < 64; i += 4) {
+            const int64_t r = tr * 64 + i, k = tk * 64 + tx;
+            long long sum = (r < p.rows_p && k < p.K_p) ? (long long)tile[tx][i] : 0;
 #pragma unroll
             for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
             if (tx == 0 && r < p.rows_p && sum)
@@ -419,6 +434,11 @@ __global__ __launch_bounds__(256) void k_lin_combine(QLinCombine g)
     for (int j = 0; j < QG_MAX_SLABS; ++j)
         if (j < g.n_slabs) s += (AccT)(((const SlabT*)g.slab[j])[i]) * ((AccT)1 << g.sh[j]);
     if (g.acc_out) { ((AccT*)g.acc_out)[i] = s; return; }
+    if (g.rsA) {   // centred operands: sum a b = sum a'b' - biasB rsA[row] - biasA rsB[col] + K biasA biasB (wrapping: the sum itself fits)
+        const int64_t t = i / ((int64_t)g.tm * g.tn), row = (t / g.tiles_n) * g.tm + i % g.tm, col = (t % g.tiles_n) * g.tn + (i / g.tm) % g.tn;
+        using U = std::conditional_t<sizeof(AccT) == 16, qg_u128, uint64_t>;
+        s = (AccT)((U)s + (U)(AccT)g.corr * (U)(AccT)g.biasA * (U)(AccT)g.biasB - (U)(AccT)g.biasB * (U)(AccT)g.rsA[row] - (U)(AccT)g.biasA * (U)(AccT)g.rsB[col]);   // (corr: K)
+    }
     if constexpr (sizeof(AccT) == 16) {
         // wide plans: the reference's multi-word conversion (qg_step_w), containers of up to 16 bytes
         const qg_i128 r = qg_step_w(s, g.to_c);
@@ -510,6 +530,8 @@ hipError_t qg_launch_cplx_combine(const QCplxCombine& g, hipStream_t st)
 
 static hipError_t zero_trailer(const QPackedGeom& p, void* dst, hipStream_t st)
 {
+    if (p.offs == 1)   // centred operand: its row sums (anywhere behind the planes; sub-operands of composite plans: the caller's)
+        if (hipError_t e = hipMemsetAsync((char*)dst + p.rowsum_off, 0, (size_t)p.rows_p * 8, st); e != hipSuccess) return e;
     if (!p.trailer) return hipSuccess;
     const size_t bytes = QG_TRAILER_BYTES + (p.digit6 ? (size_t)p.rows_p * 8 : 0);   // (row sums sit right behind the trailer)
     return hipMemsetAsync((char*)dst + p.trailer, 0, bytes, st);
@@ -523,7 +545,7 @@ hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const voi
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
     if (hipError_t e = zero_trailer(p, dst, st); e != hipSuccess) return e;
     const bool no_fast = generic != 0;   // QG_OPT_GENERIC_LAYOUT: the any-format kernel (byte-identical; the equivalence test)
-    if (!no_fast && g.parts == 1 && g.elem_bytes == 4 && g.sb[0] == 4 && g.off[0] == 0 && p.limbs >= 1 && p.limbs <= 3 && !p.digit6 && (p.bk == 64 || p.bk == 128) &&
+    if (!no_fast && g.parts == 1 && g.elem_bytes == 4 && g.sb[0] == 4 && g.off[0] == 0 && p.limbs >= 1 && p.limbs <= 3 && !p.digit6 && !p.offs && (p.bk == 64 || p.bk == 128) &&
         p.tr % 64 == 0 && p.rows_p % p.tr == 0 && p.K_p % p.bk == 0 && g.W[0] <= 30 && ((uintptr_t)src & 3) == 0 && ((uintptr_t)dst & 15) == 0) {
         const int64_t nblk = (p.K_p / 64) * (p.rows_p / 64);
         const unsigned nb = (unsigned)(nblk < 2048 ? nblk : 2048);   // grid-stride beyond 8 workgroups per CU
@@ -544,7 +566,7 @@ hipError_t qg_launch_pack_f64(const QOperandGeom& g, const QPackedGeom& p, const
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
     if (hipError_t e = zero_trailer(p, dst, st); e != hipSuccess) return e;
-    if (!generic && g.parts == 1 && p.limbs >= 1 && p.limbs <= 3 && !p.digit6 && (p.bk == 64 || p.bk == 128) && p.tr % 64 == 0 && p.rows_p % p.tr == 0 &&
+    if (!generic && g.parts == 1 && p.limbs >= 1 && p.limbs <= 3 && !p.digit6 && !p.offs && (p.bk == 64 || p.bk == 128) && p.tr % 64 == 0 && p.rows_p % p.tr == 0 &&
         p.K_p % p.bk == 0 && g.W[0] <= 30 && ((uintptr_t)src & 7) == 0 && ((uintptr_t)dst & 15) == 0) {
         const int64_t nblk = (p.K_p / 64) * (p.rows_p / 64);
         const unsigned nb = (unsigned)(nblk < 2048 ? nblk : 2048);

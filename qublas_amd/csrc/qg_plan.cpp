@@ -390,6 +390,23 @@ int qg_limbs_for(qfmt f)
     return 9;
 }
 
+int qg_limbs_centred(qfmt f, int64_t* centre)
+{
+    const Rng r = fmt_range(f);
+    *centre = 0;
+    I128 S = 0;
+    for (int n = 1; n <= 7; ++n) {
+        S = S * 256 + 1;                                  // (256^n - 1) / 255
+        if (r.hi - r.lo <= 255 * S) {
+            const I128 c = r.lo + 128 * S;                // lo - c = -128 S, hi - c <= 127 S
+            if (c < -((I128)1 << 62) || c > ((I128)1 << 62)) return 9;
+            *centre = (int64_t)c;
+            return n;
+        }
+    }
+    return 9;
+}
+
 void qg_analyze(const qgemul_desc* d, QAnalysis* out)
 {
     memset(out, 0, sizeof *out);

@@ -122,3 +122,7 @@ QHostElem qg_host_elem(const qfmt f[2], int is_complex);
 
 // int8 limbs needed to hold every raw value of format f as balanced base-256 digits
 int qg_limbs_for(qfmt f);
+// ... of x - c for the centre c that needs the fewest (returned in *centre): an interval of width <= 256^L - 1 fits L balanced
+// digits once it is moved onto [-128 S, 127 S], S = (256^L - 1) / 255 — a signed format of exactly 8 L bits is one value too wide
+// for L plain balanced digits on the positive side, an unsigned format of w bits wastes a digit on its sign
+int qg_limbs_centred(qfmt f, int64_t* centre);

@@ -122,7 +122,10 @@ def test_limb_mfma_int88_vs_oracle(oracle, ta):
 
 def test_limb_mfma_mixed_widths(oracle):
     u44 = Qu(4, 4, False)
+    # (an unsigned 8-bit format takes two plain balanced limbs; centred — x - 128, tests/test_gpu_centred.py — one)
     _vs_oracle(oracle, u44, u44, Qu(14, 8, False), 128, 128, 256, mul_args=Tags(8, 8), add_args=[Qu(18, 8, False)],
+               expect_kernel="mfma_i8")
+    _vs_oracle(oracle, u44, u44, Qu(14, 8, False), 128, 128, 256, mul_args=Tags(8, 8), add_args=[Qu(18, 8, False)], flags=capi.OPT_BALANCED_LIMBS,
                expect_kernel="mfma_i8_limb")
     _vs_oracle(oracle, E88Z, E43, Qu(20, 11), 128, 192, 128, mul_args=Tags(13, 11), add_args=[Qu(22, 11)],
                expect_kernel="mfma_i8_limb")
