@@ -43,8 +43,8 @@ def shrink(M, N, K, budget):
 
 
 def linear_case(rng):
-    wa = rng.choice([7, 12, 15, 17, 22, 24, 25, 30, 31, 33, 40, 47, 55, 61])
-    wb = rng.choice([7, 7, 12, 16, 22, 24, 28, 31, 36, 45])
+    wa = rng.choice([7, 8, 12, 15, 16, 17, 22, 23, 24, 25, 30, 31, 32, 33, 39, 40, 47, 55, 61])   # (value bits; signed formats of 16 / 24 / 32 / 40 / 48 bits and unsigned ones are stored centred)
+    wb = rng.choice([7, 7, 8, 12, 15, 16, 22, 23, 24, 28, 31, 36, 45])
     if rng.random() < 0.5:
         wa, wb = wb, wa
     ea, eb = rand_fmt(rng, wa, modes=False), rand_fmt(rng, wb, modes=False)
@@ -137,6 +137,13 @@ def main():
             print(json.dumps({"mismatch": it, "kind": tag, "M": M, "N": N, "K": K, "ta": ta, "ld": [lda, ldb, ldc], "dist": dist,
                               "a": str(ea), "b": str(eb), "c": str(ec), "kw": str(kw), "reason": info.reason.decode()}), flush=True)
             sys.exit(1)
+        if kind == "linear" and rng.random() < 0.3:   # centred operands against the plain balanced limbs: the same bytes
+            bal = np.zeros_like(out)
+            bal.view(np.uint8)[:] = 0x5a
+            capi.run(d, bal, A, B, lda=lda, ldb=ldb, ldc=ldc, flags=capi.OPT_BALANCED_LIMBS)
+            if bal.tobytes() != out.tobytes():
+                print(json.dumps({"mismatch_vs_balanced_limbs": it, "kind": tag, "M": M, "N": N, "K": K, "a": str(ea), "b": str(eb), "c": str(ec)}), flush=True)
+                sys.exit(1)
         kinds[tag] = kinds.get(tag, 0) + 1
         ran += 1
     print(json.dumps({"wide_and_composite_run": ran, "refused_by_planner": refused, "kinds": kinds, "mismatches": 0}), flush=True)

@@ -78,8 +78,10 @@ def test_classify_limbs_and_kernel():
     assert (i.cls, i.limbs[0], i.limbs[1], i.kernel) == (CLASS_LINEAR, 1, 1, 1)
     i = capi.classify(desc_from_dict(by["e88z_L_4x4x4096_full"]))
     assert (i.cls, i.limbs[0], i.limbs[1], i.kernel) == (CLASS_LINEAR, 3, 3, 2)
+    i = capi.classify(desc_from_dict(by["u44_L_8x8x64_full"]), capi.OPT_BALANCED_LIMBS)
+    assert (i.cls, i.limbs[0], i.limbs[1], i.kernel) == (CLASS_LINEAR, 2, 2, 2)       # unsigned 8 bits: two plain balanced limbs ...
     i = capi.classify(desc_from_dict(by["u44_L_8x8x64_full"]))
-    assert (i.cls, i.limbs[0], i.limbs[1], i.kernel) == (CLASS_LINEAR, 2, 2, 2)
+    assert (i.cls, i.limbs[0], i.limbs[1], i.kernel) == (CLASS_LINEAR, 1, 1, 1)       # ... one when the operand is stored centred (x - 128)
     i = capi.classify(desc_from_dict(by["e88z_L_4x4x4096_full"]), capi.OPT_FORCE_TREE)
     assert i.kernel == 4
     # README example / configuration 1: per-product and per-node quantisation -> tree class

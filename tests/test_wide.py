@@ -160,7 +160,7 @@ def test_planner_verdicts_on_wide_descriptors():
     ok = lambda d: capi.classify_status(d)
     # the "accumulate Q15.16 exactly" call of VERDICT r2: linear class, composite MFMA plan with the 128-bit combine
     st, info = ok(lower(q, q, Qu(43, 32), 256, 256, 4096, mul_args=Tags(31, 32), add_args=[Qu(43, 32)]))
-    assert st == capi.QG_OK and capi.KERNEL_NAMES[info.kernel] == "mfma_i8_limb" and b"128-bit combine" in info.reason and list(info.limbs) == [5, 5]   # (a full-range 32-bit word needs five balanced base-256 digits: 127 * (256^4 - 1) / 255 < 2^31 - 1)
+    assert st == capi.QG_OK and capi.KERNEL_NAMES[info.kernel] == "mfma_i8_limb" and b"128-bit combine" in info.reason and list(info.limbs) == [4, 4]   # (a full-range 32-bit word needs five PLAIN balanced base-256 digits — 127 * (256^4 - 1) / 255 < 2^31 - 1 — and four once it is stored centred, x - 0x808080)
     assert info.host_elem_bytes[2] == 16 and info.packed_bytes[2] == 256 * 256 * 16
     # int<16,15> linear (What's missing 1)
     e = Qu(16, 15)
