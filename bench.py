@@ -18,8 +18,8 @@ oracle implements).
   extra.c4 (every N): BASELINE.json configs[3] — 16384 x 16384 x 4096 int<4,3>, linear class, STRONG scaling: rank r owns
       16384 / N rows (whole 256-row packed tiles), B replicated, packed 1-byte C, gathered to rank 0; reported without the
       gather, with one gather per step, and with the gather cut into row chunks that travel while later chunks compute.
-  extra.c3T / c3Td / c2L / c2T / c5TF / c5B / c5L / reduce / long_k (N = 1): the remaining BASELINE configurations and the
-      round's other paths, each with its own roofline block against its declared bound.
+  extra.c3T / c3Td / c2L / c2T / c5TF / c5B / c5L / reduce / long_k / w16 / u8 (N = 1): the remaining BASELINE configurations and
+      the round's other paths (w16, u8: 16-bit words and unsigned bytes, stored centred), each with its own roofline block against its declared bound.
 
 No PyTorch anywhere: device memory comes from the engine (qgemul_dev_alloc), the collective is the library's, timing uses HIP
 events on the engine's stream (qgemul_time_execute) and the host clock around synchronised regions.  (Under
@@ -62,7 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c3L", choices=["c3L", "c3T", "c3Td", "c2L", "c2T", "c4L", "c5TF", "c5B", "c5L", "reduce", "long_k"])
+    ap.add_argument("--workload", default="c3L", choices=["c3L", "c3T", "c3Td", "c2L", "c2T", "c4L", "c5TF", "c5B", "c5L", "reduce", "long_k", "w16", "u8"])
     ap.add_argument("--size", type=int, default=4096, help="M=N=K per GPU of the primary workload")
     ap.add_argument("--backend", default="rccl", help="transport of the gather for N > 1: rccl (the library's communicator) or host (rehearsal on a box with fewer GPUs than ranks: packed bands through host memory + TCP)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the collective path even with one rank (the RCCL calls on a 1-GPU box)")
@@ -147,6 +147,10 @@ def workloads():
         "c5L": dict(a=c5, b=c5, c=c5, mul=BasicComplexMul(acT=Qu(14, 6), bdT=Qu(14, -6), adT=Qu(14, 0), bcT=Qu(14, 0), acbdT=Qu(15, 6), adbcT=Qu(15, 0)),
                     add=[Qcomplex(Qu(30, 6), Qu(30, 0))], cfg="configs[4] operands, BasicComplexMul with exact sub-operation types (linear class)", ref=None,
                     text="2048^3 Qgemul Qcomplex<int<6,3>,int<6,-3>> BasicComplexMul, exact sub-op / level types: stacked 2x2 int8-limb MFMA + combine"),
+        "w16": dict(a=Qu(7, 8), b=Qu(7, 8), c=Qu(23, 8), mul=Tags(15, 16), add=[Qu(27, 16)], cfg="16-bit words (Q7.8), the size of configs[2]", ref=None,
+                    text="4096^3 Qgemul int<7,8> signed (16-bit words), linear class: operands stored centred (x - 128) in 2 x 2 int8 limbs instead of 3 x 3"),
+        "u8": dict(a=Qu(8, 0, False), b=Qu(8, 0, False), c=Qu(28, 0, False), mul=Tags(16, 0, False), add=[Qu(28, 0, False)], cfg="unsigned bytes, the size of configs[2]", ref=None,
+                   text="4096^3 Qgemul of unsigned 8-bit integers with exact sums, linear class: operands stored centred (x - 128) in ONE int8 limb + combine pass"),
         "long_k": dict(a=e88z, b=e88z, c=Qu(33, 16), mul=Tags(17, 16), add=[Qu(33, 16)], cfg="configs[2] operands, K = 65536 (beyond one MFMA launch's exact int32 range)", ref=None,
                        text="4096x4096x65536 Qgemul int<8,8> signed, linear class: 2 k-chunks on the 3x3 int8-limb MFMA kernel + exact combine pass"),
     }
@@ -154,7 +158,7 @@ def workloads():
 
 SHAPES = {"c3L": (4096, 4096, 4096), "c3T": (4096, 4096, 4096), "c3Td": (4096, 4096, 4096), "c2L": (1024, 1024, 1024), "c2T": (1024, 1024, 1024),
           "c4L": (16384, 16384, 4096), "c5TF": (2048, 2048, 2048), "c5B": (2048, 2048, 2048), "c5L": (2048, 2048, 2048), "reduce": (65536, 1, 4096),
-          "long_k": (4096, 4096, 65536)}
+          "long_k": (4096, 4096, 65536), "w16": (4096, 4096, 4096), "u8": (4096, 4096, 4096)}
 REDUCE_TEXT = "batched Qreduce: 65536 vectors of 4096 int<8,8> elements (TRN::TCPL / SAT::ZERO), every tree node quantised; one wave per row"
 
 
@@ -611,7 +615,7 @@ def main(argv=None):
             lb.free()
         except Exception as e:
             out["layout_steps"] = {"error": str(e)}
-        for nm, iters in (("c3T", 10), ("c3Td", 10), ("c2L", 200), ("c2T", 20), ("c5TF", 10), ("c5B", 10), ("c5L", 50), ("reduce", 50), ("long_k", 5)):
+        for nm, iters in (("c3T", 10), ("c3Td", 10), ("c2L", 200), ("c2T", 20), ("c5TF", 10), ("c5B", 10), ("c5L", 50), ("reduce", 50), ("long_k", 5), ("w16", 50), ("u8", 50)):
             if nm == name:
                 continue
             try:
