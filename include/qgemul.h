@@ -332,6 +332,11 @@ int qgemul_classify_ep(const qgemul_desc* d, const qgemul_epilogue* ep, uint32_t
 int qgemul_plan_create_ep(qgemul_ctx* c, const qgemul_desc* d, const qgemul_epilogue* ep, uint32_t opt_flags, qgemul_plan** out);
 /* 1 when qgemul_execute_ep runs the chain inside the GEMM kernel, 0 when it runs as its own pass after it */
 int qgemul_plan_fuses_epilogue(const qgemul_plan* p);
+/* Where the non-plane parts of a packed operand of the linear class sit (introspection for tests and tools; device-private layout):
+ * out[0] = byte offset of the 256-byte plane-mask trailer (0: none), out[1] = byte offset of the int64 row sums of a CENTRED
+ * operand (0: none; QG_OPT_BALANCED_LIMBS), out[2] = rows of the packed operand (padded), out[3] = the centre taken off every
+ * stored value.  Composite plans (limb groups / k-chunks) report 0 for the trailer: every sub-operand has its own. */
+int qgemul_plan_packed_layout(const qgemul_plan* p, int operand, int64_t out[4]);
 /* bytes of one packed tensor operand of stage k (0 for a scalar stage) */
 int64_t qgemul_packed_e_bytes(const qgemul_plan* p, int stage);
 /* reference-layout tensor operand of stage k (device-resident copy, column-major M x N, ld in elements,

@@ -36,7 +36,7 @@ EXPORTS = [
     "qgemul_dev_alloc", "qgemul_dev_free", "qgemul_memcpy_h2d", "qgemul_memcpy_d2h",
     "qgemul_pack", "qgemul_pack_f64", "qgemul_unpack_c", "qgemul_execute", "qgemul_fill_packed", "qgemul_time_execute",
     "qgemul_classify_ep", "qgemul_plan_create_ep", "qgemul_packed_e_bytes", "qgemul_pack_e", "qgemul_execute_ep",
-    "qgemul_time_execute_ep", "qgemul_run_ep", "qgemul_plan_fuses_epilogue", "qgemul_classify_epc", "qgemul_plan_create_epc", "qgemul_run_epc",
+    "qgemul_time_execute_ep", "qgemul_run_ep", "qgemul_plan_fuses_epilogue", "qgemul_plan_packed_layout", "qgemul_classify_epc", "qgemul_plan_create_epc", "qgemul_run_epc",
     "qgemul_bitstream_bytes", "qgemul_export_bitstream", "qgemul_run_release", "qgemul_run_sharded", "qgemul_execute_host_c", "qgemul_plan_stores_host_c",
     "qgemul_comm_unique_id", "qgemul_comm_create", "qgemul_comm_destroy", "qgemul_comm_info", "qgemul_gather_packed_c", "qgemul_comm_fence",
     "qgemul_comm_sync", "qgemul_comm_barrier", "qgemul_comm_max_f64", "qgemul_last_rccl_error", "qgemul_ctx_device",
@@ -98,6 +98,7 @@ def lib() -> C.CDLL:
         L.qgemul_plan_create_epc.argtypes = [vp, pd, pec, u32, C.POINTER(vp)]
         L.qgemul_run_epc.argtypes = [pd, pec, vp, vp, vp, C.POINTER(vp), C.POINTER(qgemul_opts)]
         L.qgemul_plan_fuses_epilogue.argtypes = [vp]
+        L.qgemul_plan_packed_layout.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
         L.qgemul_run_release.argtypes = []
         L.qgemul_run_release.restype = None
         L.qgemul_bitstream_bytes.argtypes = [vp, C.c_int]
@@ -341,6 +342,12 @@ class Plan:
     def export_bitstream(self, pC: int, out_dev: int, tensor_chunk: int = 0, elem_chunk: int = 0, fmt: int = 0):
         _chk(lib().qgemul_export_bitstream(self.h, C.c_void_p(pC), tensor_chunk, elem_chunk, fmt, C.c_void_p(out_dev)),
              "qgemul_export_bitstream")
+
+    def packed_layout(self, operand):
+        """(trailer offset, row-sum offset, padded rows, centre) of a packed operand of the linear class (include/qgemul.h)"""
+        out = (C.c_int64 * 4)()
+        _chk(lib().qgemul_plan_packed_layout(self.h, operand, out), "qgemul_plan_packed_layout")
+        return tuple(int(x) for x in out)
 
     def fuses_epilogue(self) -> bool:
         return bool(lib().qgemul_plan_fuses_epilogue(self.h))

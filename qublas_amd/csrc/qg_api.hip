@@ -520,6 +520,17 @@ static bool wide_epilogue(const qgemul_plan* p)
     return p->info.kernel == QG_KERNEL_MFMA_I8 && !q.identity && (q.W > 30 || (q.d < 0 && p->an.dot_bits - q.d > 31));
 }
 
+// centred operands (QPackedGeom::offs): the limb kernels' epilogues take the centres back out before the one round + overflow
+static void centre_args(const qgemul_plan* p, QMfmaArgs& a, const void* packedA, const void* packedB)
+{
+    if (!p->pa.offs || p->comp.on) return;
+    a.rsA = (const int64_t*)((const char*)packedA + p->pa.rowsum_off);
+    a.rsB = (const int64_t*)((const char*)packedB + p->pb.rowsum_off);
+    a.biasA = p->pa.bias;
+    a.biasB = p->pb.bias;
+    a.corr = (int64_t)((uint64_t)p->desc.K * (uint64_t)p->pa.bias * (uint64_t)p->pb.bias);
+}
+
 #ifdef QG_DIAG
 static uint32_t* g_diag_stamps = nullptr;   // device buffer for in-kernel clock stamps (diagnostic build only)
 extern "C" void qgemul_diag_set_stamps(void* dev) { g_diag_stamps = (uint32_t*)dev; }
@@ -960,6 +971,7 @@ int qgemul_execute_ep(qgemul_plan* p, void* packedD, const void* packedA, const 
         m.has_ep = 1;
         m.ep = p->ept;
         m.epa = a;
+        centre_args(p, m, packedA, packedB);
         QG_HIP(qg_launch_mfma(p->LA, p->LB, m, st));
         return QG_OK;
     }
@@ -990,6 +1002,17 @@ int qgemul_execute_ep(qgemul_plan* p, void* packedD, const void* packedA, const 
 }
 
 int qgemul_plan_fuses_epilogue(const qgemul_plan* p) { return p && p->has_ep && fuses_epilogue(p) ? 1 : 0; }
+
+int qgemul_plan_packed_layout(const qgemul_plan* p, int operand, int64_t out[4])
+{
+    if (!p || !out || (operand != QG_OPERAND_A && operand != QG_OPERAND_B)) return QG_EINVAL;
+    const QPackedGeom& g = operand == QG_OPERAND_A ? p->pa : p->pb;
+    out[0] = p->comp.on ? 0 : g.trailer;
+    out[1] = g.offs ? g.rowsum_off : 0;
+    out[2] = g.rows_p;
+    out[3] = g.offs ? -g.bias : 0;
+    return QG_OK;
+}
 
 // the stage entry that reads stage k's tensor operand (nullptr: the stage has no tensor operand)
 static const QEpStage* stage_tensor(const qgemul_plan* p, int k)
@@ -1104,13 +1127,7 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
 #ifdef QG_DIAG
         a.dbg = g_diag_stamps;
 #endif
-        if (p->pa.offs && !p->comp.on) {   // centred operands: the epilogue takes the centres back out (QPackedGeom::offs)
-            a.rsA = (const int64_t*)((const char*)packedA + p->pa.rowsum_off);
-            a.rsB = (const int64_t*)((const char*)packedB + p->pb.rowsum_off);
-            a.biasA = p->pa.bias;
-            a.biasB = p->pb.bias;
-            a.corr = (int64_t)((uint64_t)p->desc.K * (uint64_t)p->pa.bias * (uint64_t)p->pb.bias);
-        }
+        centre_args(p, a, packedA, packedB);
         if (p->pa.digit6) {
             a.kara = 1;
             a.rsA = (const int64_t*)((const char*)packedA + p->pa.rowsum_off);

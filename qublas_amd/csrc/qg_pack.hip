@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void k_pack_limb32(QOperandGeom g, QPackedGeom
     const int64_t lo = g.S[0] ? -((int64_t)1 << W) : 0, hi = ((int64_t)1 << W) - 1;
     unsigned mask = 0;
     bool bad = false;
+    __shared__ unsigned long long rs_sh[64];
     for (int64_t blk_id = blockIdx.x; blk_id < nblk; blk_id += gridDim.x) {
     const int tk = (int)(blk_id % kt), tr64 = (int)(blk_id / kt);
     const int64_t r = (int64_t)tr64 * 64 + row_l, k0 = (int64_t)tk * 64 + kc * 16;
@@ -163,6 +164,24 @@ __global__ __launch_bounds__(256) void k_pack_limb32(QOperandGeom g, QPackedGeom
         for (int j = 0; j < 16; ++j) {
             v[j] = (row_in && k0 + j < g.K) ? q[(int64_t)j * g.ks] : 0;
             bad |= (v[j] < lo) | (v[j] > hi);
+        }
+    }
+    if (p.offs) {   // centred operand (QPackedGeom::offs): x - centre, padding stays 0; row sums of the stored values through LDS
+        const int32_t bias = (int32_t)p.bias;   // (|bias| < 2^24 and W <= 24 on this path: qg_launch_pack)
+        long long part = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (row_in && k0 + j < g.K) v[j] += bias;
+            part += v[j];
+        }
+        if (p.offs != 3) {
+            __syncthreads();                       // (the previous block's sums have left rs_sh)
+            if (t < 64) rs_sh[t] = 0;
+            __syncthreads();
+            if (part) atomicAdd(&rs_sh[row_l], (unsigned long long)part);
+            __syncthreads();
+            if (t < 64 && rs_sh[t] && (int64_t)tr64 * 64 + t < p.rows_p)
+                atomicAdd((unsigned long long*)((char*)dst + p.rowsum_off) + (int64_t)tr64 * 64 + t, rs_sh[t]);
         }
     }
     const int rl = (int)(r % p.tr);
@@ -545,7 +564,8 @@ hipError_t qg_launch_pack(const QOperandGeom& g, const QPackedGeom& p, const voi
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
     if (hipError_t e = zero_trailer(p, dst, st); e != hipSuccess) return e;
     const bool no_fast = generic != 0;   // QG_OPT_GENERIC_LAYOUT: the any-format kernel (byte-identical; the equivalence test)
-    if (!no_fast && g.parts == 1 && g.elem_bytes == 4 && g.sb[0] == 4 && g.off[0] == 0 && p.limbs >= 1 && p.limbs <= 3 && !p.digit6 && !p.offs && (p.bk == 64 || p.bk == 128) &&
+    const bool centred_fast = !p.offs || (g.W[0] <= 24 && p.bias > -(1ll << 24) && p.bias < (1ll << 24));   // (x - centre within int32)
+    if (!no_fast && g.parts == 1 && g.elem_bytes == 4 && g.sb[0] == 4 && g.off[0] == 0 && p.limbs >= 1 && p.limbs <= 3 && !p.digit6 && centred_fast && (p.bk == 64 || p.bk == 128) &&
         p.tr % 64 == 0 && p.rows_p % p.tr == 0 && p.K_p % p.bk == 0 && g.W[0] <= 30 && ((uintptr_t)src & 3) == 0 && ((uintptr_t)dst & 15) == 0) {
         const int64_t nblk = (p.K_p / 64) * (p.rows_p / 64);
         const unsigned nb = (unsigned)(nblk < 2048 ? nblk : 2048);   // grid-stride beyond 8 workgroups per CU
@@ -566,7 +586,8 @@ hipError_t qg_launch_pack_f64(const QOperandGeom& g, const QPackedGeom& p, const
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
     if (hipError_t e = zero_trailer(p, dst, st); e != hipSuccess) return e;
-    if (!generic && g.parts == 1 && p.limbs >= 1 && p.limbs <= 3 && !p.digit6 && !p.offs && (p.bk == 64 || p.bk == 128) && p.tr % 64 == 0 && p.rows_p % p.tr == 0 &&
+    const bool centred_fast = !p.offs || (g.W[0] <= 24 && p.bias > -(1ll << 24) && p.bias < (1ll << 24));
+    if (!generic && g.parts == 1 && p.limbs >= 1 && p.limbs <= 3 && !p.digit6 && centred_fast && (p.bk == 64 || p.bk == 128) && p.tr % 64 == 0 && p.rows_p % p.tr == 0 &&
         p.K_p % p.bk == 0 && g.W[0] <= 30 && ((uintptr_t)src & 7) == 0 && ((uintptr_t)dst & 15) == 0) {
         const int64_t nblk = (p.K_p / 64) * (p.rows_p / 64);
         const unsigned nb = (unsigned)(nblk < 2048 ? nblk : 2048);

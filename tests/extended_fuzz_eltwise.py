@@ -26,7 +26,7 @@ def main():
     ran = skipped = fused = 0
     kernels = {}
     for it in range(cases):
-        ea = rand_qu(rng, rng.choice([7, 12, 16]))
+        ea = rand_qu(rng, rng.choice([7, 12, 15, 16, 23]))   # (15 / 23 value bits + sign: 16- and 24-bit words, stored centred; 24-bit words fuse the chain on 3 x 3 limbs)
         kind = rng.random()
         if kind < 0.6:
             pf = Qu(2 * ea.intBits + 1, 2 * ea.fracBits, ea.isSigned)

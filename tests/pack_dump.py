@@ -20,6 +20,11 @@ CASES = [  # (elem A, elem B, C, M, N, K, transposed_a, lda pad)
     (Qu(8, 8), Qu(8, 8), Qu(23, 8), 1024, 1024, 512, False, 0),
     (Qu(8, 8), Qu(8, 8), Qu(23, 8), 260, 200, 1000, True, 4),     # k contiguous, 16-byte aligned rows, ragged K: vector + scalar loads
     (Qu(4, 3), Qu(4, 3), Qu(16, 3), 4096, 4096, 256, False, 0),   # the 256-row / 128-byte k-tile layout of the two-group kernel
+    # centred operands (x - centre, row sums behind the planes): 16-bit words, 24-bit words x unsigned bytes, both axis orders
+    (Qu(7, 8), Qu(7, 8), Qu(23, 8), 300, 200, 130, False, 0),
+    (Qu(7, 8), Qu(7, 8), Qu(23, 8), 260, 200, 1000, True, 4),
+    (Qu(11, 12), Qu(8, 0, False), Qu(30, 12), 257, 129, 192, False, 3),
+    (Qu(8, 0, False), Qu(7, 8), Qu(23, 8), 1024, 512, 256, True, 0),
 ]
 
 
@@ -45,9 +50,10 @@ def dump(flags):
                 ctx.sync()
                 buf = np.zeros(pb[0 if op == capi.OPERAND_A else 1], dtype=np.uint8)
                 ctx.d2h(buf, pk)
-                if plan.info.limbs[0 if op == capi.OPERAND_A else 1] > 1:
+                t_off, rs_off, rows_p, centre = plan.packed_layout(op)
+                if t_off:
                     # the plane mask is the OR of the trailer's 64 words; which word a wave ORs into is the kernel's business
-                    tr = buf[-256:].view(np.uint32)
+                    tr = buf[t_off:t_off + 256].view(np.uint32)
                     m = np.bitwise_or.reduce(tr)
                     tr[:] = 0
                     tr[0] = m

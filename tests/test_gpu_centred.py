@@ -102,3 +102,33 @@ def test_centred_operands_with_leading_dimensions_and_device_fill(oracle):
             for p in (pA, pB, pC, hC):
                 ctx.free(p)
             plan.close()
+
+
+def test_centred_operands_with_element_wise_chains(oracle):
+    """the reference's lazy tensor operators after a GEMM on centred operands: as the pass after the kernel, fused into the limb
+    kernels' epilogue (the centres go back in BEFORE the one round + overflow into C, then the chain), after a composite plan's
+    combine pass — against oracle GEMM + oracle chain and against the plain balanced limbs"""
+    from qublas_amd.desc import Ew, lower_epilogue
+    B106, S34 = Qu(10, 6), Qu(3, 4)
+    chains = [([Ew("mul", S34, Tags(24, 8), scalar=True, into=Qu(24, 8)), Ew("add", B106)], Qu(16, 6, True, RND.ZERO, SAT.TCPL)),
+              ([], Qu(9, 3, True, RND.NEG_INF, SAT.SMGN))]
+    cfgs = [(Q78, Qu(15, 8), dict(mul_args=Tags(15, 16), add_args=[Qu(27, 16)]), 200, 136, 192),
+            (Q1112, Qu(15, 8), dict(mul_args=Tags(23, 24), add_args=[Qu(35, 24)]), 200, 136, 192),
+            (U8, Qu(15, 8), dict(mul_args=Tags(16, 0, False), add_args=[Qu(28, 0, False)]), 130, 260, 128)]
+    for ea, ec, kw, M, N, K in cfgs:
+        d = lower(ea, ea, ec, M, N, K, **kw)
+        A, B = oracle.fill(ea, M * K, 1), oracle.fill(ea, K * N, 2)
+        sh = ea.intBits + ea.fracBits - 10 if ea.isSigned else 4   # small magnitudes: C must not saturate everywhere, or a wrong sum would hide behind the clamp
+        A, B = (A >> sh).astype(A.dtype), (B >> sh).astype(B.dtype)
+        Cx = oracle.gemm(d, A, B, ec, nthreads=8).astype(np.int64)
+        for stages, dq in chains:
+            ep = lower_epilogue(ec, stages, dq)
+            st, info = capi.classify_ep_status(d, ep)
+            assert st == capi.QG_OK, info.reason
+            Eh = [oracle.fill(s.e, 1 if s.scalar else M * N, 70 + k, 0) for k, s in enumerate(stages)]
+            exp = oracle.eltwise(ep, ec, Cx, [e.astype(np.int64) for e in Eh])
+            assert np.mean(np.abs(Cx) >= ec.raw_max) < 0.5
+            for fl in (0, capi.OPT_FUSED_EPILOGUE, capi.OPT_UNFUSED_EPILOGUE, capi.OPT_BALANCED_LIMBS):
+                out = np.zeros(M * N, dtype=np.int32 if dq.storage_bits <= 32 else np.int64)
+                got = capi.run_ep(d, ep, out, A, B, Eh, flags=fl)
+                assert np.array_equal(got.astype(np.int64), exp), (str(ea), fl, len(stages))
