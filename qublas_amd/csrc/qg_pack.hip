@@ -454,7 +454,11 @@ __global__ __launch_bounds__(256) void k_lin_combine(QLinCombine g)
         if (j < g.n_slabs) s += (AccT)(((const SlabT*)g.slab[j])[i]) * ((AccT)1 << g.sh[j]);
     if (g.acc_out) { ((AccT*)g.acc_out)[i] = s; return; }
     if (g.rsA) {   // centred operands: sum a b = sum a'b' - biasB rsA[row] - biasA rsB[col] + K biasA biasB (wrapping: the sum itself fits)
-        const int64_t t = i / ((int64_t)g.tm * g.tn), row = (t / g.tiles_n) * g.tm + i % g.tm, col = (t % g.tiles_n) * g.tn + (i / g.tm) % g.tn;
+        // (tile sizes are powers of two and there are fewer than 2^32 tiles: shifts, masks and ONE 32-bit division — with three 64-bit
+        //  divisions this pass was as long as the uint8 GEMM in front of it)
+        const int ltm = __ffs(g.tm) - 1, ltn = __ffs(g.tn) - 1;
+        const uint32_t t = (uint32_t)(i >> (ltm + ltn)), tmq = t / (uint32_t)g.tiles_n, tnq = t - tmq * (uint32_t)g.tiles_n;
+        const int64_t row = (int64_t)tmq * g.tm + (i & (g.tm - 1)), col = (int64_t)tnq * g.tn + ((i >> ltm) & (g.tn - 1));
         using U = std::conditional_t<sizeof(AccT) == 16, qg_u128, uint64_t>;
         s = (AccT)((U)s + (U)(AccT)g.corr * (U)(AccT)g.biasA * (U)(AccT)g.biasB - (U)(AccT)g.biasB * (U)(AccT)g.rsA[row] - (U)(AccT)g.biasA * (U)(AccT)g.rsB[col]);   // (corr: K)
     }
@@ -503,6 +507,7 @@ hipError_t qg_launch_lin_combine(const QLinCombine& g, hipStream_t st)
     if (g.n <= 0) return hipSuccess;
     const int64_t blocks = (g.n + 255) / 256;
     if (blocks > 0x7fffffffll || g.n_slabs < 1 || g.n_slabs > QG_MAX_SLABS) return hipErrorInvalidValue;
+    if (g.rsA && (g.tm <= 0 || g.tn <= 0 || (g.tm & (g.tm - 1)) || (g.tn & (g.tn - 1)) || g.tiles_n <= 0 || g.tiles_n > 0x7fffffffll)) return hipErrorInvalidValue;
     if (g.wide) {
         if (g.slab_bytes == 4) hipLaunchKernelGGL((k_lin_combine<int32_t, qg_i128>), dim3((unsigned)blocks), dim3(256), 0, st, g);
         else hipLaunchKernelGGL((k_lin_combine<int64_t, qg_i128>), dim3((unsigned)blocks), dim3(256), 0, st, g);
