@@ -150,7 +150,7 @@ def workloads():
         "w16": dict(a=Qu(7, 8), b=Qu(7, 8), c=Qu(23, 8), mul=Tags(15, 16), add=[Qu(27, 16)], cfg="16-bit words (Q7.8), the size of configs[2]", ref=None,
                     text="4096^3 Qgemul int<7,8> signed (16-bit words), linear class: operands stored centred (x - 128) in 2 x 2 int8 limbs instead of 3 x 3"),
         "u8": dict(a=Qu(8, 0, False), b=Qu(8, 0, False), c=Qu(28, 0, False), mul=Tags(16, 0, False), add=[Qu(28, 0, False)], cfg="unsigned bytes, the size of configs[2]", ref=None,
-                   text="4096^3 Qgemul of unsigned 8-bit integers with exact sums, linear class: operands stored centred (x - 128) in ONE int8 limb + combine pass"),
+                   text="4096^3 Qgemul of unsigned 8-bit integers with exact sums, linear class: operands stored centred (x - 128) in ONE int8 limb, the centres restored in the kernel epilogue"),
         "long_k": dict(a=e88z, b=e88z, c=Qu(33, 16), mul=Tags(17, 16), add=[Qu(33, 16)], cfg="configs[2] operands, K = 65536 (beyond one MFMA launch's exact int32 range)", ref=None,
                        text="4096x4096x65536 Qgemul int<8,8> signed, linear class: 2 k-chunks on the 3x3 int8-limb MFMA kernel + exact combine pass"),
     }

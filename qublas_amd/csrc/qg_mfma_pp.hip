@@ -340,6 +340,24 @@ __global__ __launch_bounds__(512) void k_mfma_pp(QMfmaArgs g)
                 qg_step_all<int32_t, 16>(v, st);
             }
         };
+        // centred operands (QPackedGeom::offs; k_mfma): sum a b = acc - biasB rsA[row] - biasA rsB[col] + K biasA biasB needs more than
+        // 32 bits, its image in C's format (at most 31 bits on this path: qg_api.hip) does not.  rowf / colf: tile-local row and
+        // column of value o of the 16
+        auto convert16c = [&](int32_t (&v)[16], auto rowf, auto colf) {
+            if (!g.rsA) { convert16(v); return; }
+            const int64_t* ra = g.rsA + (int64_t)tile_m * TM;
+            const int64_t* rb = g.rsB + (int64_t)tile_n * TN;
+#pragma unroll
+            for (int o = 0; o < 16; ++o) {
+                const int64_t x = (int64_t)((uint64_t)(int64_t)v[o] + (uint64_t)g.corr - (uint64_t)g.biasB * (uint64_t)ra[rowf(o)] - (uint64_t)g.biasA * (uint64_t)rb[colf(o)]);
+                if constexpr (FAST) {
+                    const int64_t y = x >> sh;
+                    v[o] = (int32_t)(y < (int64_t)clo ? (int64_t)clo : y > (int64_t)chi ? (int64_t)chi : y);
+                } else {
+                    v[o] = (int32_t)qg_step<int64_t>(x, st);
+                }
+            }
+        };
         char* C = (char*)g.C;
         const int64_t tile_base = ((int64_t)tile_m * tiles_n + tile_n) * TM * TN;
         if constexpr (CB <= 2) {
@@ -370,7 +388,8 @@ __global__ __launch_bounds__(512) void k_mfma_pp(QMfmaArgs g)
                         for (int t = 0; t < 4; ++t)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) s[t * 4 + e] = acc[qi][qj][t][u][e];
-                        convert16(s);
+                        convert16c(s, [&](int o) { return qi * 128 + wr * 64 + (o >> 2) * 16 + 4 * fq + (o & 3); },
+                                   [&](int) { return qj * 128 + wc * 32 + u * 16 + fr; });
                         const int col = qj * 128 + wc * 32 + u * 16 + fr;
                         const int64_t base = tile_base + (int64_t)col * TM + qi * 128 + wr * 64 + fq * 16;   // 16 rows of tile t = fq
                         if constexpr (CB == 1) {
@@ -408,7 +427,8 @@ __global__ __launch_bounds__(512) void k_mfma_pp(QMfmaArgs g)
                         for (int u = 0; u < 2; ++u)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) s[(qj * 2 + u) * 4 + e] = acc[qi][qj][t][u][e];
-                    convert16(s);
+                    convert16c(s, [&](int o) { return qi * 128 + wr * 64 + t * 16 + 4 * fq + (o & 3); },
+                               [&](int o) { return (o >> 3) * 128 + wc * 32 + ((o >> 2) & 1) * 16 + fr; });
                     const int row0 = qi * 128 + wr * 64 + t * 16 + 4 * fq;
 #pragma unroll
                     for (int qj = 0; qj < 2; ++qj)

@@ -24,7 +24,11 @@ CASES = [
     (Q78, Q78, Qu(20, 8), dict(mul_args=Tags(15, 16), add_args=[Qu(28, 16)]), [(256, 256, 256), (130, 70, 200), (1, 3, 1), (2048, 2048, 512)], [2, 2], [3, 3], "mfma_i8_limb"),
     (Q78, Q78, Qu(9, 3, True, RND.CONV, SAT.SMGN), dict(mul_args=Tags(15, 16), add_args=[Qu(28, 16)]), [(257, 129, 64)], [2, 2], [3, 3], "mfma_i8_limb"),
     (U8, U8, Qu(26, 0, False), dict(mul_args=Tags(16, 0, False), add_args=[Qu(28, 0, False)]), [(256, 256, 256), (130, 70, 200), (2048, 1024, 2048)], [1, 1], [2, 2], "mfma_i8"),
-    (U8, E43, Qu(20, 3), dict(mul_args=Tags(12, 3), add_args=[Qu(24, 3)]), [(300, 200, 100)], [1, 1], [2, 1], "mfma_i8"),      # one centred, one not
+    # large single-limb problems: the two-group kernel's own epilogue restores the sum in 64 bits (C of at most 31 bits), 4-, 2- and 1-byte containers
+    (U8, U8, Qu(28, 0, False), dict(mul_args=Tags(16, 0, False), add_args=[Qu(28, 0, False)]), [(4096, 4096, 256), (4000, 4100, 320)], [1, 1], [2, 2], "mfma_i8"),
+    (U8, U8, Qu(25, -16, False, RND.CONV, SAT.SMGN), dict(mul_args=Tags(16, 0, False), add_args=[Qu(28, 0, False)]), [(4096, 4096, 512)], [1, 1], [2, 2], "mfma_i8"),
+    (U8, U8, Qu(23, -16, False), dict(mul_args=Tags(16, 0, False), add_args=[Qu(28, 0, False)]), [(4096, 4096, 512)], [1, 1], [2, 2], "mfma_i8"),
+    (U8, E43, Qu(20, 3), dict(mul_args=Tags(12, 3), add_args=[Qu(24, 3)]), [(300, 200, 100), (4096, 4096, 256)], [1, 1], [2, 1], "mfma_i8"),      # one centred, one not
     (Q78, E43, Qu(20, 8), dict(mul_args=Tags(12, 11), add_args=[Qu(22, 11)]), [(300, 200, 100), (1024, 1024, 256)], [2, 1], [3, 1], "mfma_i8_limb"),
     (E88, Q78, Qu(20, 8), dict(mul_args=Tags(16, 16), add_args=[Qu(28, 16)]), [(200, 300, 128)], [3, 2], [3, 3], "mfma_i8_limb"),
     (U16, U16, Qu(30, 12, False), dict(mul_args=Tags(20, 12, False), add_args=[Qu(32, 12, False)]), [(256, 384, 512)], [2, 2], [3, 3], "mfma_i8_limb"),
