@@ -358,7 +358,7 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     if (kernel == QG_KERNEL_TREE_I32) {
         const int fm = (flags & QG_OPT_RUNTIME_MODES) ? 0 : an->fast_mode;
         snprintf(info->reason, sizeof info->reason, "exact tree evaluation; tree kernel steps: %s",
-                 fm == 7 ? "one format, SAT::TCPL, left-justified, packed 16-bit" : fm == 6 ? "one format, SAT::TCPL, left-justified" : fm == 1 ? "one format, SAT::ZERO" : fm == 2 ? "one format, SAT::TCPL" : fm == 3 ? "per-level formats, compact (clamps)" : fm == 4 ? "per-level formats, compact" : fm == 5 ? "per-level formats, compact (unbiased)" : "run-time modes");
+                 fm >= 8 ? "one format, SAT::TCPL, left-justified, packed nodes" : fm == 7 ? "one format, SAT::TCPL, left-justified, packed 16-bit" : fm == 6 ? "one format, SAT::TCPL, left-justified" : fm == 1 ? "one format, SAT::ZERO" : fm == 2 ? "one format, SAT::TCPL" : fm == 3 ? "per-level formats, compact (clamps)" : fm == 4 ? "per-level formats, compact" : fm == 5 ? "per-level formats, compact (unbiased)" : "run-time modes");
     }
     if (kernel == QG_KERNEL_GEMV_I64)
         snprintf(info->reason, sizeof info->reason, "exact tree evaluation; one-column kernel steps: run-time modes, 64-bit values");
@@ -1203,7 +1203,7 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
     case QG_KERNEL_TREE_I32: {
         static const bool no_lj = QG_DIAG_ENV("QG_NO_LEFT_JUSTIFIED");   // A/B switch (diagnostic library): the form such a descriptor had before
         static const bool no_pk = QG_DIAG_ENV("QG_NO_PACKED16");
-        const int fm = (p->an.fast_mode >= 6 && no_lj) ? p->an.fast_mode_base : (p->an.fast_mode == 7 && no_pk) ? 6 : p->an.fast_mode;
+        const int fm = (p->an.fast_mode >= 6 && no_lj) ? p->an.fast_mode_base : (p->an.fast_mode >= 7 && no_pk) ? 6 : p->an.fast_mode;
         QG_HIP(qg_launch_tree_fast(p->dev_table, p->an.tree.n_levels_k, p->an.split_s, p->an.mul24_ok,
                                    (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : fm, packedA, packedB, packedC,
                                    p->desc.M, p->desc.N, p->pa.K_p, pcg.cbytes, st));

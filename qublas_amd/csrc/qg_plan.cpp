@@ -779,6 +779,9 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                         out->fast_mode = 7;
                     }
                 }
+                // 8: the format has at most 16 bits but its product does not fit the halves (bits + shift > 16): MODE 6's 32-bit justified
+                // product, whose high half is the value justified in 16 bits, and the tree on packed halves (k_tree_pk16<., true>)
+                if (out->fast_mode == 6 && Wt >= 2 && Wt <= 16) out->fast_mode = Wt == 16 ? 9 : 8;   // (9: no bits below the unit in a half)
             }
         }
     }

@@ -498,17 +498,23 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
 // tx + 16) pairs per k), + v_and; a node pair is one v_pk_add_i16 ... clamp, + v_and at the odd levels: 1.9 vector
 // instructions per MAC where MODE 6 spends 3.8 and the v_med3 form 5.3 (BASELINE configuration 2 as literally configured).
 constexpr int PKP = 18;   // dwords per sA16 row (16 + 2: 8-byte reads stay aligned)
+// HYB (fast_mode 8): formats of 9 ... 16 bits whose PRODUCT does not fit the halves (format bits + the product's rounding shift
+// > 16: int<7,8>, the 16-bit words of most fixed-point code).  The product is MODE 6's — one saturating v_mad_i32_i24 per output
+// on x * 2^(32 - bits) — and its HIGH half is the value justified in 16 bits: one v_perm_b32 packs the high halves of a lane's two
+// columns and drops the low ones — for a 16-bit format that IS the rounding's floor and no low bits exist to be cleared anywhere
+// (2.0 vector instructions per MAC); narrower formats clear the rest of the fraction with one v_and per pair and then follow the
+// packed form's rule (2.7 per MAC) — where MODE 6 spends 3.5.
 #define NODE16(X, L)                                                                                     \
     do {                                                                                                 \
         _Pragma("unroll") for (int o_ = 0; o_ < 4; ++o_) v[o_] = pk_add_sat(X[o_], v[o_]);               \
-        if ((L) & 1) { _Pragma("unroll") for (int o_ = 0; o_ < 4; ++o_) v[o_] &= mask2; }                \
+        if (((L) & 1) && HYB != 2) { _Pragma("unroll") for (int o_ = 0; o_ < 4; ++o_) v[o_] &= mask2; }       \
     } while (0)
 
-template <int MAXL>
+template <int MAXL, int HYB = 0>   // HYB 1: formats of fewer than 16 bits; 2: exactly 16 (no bits below the unit in a half: nothing to clear, ever)
 __global__ __launch_bounds__(256) void k_tree_pk16(QTreeFastArgs g)
 {
-    __shared__ __attribute__((aligned(16))) int sA[TMB][PKP];       // [row][k / 2]: (k even, k odd)
-    __shared__ __attribute__((aligned(16))) int sB[TNB / 2][PITCH]; // [column pair][k]: (column p, column p + 16)
+    __shared__ __attribute__((aligned(16))) int sA[TMB][HYB ? PITCH : PKP];              // [row][k / 2]: (k even, k odd); HYB: [row][k] of 32-bit values
+    __shared__ __attribute__((aligned(16))) int sB[HYB ? TNB : TNB / 2][PITCH];          // [column pair][k]: (column p, column p + 16); HYB: [column][k]
     const QTreeTable* __restrict__ tab = g.tab;
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
@@ -523,9 +529,9 @@ __global__ __launch_bounds__(256) void k_tree_pk16(QTreeFastArgs g)
     const int64_t gsz = (tiles_m - first_m) < GMT ? (tiles_m - first_m) : GMT;
     const int64_t m0 = (first_m + (bid % (GMT * tiles_n)) % gsz) * TMB, n0 = ((bid % (GMT * tiles_n)) / gsz) * TNB;
     const int nl = tab->n_levels_k;
-    const int s16 = tab->lj16.s, ea = tab->lj16.e[0], eb = tab->lj16.e[1];
+    const int s16 = HYB ? tab->lj.s - 16 : tab->lj16.s, ea = HYB ? tab->lj.e[0] : tab->lj16.e[0], eb = HYB ? tab->lj.e[1] : tab->lj16.e[1];
     const int m1 = (0xffff << s16) & 0xffff, mask2 = m1 | (m1 << 16);
-    const int t2 = pk2(tab->lj16.t[0], tab->lj16.t[0]);
+    const int t2 = HYB ? tab->lj.t[0] : pk2(tab->lj16.t[0], tab->lj16.t[0]);   // (HYB: the 32-bit product's scaled addend)
 
     int low[4][4];
     int up[MAXL - 4][4];
@@ -542,7 +548,10 @@ __global__ __launch_bounds__(256) void k_tree_pk16(QTreeFastArgs g)
             if (m0 + r < g.M) ra[c] = *(const int4*)(g.A + (m0 + r) * g.K + k0 + q * 4);
         }
         rb[0] = rb[1] = make_int4(0, 0, 0, 0);
-        if (tid < 128) {
+        if (HYB) {   // 32 columns x 8 chunks of 4 k: one per thread
+            const int r = tid >> 3, q = tid & 7;
+            if (n0 + r < g.N) rb[0] = *(const int4*)(g.B + (n0 + r) * g.K + k0 + q * 4);
+        } else if (tid < 128) {
             const int p = tid >> 3, q = tid & 7;
             if (n0 + p < g.N) rb[0] = *(const int4*)(g.B + (n0 + p) * g.K + k0 + q * 4);
             if (n0 + p + 16 < g.N) rb[1] = *(const int4*)(g.B + (n0 + p + 16) * g.K + k0 + q * 4);
@@ -556,9 +565,14 @@ __global__ __launch_bounds__(256) void k_tree_pk16(QTreeFastArgs g)
         for (int c = 0; c < 2; ++c) {
             const int ch = tid + 256 * c, r = ch >> 3, q = ch & 7;
             const int4 x = ra[c];
-            *(int2*)&sA[r][q * 2] = make_int2(pk2(x.x << ea, x.y << ea), pk2(x.z << ea, x.w << ea));
+            if (HYB) *(int4*)&sA[r][q * 4] = make_int4(x.x << ea, x.y << ea, x.z << ea, x.w << ea);
+            else *(int2*)&sA[r][q * 2] = make_int2(pk2(x.x << ea, x.y << ea), pk2(x.z << ea, x.w << ea));
         }
-        if (tid < 128) {
+        if (HYB) {
+            const int r = tid >> 3, q = tid & 7;
+            const int4 x = rb[0];
+            *(int4*)&sB[r][q * 4] = make_int4(x.x << eb, x.y << eb, x.z << eb, x.w << eb);
+        } else if (tid < 128) {
             const int p = tid >> 3, q = tid & 7;
             const int4 x = rb[0], y = rb[1];
             *(int4*)&sB[p][q * 4] = make_int4(pk2(x.x << eb, y.x << eb), pk2(x.y << eb, y.y << eb), pk2(x.z << eb, y.z << eb), pk2(x.w << eb, y.w << eb));
@@ -570,13 +584,33 @@ __global__ __launch_bounds__(256) void k_tree_pk16(QTreeFastArgs g)
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq) {
                 int2 a2[4];
+                int4 a4[4], b4h[2];   // HYB: 32-bit operands, four k per read
+                int4 b4 = make_int4(0, 0, 0, 0);
+                if (HYB) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a2[i] = *(const int2*)&sA[ty * 4 + i][kb * 8 + kq * 2];
-                const int4 b4 = *(const int4*)&sB[tx][kb * 16 + kq * 4];
+                    for (int i = 0; i < 4; ++i) a4[i] = *(const int4*)&sA[ty * 4 + i][kb * 16 + kq * 4];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) b4h[j] = *(const int4*)&sB[tx + 16 * j][kb * 16 + kq * 4];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a2[i] = *(const int2*)&sA[ty * 4 + i][kb * 8 + kq * 2];
+                    b4 = *(const int4*)&sB[tx][kb * 16 + kq * 4];
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int kk = kq * 4 + e;
                     const int bv = e == 0 ? b4.x : e == 1 ? b4.y : e == 2 ? b4.z : b4.w;
+                    if (HYB) {
+                        const int b0 = e == 0 ? b4h[0].x : e == 1 ? b4h[0].y : e == 2 ? b4h[0].z : b4h[0].w;
+                        const int b1 = e == 0 ? b4h[1].x : e == 1 ? b4h[1].y : e == 2 ? b4h[1].z : b4h[1].w;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int av = e == 0 ? a4[i].x : e == 1 ? a4[i].y : e == 2 ? a4[i].z : a4[i].w;
+                            // the high halves of the two justified products: (column tx, column tx + 16); the dropped halves are the floor
+                            v[i] = (int)__builtin_amdgcn_perm((unsigned)sat_mad24_vvs(av, b1, t2), (unsigned)sat_mad24_vvs(av, b0, t2), 0x07060302u);
+                            if (HYB == 1) v[i] &= mask2;   // (fewer than 16 bits: the rest of the fraction sits in the halves' low bits)
+                        }
+                    } else
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int av = e < 2 ? a2[i].x : a2[i].y;
@@ -672,6 +706,18 @@ hipError_t qg_launch_tree_fast(const QTreeTable* dev_table, int n_levels, int sp
     if (mode == 7) {   // ... in packed 16-bit halves
         if (n_levels <= 12) hipLaunchKernelGGL((k_tree_pk16<12>), grid, dim3(256), 0, st, g);
         else hipLaunchKernelGGL((k_tree_pk16<16>), grid, dim3(256), 0, st, g);
+        return hipGetLastError();
+    }
+    const bool full16 = mode == 9;   // (8: fewer than 16 bits; 9: exactly 16)
+    if (mode == 9) mode = 8;
+    if (mode == 8) {   // ... 32-bit justified products, packed 16-bit nodes
+        if (full16) {
+            if (n_levels <= 12) hipLaunchKernelGGL((k_tree_pk16<12, 2>), grid, dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((k_tree_pk16<16, 2>), grid, dim3(256), 0, st, g);
+        } else {
+            if (n_levels <= 12) hipLaunchKernelGGL((k_tree_pk16<12, 1>), grid, dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((k_tree_pk16<16, 1>), grid, dim3(256), 0, st, g);
+        }
         return hipGetLastError();
     }
     if (mode == 6) {   // left-justified saturating form: never split (the planner checked the scaled operands against 24 bits)

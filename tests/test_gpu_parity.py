@@ -307,7 +307,9 @@ def test_real_tree_kernel_step_forms(oracle):
         (Qu(4, 3), Qu(9, 2), dict(mul_args=Qu(5, 4, True, RND.POS_INF, SAT.TCPL), add_args=[Qu(5, 4)]), "one format, SAT::TCPL, left-justified, packed 16-bit"),
         (Qu(3, 2, False), Qu(9, 2), dict(mul_args=Qu(4, 2, True, RND.NEG_INF, SAT.TCPL), add_args=[Qu(4, 2)]), "one format, SAT::TCPL, left-justified, packed 16-bit"),   # unsigned operands in a signed format
         (e88, Qu(12, 8), dict(mul_args=Qu(8, 8, True, RND.POS_INF, SAT.TCPL), add_args=[Qu(8, 8)]), "one format, SAT::TCPL, left-justified"),   # the addend rides in the multiply-add
-        (Qu(6, 5), Qu(9, 2), dict(mul_args=Qu(7, 6, True, RND.NEG_INF, SAT.TCPL), add_args=[Qu(7, 6)]), "one format, SAT::TCPL, left-justified"),
+        (Qu(6, 5), Qu(9, 2), dict(mul_args=Qu(7, 6, True, RND.NEG_INF, SAT.TCPL), add_args=[Qu(7, 6)]), "one format, SAT::TCPL, left-justified, packed nodes"),   # 14 bits, product shift 4: 32-bit products, packed nodes
+        (Qu(7, 8), Qu(7, 8), dict(), "one format, SAT::TCPL, left-justified, packed nodes"),                         # 16-bit words: the high half of the justified product IS the value
+        (Qu(7, 8, True, RND.POS_INF, SAT.TCPL), Qu(12, 4), dict(), "one format, SAT::TCPL, left-justified, packed nodes"),
         (Qu(8, 8, False), Qu(8, 8, False), dict(), "one format, SAT::TCPL"),                                          # unsigned: [0, 2^W - 1] is not the int32 range
         (e88z, e88z, dict(), "one format, SAT::ZERO"),
         (e88, Qu(12, 8), dict(add_args=[Qu(12, 8)]), "per-level formats, compact (clamps)"),                          # a wider level type (split product)
@@ -374,6 +376,8 @@ def test_justified_forms_edge_shapes(oracle, K):
     c5 = Qcomplex(P(6, 3), P(6, -3))
     cases = [(Qu(4, 3), Qu(4, 3), {}, "tree_i32", "packed 16-bit"),
              (Qu(8, 8), Qu(8, 8), {}, "tree_i32", "left-justified"),
+             (Qu(7, 8), Qu(7, 8), {}, "tree_i32", "packed nodes"),
+             (Qu(5, 6), Qu(9, 2), {}, "tree_i32", "packed nodes"),
              (c5, c5, dict(mul_args=TFComplexMul()), "tree_cplx_i32", "packed 16-bit"),
              (Qcomplex(P(6, 3), P(6, 3)), c5, dict(mul_args=BasicComplexMul()), "tree_cplx_i32", "packed 16-bit"),
              (Qcomplex(P(8, 4), P(8, 4)), c5, dict(mul_args=TFComplexMul()), "tree_cplx_i32", "left-justified")]

@@ -23,6 +23,7 @@ CASES = [
     ("same, run-time modes forced", lower(E, E, E, S, S, S), capi.OPT_RUNTIME_MODES),
     ("int<4,3> default tags at 1024^3 (configuration 2 as literally configured: packed 16-bit; QG_NO_PACKED16=1: left-justified 32-bit; QG_NO_LEFT_JUSTIFIED=1: v_med3)",
      lower(Qu(4, 3), Qu(4, 3), Qu(4, 3), 1024, 1024, 1024), 0),
+    ("int<7,8> (16-bit words) default tags at 2048^3 (32-bit justified products, packed 16-bit nodes; QG_NO_PACKED16=1: left-justified 32-bit)", lower(Qu(7, 8), Qu(7, 8), Qu(7, 8), S, S, S), 0),
     ("int<4,3> default tags at 4096^3", lower(Qu(4, 3), Qu(4, 3), Qu(4, 3), 4096, 4096, 4096), 0),
     ("int<8,8>, level type Qu<12,8> (QgemulAddArgs)", lower(E, E, Qu(12, 8), S, S, S, add_args=[Qu(12, 8)]), 0),
     ("same, run-time modes forced", lower(E, E, Qu(12, 8), S, S, S, add_args=[Qu(12, 8)]), capi.OPT_RUNTIME_MODES),
