@@ -39,7 +39,9 @@ def test_golden_gemms_through_the_sharded_entry(oracle, ndev):
 def test_bands_against_the_oracle(oracle, M, N, K, ndev, ta):
     """Ragged M (the last band is short), transposed and plain A, padded leading dimensions; tree class and linear class."""
     rng = np.random.default_rng(M + N)
-    for ea, ec, kw in ((E88, E88, {}), (E43, Qu(16, 3), dict(mul_args=Tags(9, 6), add_args=[Qu(21, 6)]))):
+    Q78, U8 = Qu(7, 8), Qu(8, 0, False)   # (centred operands: every band packs its own rows of A — and their row sums)
+    for ea, ec, kw in ((E88, E88, {}), (E43, Qu(16, 3), dict(mul_args=Tags(9, 6), add_args=[Qu(21, 6)])),
+                       (Q78, Qu(20, 8), dict(mul_args=Tags(15, 16), add_args=[Qu(27, 16)])), (U8, Qu(24, 0, False), dict(mul_args=Tags(16, 0, False), add_args=[Qu(24, 0, False)]))):
         d = lower(ea, ea, ec, M, N, K, transposed_a=ta, **kw)
         lda = (K if ta else M) + 3
         ldc = M + 5
