@@ -282,6 +282,20 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
             if (l < LA) { LA = l; centreA = c; centred = true; }
             l = qg_limbs_centred(d->b[0], &c);
             if (l < LB) { LB = l; centreB = c; centred = true; }
+            // the row sums are int64.  A 64-bit plan may let them wrap (its whole correction is arithmetic modulo 2^64 and the sum
+            // itself fits); a wide plan (128-bit combine) may not: there an operand's row sums must fit — |x'| < 2^(8 L - 1) * 1.01,
+            // K of them (found by the wide fuzzer: a 56-bit operand over K = 43 519 next to a centred 32-bit one)
+            if (centred && an->wide) {
+                int lgk = 0;
+                while (((int64_t)1 << lgk) < d->K) ++lgk;
+                const bool fitA = 8 * LA + lgk <= 62, fitB = 8 * LB + lgk <= 62;
+                if ((centreB != 0 && !fitA) || (centreA != 0 && !fitB)) {
+                    LA = qg_limbs_for(d->a[0]);
+                    LB = qg_limbs_for(d->b[0]);
+                    centreA = centreB = 0;
+                    centred = false;
+                }
+            }
         }
         const int mn = LA < LB ? LA : LB;
         cfg = qg_mfma_pick(LA, LB, d->M * parts, d->N * parts, (ep ? QG_OPT_LOCKSTEP_TILES : 0u) | flags);   // (the fused / unfused element-wise chain keeps the kernel it was measured on)

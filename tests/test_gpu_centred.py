@@ -136,3 +136,20 @@ def test_centred_operands_with_element_wise_chains(oracle):
                 out = np.zeros(M * N, dtype=np.int32 if dq.storage_bits <= 32 else np.int64)
                 got = capi.run_ep(d, ep, out, A, B, Eh, flags=fl)
                 assert np.array_equal(got.astype(np.int64), exp), (str(ea), fl, len(stages))
+
+
+def test_wide_plans_keep_plain_limbs_where_int64_row_sums_could_overflow(oracle):
+    """Two finds of the wide fuzzer: in a plan with the 128-bit combine the row sums (int64) of a 56- or 61-bit operand over K terms
+    do not fit, so such descriptors keep the plain balanced limbs (a 64-bit plan may let the row sums wrap: all of its correction
+    is arithmetic modulo 2^64)."""
+    cases = [(Qu(13, 48, False), Qu(9, 14), Qu(5, 0, True, TRN.TCPL, SAT.TCPL), 257, 129, 7, True, dict(mul_args=Qu(23, 62), add_args=[Qu(26, 62)]), [8, 4]),
+             (Qu(44, 11), Qu(10, 21), Qu(48, 24, True, TRN.TCPL, SAT.SMGN), 16, 16, 43519, False, dict(mul_args=Qu(55, 32), add_args=[Qu(71, 32)]), [8, 5]),
+             (Q1516, Q1516, Qu(43, 32), 64, 48, 4096, False, dict(mul_args=Tags(31, 32), add_args=[Qu(43, 32)]), [4, 4])]     # (fits: centred)
+    for ea, eb, ec, M, N, K, ta, kw, limbs in cases:
+        d = lower(ea, eb, ec, M, N, K, transposed_a=ta, **kw)
+        info = capi.classify(d)
+        assert list(info.limbs) == limbs and b"128-bit" in info.reason, (list(info.limbs), info.reason)
+        A, B = oracle.fill(ea, M * K, 21), oracle.fill(eb, K * N, 22)
+        got = _run(d, A, B, ec, oracle)
+        exp = oracle.gemm(d, A, B, ec, nthreads=8)
+        assert got.tobytes() == exp.tobytes()
