@@ -448,10 +448,11 @@ __global__ __launch_bounds__(256) void k_lin_combine(QLinCombine g)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= g.n) return;
+    using UAcc = std::conditional_t<sizeof(AccT) == 16, qg_u128, uint64_t>;   // (wrapping sums: with centred operands sum a'b' may pass the accumulator where sum a b does not)
     AccT s = g.acc_in ? ((const AccT*)g.acc_in)[i] : (AccT)0;
 #pragma unroll
     for (int j = 0; j < QG_MAX_SLABS; ++j)
-        if (j < g.n_slabs) s += (AccT)(((const SlabT*)g.slab[j])[i]) * ((AccT)1 << g.sh[j]);
+        if (j < g.n_slabs) s = (AccT)((UAcc)s + ((UAcc)(AccT)(((const SlabT*)g.slab[j])[i]) << g.sh[j]));
     if (g.acc_out) { ((AccT*)g.acc_out)[i] = s; return; }
     if (g.rsA) {   // centred operands: sum a b = sum a'b' - biasB rsA[row] - biasA rsB[col] + K biasA biasB (wrapping: the sum itself fits)
         // (tile sizes are powers of two and there are fewer than 2^32 tiles: shifts, masks and ONE 32-bit division — with three 64-bit
