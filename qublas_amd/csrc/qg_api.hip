@@ -1217,7 +1217,8 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
     case QG_KERNEL_TREE_I32: {
         static const bool no_lj = QG_DIAG_ENV("QG_NO_LEFT_JUSTIFIED");   // A/B switch (diagnostic library): the form such a descriptor had before
         static const bool no_pk = QG_DIAG_ENV("QG_NO_PACKED16");
-        const int fm = (p->an.fast_mode >= 6 && no_lj) ? p->an.fast_mode_base : (p->an.fast_mode >= 7 && no_pk) ? 6 : p->an.fast_mode;
+        int fm = (p->an.fast_mode >= 6 && no_lj) ? p->an.fast_mode_base : (p->an.fast_mode >= 7 && no_pk) ? 6 : p->an.fast_mode;
+        if (fm >= 6 && p->an.lj_unsigned) fm += 16;   // (the unsigned counterparts: qg_launch_tree_fast)
         QG_HIP(qg_launch_tree_fast(p->dev_table, p->an.tree.n_levels_k, p->an.split_s, p->an.mul24_ok,
                                    (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : fm, packedA, packedB, packedC,
                                    p->desc.M, p->desc.N, p->pa.K_p, pcg.cbytes, st));

@@ -50,6 +50,20 @@ __device__ __forceinline__ int sat_mad24_vvs(int a, int b, int c)
     return r;
 }
 
+// UNSIGNED formats (all operands unsigned: nothing ever goes below 0): x * 2^(32 - bits) fills the uint32 range, and the clamp bit of
+// v_mad_u32_u24 / v_add_u32 (v_pk_mad_u16 / v_pk_add_u16) saturates at 2^32 - 1 (2^16 - 1) — the same ones-below-the-unit rule
+__device__ __forceinline__ int usat_add(int a, int b)
+{
+    int r;
+    asm("v_add_u32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int usat_mad24_vvs(int a, int b, int c)
+{
+    int r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
 // ... and in packed 16-bit halves (x * 2^(16 - width), two values per register).  The multiply-add's first operand is one half
 // (HALF) of its register for BOTH results: an A element against a pair of B columns.
 template <int HALF>
@@ -64,6 +78,20 @@ __device__ __forceinline__ int pk_add_sat(int a, int b)
 {
     int r;
     asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int HALF>
+__device__ __forceinline__ int pk_mad_usat(int a2, int b2, int t2)
+{
+    int r;
+    if (HALF == 0) asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] clamp" : "=v"(r) : "v"(a2), "v"(b2), "s"(t2));
+    else asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] clamp" : "=v"(r) : "v"(a2), "v"(b2), "s"(t2));
+    return r;
+}
+__device__ __forceinline__ int pk_add_usat(int a, int b)
+{
+    int r;
+    asm("v_pk_add_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 __device__ __forceinline__ int pk_sub_sat(int a, int b)

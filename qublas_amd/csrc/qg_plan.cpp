@@ -736,17 +736,20 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     if (out->tree_fast_ok && (out->fast_mode == 2 || out->fast_mode == 3)) {
         const QStep& pq = T.mul[0].q;
         const int bitsA = 1 + (int)d->a[0].I + (int)d->a[0].F, bitsB = 1 + (int)d->b[0].I + (int)d->b[0].F;
-        bool lj = !pq.identity && pq.O == QG_SAT_TCPL && pq.S && pq.d >= 0 && pq.lo == -pq.hi - 1 && ((pq.hi + 1) & pq.hi) == 0 && pq.hi > 0 &&
+        // (unsigned: every operand, the product and the levels unsigned — nothing ever goes below 0 — and [0, 2^W - 1] is the uint32
+        //  range of x * 2^(32 - W): the unsigned multiply-add / add with the clamp bit, QAnalysis::lj_unsigned)
+        const bool uns = !pq.S && !d->a[0].S && !d->b[0].S && pq.lo == 0;
+        bool lj = !pq.identity && pq.O == QG_SAT_TCPL && (uns || (pq.S && pq.lo == -pq.hi - 1)) && pq.d >= 0 && ((pq.hi + 1) & pq.hi) == 0 && pq.hi > 0 &&
                   (pq.d == 0 || pq.Q == QG_TRN_TCPL || pq.Q == QG_RND_POS_INF || pq.Q == QG_RND_NEG_INF);
-        int Wt = 1;
-        while (lj && ((int64_t)1 << (Wt - 1)) <= pq.hi) ++Wt;   // hi = 2^(Wt-1) - 1
+        int Wt = uns ? 0 : 1;
+        while (lj && ((int64_t)1 << (Wt - (uns ? 0 : 1))) <= pq.hi) ++Wt;   // hi = 2^(Wt-1) - 1 (signed), 2^Wt - 1 (unsigned)
         const int sj = 32 - Wt;
         lj = lj && sj >= 1 && sj - pq.d >= 0;
         for (uint32_t l = 0; l < (uint32_t)T.n_levels_k && lj; ++l) {
             const QStep& q = T.level_add[0][l].q;
             const bool pad = (int)l >= T.n_levels && q.identity;   // (x + 0 behind a short tree)
             lj = T.level_cvt[0][l].identity && T.level_add[0][l].sa == 0 && T.level_add[0][l].sb == 0 &&
-                 (pad || (!q.identity && q.O == QG_SAT_TCPL && q.S && q.d == 0 && q.lo == pq.lo && q.hi == pq.hi));
+                 (pad || (!q.identity && q.O == QG_SAT_TCPL && q.S == pq.S && q.d == 0 && q.lo == pq.lo && q.hi == pq.hi));
         }
         if (lj) {
             int ea = sj - pq.d;
@@ -762,6 +765,7 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
                 T.lj.e[0] = ea;
                 T.lj.e[1] = eb;
                 out->fast_mode = 6;
+                out->lj_unsigned = uns ? 1 : 0;
                 // 7: ... in 16-bit halves, two outputs per register (k_tree_pk16): the format has at most 16 bits and the justified
                 // operands fit int16 (QTreeTable::lj16).
                 const int s16 = 16 - Wt;

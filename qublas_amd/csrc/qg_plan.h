@@ -82,6 +82,7 @@ struct QAnalysis {
     int cplx_fixed_base;     // cplx_fixed_ok 5 / 6: the form the descriptor has without the justified values (4 when the strict one-clamp form holds, else 2)
     int fast_mode;           // 0 runtime modes; 1 one format everywhere, TCPL + SAT::ZERO; 2 TCPL + SAT::TCPL; 3 / 4 / 5 per-level formats, compact steps (QFix; 3: every step clamps, 4: biased values, 5: unbiased); 6 one signed SAT::TCPL format on left-justified values, 7 ... in packed 16-bit halves, 8 ... 32-bit products, packed 16-bit nodes
     int fast_mode_base;      // fast_mode 6 / 7 (one signed SAT::TCPL format, left-justified saturating steps): the form (2 / 3) the descriptor has without it
+    int lj_unsigned;         // fast_mode 6 ... 9 on an unsigned format (all operands unsigned): the unsigned saturating instructions
     int tree64_ok;           // the 2x2-outputs-per-lane 64-bit tree kernel applies (real, 5..16 levels)
     int gemv_ok;             // the one-column 32-bit tree kernel applies (N = 1, K = 2^p >= 16)
     int gemv_wide_ok;        // ... or its 64-bit-value form: elements of at most 32 storage bits, wider sums / level types

@@ -212,8 +212,8 @@ struct QTreeFastArgs {
 //   (the hardware saturates from the full 48-bit product).
 #define NODE(X, L)                                                         \
     do {                                                                   \
-        if (MODE == 6) {                                                   \
-            _Pragma("unroll") for (int o_ = 0; o_ < NOUT; ++o_) v[o_] = sat_add(X[o_], v[o_]);                    \
+        if (MODE == 6 || MODE == 16) {                                     \
+            _Pragma("unroll") for (int o_ = 0; o_ < NOUT; ++o_) v[o_] = MODE == 16 ? usat_add(X[o_], v[o_]) : sat_add(X[o_], v[o_]);   \
             if ((L) & 1) { _Pragma("unroll") for (int o_ = 0; o_ < NOUT; ++o_) v[o_] &= lj_mask; }               \
         } else if (MODE >= 3) { if ((L) < 4) node_fx_rec<MODE>(v, X, flow[(L) < 4 ? (L) : 0]); else node_fx<MODE>(v, X, tab, L); } \
         else if (MODE != 0) node_fixed<MODE>(v, X, flo, fhi, bias, span);  \
@@ -258,8 +258,9 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
 #pragma unroll
     for (int l = 0; l < 4; ++l) flow[l] = tab->fadd[0][l];
     // MODE 6 (QTreeTable::lj): shift of the justified values, their mask, the product's scaled rounding addend, the operands' factors
-    const int lj_s = MODE == 6 ? tab->lj.s : 0, lj_mask = MODE == 6 ? (int)(~0u << lj_s) : -1, lj_t = MODE == 6 ? tab->lj.t[0] : 0;
-    const int lj_ea = MODE == 6 ? tab->lj.e[0] : 0, lj_eb = MODE == 6 ? tab->lj.e[1] : 0;
+    constexpr bool LJ = MODE == 6 || MODE == 16;   // (16: the unsigned counterpart — uint32 range, v_mad_u32_u24 / v_add_u32 ... clamp)
+    const int lj_s = LJ ? tab->lj.s : 0, lj_mask = LJ ? (int)(~0u << lj_s) : -1, lj_t = LJ ? tab->lj.t[0] : 0;
+    const int lj_ea = LJ ? tab->lj.e[0] : 0, lj_eb = LJ ? tab->lj.e[1] : 0;
 
     int low[4][NOUT];
     int up[MAXL - 4][NOUT];
@@ -275,14 +276,14 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
             const int ch = tid + 256 * c, r = ch >> 3, q = ch & 7;
             int4 x = make_int4(0, 0, 0, 0);
             if (m0 + r < g.M) x = *(const int4*)(g.A + (m0 + r) * g.K + k0 + q * 4);
-            if (MODE == 6) x = make_int4(x.x << lj_ea, x.y << lj_ea, x.z << lj_ea, x.w << lj_ea);
+            if (LJ) x = make_int4(x.x << lj_ea, x.y << lj_ea, x.z << lj_ea, x.w << lj_ea);
             *(int4*)&sA[r][q * 4] = x;
         }
         {
             const int r = tid >> 3, q = tid & 7;
             int4 x = make_int4(0, 0, 0, 0);
             if (n0 + r < g.N) x = *(const int4*)(g.B + (n0 + r) * g.K + k0 + q * 4);
-            if (MODE == 6) x = make_int4(x.x << lj_eb, x.y << lj_eb, x.z << lj_eb, x.w << lj_eb);
+            if (LJ) x = make_int4(x.x << lj_eb, x.y << lj_eb, x.z << lj_eb, x.w << lj_eb);
             if (SPLIT) {
                 *(int4*)&sBh[r][q * 4] = make_int4(x.x >> s, x.y >> s, x.z >> s, x.w >> s);
                 *(int4*)&sBl[r][q * 4] = make_int4(x.x & smask, x.y & smask, x.z & smask, x.w & smask);
@@ -318,11 +319,11 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
                         if (SPLIT) blv[j] = e == 0 ? bl4[j].x : e == 1 ? bl4[j].y : e == 2 ? bl4[j].z : bl4[j].w;
                     }
                     // ---- leaves: 8 quantised products
-                    if (MODE == 6) {
+                    if (LJ) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) v[i * 2 + j] = sat_mad24_vvs(av[i], bhv[j], lj_t) & lj_mask;
+                            for (int j = 0; j < 2; ++j) v[i * 2 + j] = (MODE == 16 ? usat_mad24_vvs(av[i], bhv[j], lj_t) : sat_mad24_vvs(av[i], bhv[j], lj_t)) & lj_mask;
                     } else if (MODE == 5 && fp.skip != 0) {
                         // a product whose rounding looks at the value's sign or parity (RND::ZERO / INF / CONV, TRN::SMGN)
                         if (SPLIT) {
@@ -468,9 +469,9 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) v[o] -= fp.ka;
     }
-    if (MODE == 6) {   // floor(v / 2^s): the value
+    if (LJ) {   // floor(v / 2^s): the value
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) v[o] >>= lj_s;
+        for (int o = 0; o < NOUT; ++o) v[o] = MODE == 16 ? (int)((unsigned)v[o] >> lj_s) : v[o] >> lj_s;
     }
     step_all(v, tab->c_cvt[0]);
 #pragma unroll
@@ -506,11 +507,11 @@ constexpr int PKP = 18;   // dwords per sA16 row (16 + 2: 8-byte reads stay alig
 // packed form's rule (2.7 per MAC) — where MODE 6 spends 3.5.
 #define NODE16(X, L)                                                                                     \
     do {                                                                                                 \
-        _Pragma("unroll") for (int o_ = 0; o_ < 4; ++o_) v[o_] = pk_add_sat(X[o_], v[o_]);               \
+        _Pragma("unroll") for (int o_ = 0; o_ < 4; ++o_) v[o_] = UNS ? pk_add_usat(X[o_], v[o_]) : pk_add_sat(X[o_], v[o_]);   \
         if (((L) & 1) && HYB != 2) { _Pragma("unroll") for (int o_ = 0; o_ < 4; ++o_) v[o_] &= mask2; }       \
     } while (0)
 
-template <int MAXL, int HYB = 0>   // HYB 1: formats of fewer than 16 bits; 2: exactly 16 (no bits below the unit in a half: nothing to clear, ever)
+template <int MAXL, int HYB = 0, bool UNS = false>   // UNS: unsigned formats (qg_fix.h); HYB 1: formats of fewer than 16 bits; 2: exactly 16 (no bits below the unit in a half: nothing to clear, ever)
 __global__ __launch_bounds__(256) void k_tree_pk16(QTreeFastArgs g)
 {
     __shared__ __attribute__((aligned(16))) int sA[TMB][HYB ? PITCH : PKP];              // [row][k / 2]: (k even, k odd); HYB: [row][k] of 32-bit values
@@ -607,14 +608,15 @@ __global__ __launch_bounds__(256) void k_tree_pk16(QTreeFastArgs g)
                         for (int i = 0; i < 4; ++i) {
                             const int av = e == 0 ? a4[i].x : e == 1 ? a4[i].y : e == 2 ? a4[i].z : a4[i].w;
                             // the high halves of the two justified products: (column tx, column tx + 16); the dropped halves are the floor
-                            v[i] = (int)__builtin_amdgcn_perm((unsigned)sat_mad24_vvs(av, b1, t2), (unsigned)sat_mad24_vvs(av, b0, t2), 0x07060302u);
+                            v[i] = UNS ? (int)__builtin_amdgcn_perm((unsigned)usat_mad24_vvs(av, b1, t2), (unsigned)usat_mad24_vvs(av, b0, t2), 0x07060302u)
+                                       : (int)__builtin_amdgcn_perm((unsigned)sat_mad24_vvs(av, b1, t2), (unsigned)sat_mad24_vvs(av, b0, t2), 0x07060302u);
                             if (HYB == 1) v[i] &= mask2;   // (fewer than 16 bits: the rest of the fraction sits in the halves' low bits)
                         }
                     } else
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int av = e < 2 ? a2[i].x : a2[i].y;
-                        v[i] = ((e & 1) ? pk_mad_sat<1>(av, bv, t2) : pk_mad_sat<0>(av, bv, t2)) & mask2;
+                        v[i] = (UNS ? ((e & 1) ? pk_mad_usat<1>(av, bv, t2) : pk_mad_usat<0>(av, bv, t2)) : ((e & 1) ? pk_mad_sat<1>(av, bv, t2) : pk_mad_sat<0>(av, bv, t2))) & mask2;
                     }
                     if ((kk & 1) == 0) {
 #pragma unroll
@@ -662,8 +664,8 @@ __global__ __launch_bounds__(256) void k_tree_pk16(QTreeFastArgs g)
     int r8[NOUT];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        r8[i * 2 + 0] = ((int)((unsigned)v[i] << 16) >> 16) >> s16;
-        r8[i * 2 + 1] = (v[i] >> 16) >> s16;
+        r8[i * 2 + 0] = UNS ? (int)(((unsigned)v[i] & 0xffffu) >> s16) : ((int)((unsigned)v[i] << 16) >> 16) >> s16;
+        r8[i * 2 + 1] = UNS ? (int)(((unsigned)v[i] >> 16) >> s16) : (v[i] >> 16) >> s16;
     }
     step_all(r8, tab->c_cvt[0]);
 #pragma unroll
@@ -703,25 +705,22 @@ hipError_t qg_launch_tree_fast(const QTreeTable* dev_table, int n_levels, int sp
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks);
     if (mode != 0 && !mul24) mode = 0;  // the fixed-mode variants are built for 24-bit multiplies only
-    if (mode == 7) {   // ... in packed 16-bit halves
-        if (n_levels <= 12) hipLaunchKernelGGL((k_tree_pk16<12>), grid, dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((k_tree_pk16<16>), grid, dim3(256), 0, st, g);
-        return hipGetLastError();
-    }
-    const bool full16 = mode == 9;   // (8: fewer than 16 bits; 9: exactly 16)
-    if (mode == 9) mode = 8;
-    if (mode == 8) {   // ... 32-bit justified products, packed 16-bit nodes
-        if (full16) {
-            if (n_levels <= 12) hipLaunchKernelGGL((k_tree_pk16<12, 2>), grid, dim3(256), 0, st, g);
-            else hipLaunchKernelGGL((k_tree_pk16<16, 2>), grid, dim3(256), 0, st, g);
-        } else {
-            if (n_levels <= 12) hipLaunchKernelGGL((k_tree_pk16<12, 1>), grid, dim3(256), 0, st, g);
-            else hipLaunchKernelGGL((k_tree_pk16<16, 1>), grid, dim3(256), 0, st, g);
-        }
+    const bool uns = mode >= 16;   // (+ 16: the unsigned counterparts)
+    if (uns) mode -= 16;
+    if (mode >= 7 && mode <= 9) {   // packed 16-bit halves (7); 32-bit justified products, packed 16-bit nodes (8: fewer than 16 bits; 9: exactly 16)
+#define QG_PK16_LAUNCH(H, U)                                                                                   \
+        do {                                                                                                       \
+            if (n_levels <= 12) hipLaunchKernelGGL((k_tree_pk16<12, H, U>), grid, dim3(256), 0, st, g);            \
+            else hipLaunchKernelGGL((k_tree_pk16<16, H, U>), grid, dim3(256), 0, st, g);                           \
+        } while (0)
+        if (uns) { if (mode == 7) QG_PK16_LAUNCH(0, true); else if (mode == 8) QG_PK16_LAUNCH(1, true); else QG_PK16_LAUNCH(2, true); }
+        else { if (mode == 7) QG_PK16_LAUNCH(0, false); else if (mode == 8) QG_PK16_LAUNCH(1, false); else QG_PK16_LAUNCH(2, false); }
+#undef QG_PK16_LAUNCH
         return hipGetLastError();
     }
     if (mode == 6) {   // left-justified saturating form: never split (the planner checked the scaled operands against 24 bits)
-        launch_tf<false, true, 6>(n_levels, grid, st, g);
+        if (uns) launch_tf<false, true, 16>(n_levels, grid, st, g);
+        else launch_tf<false, true, 6>(n_levels, grid, st, g);
         return hipGetLastError();
     }
     if (split_s > 0) {

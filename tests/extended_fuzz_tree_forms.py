@@ -49,8 +49,12 @@ def main():
             if rng.random() < 0.5:   # narrow operands too: the packed 16-bit form needs format bits + the product's shift <= 16
                 ea = rq(rng, rng.choice([3, 4, 5, 7]))
                 eb = ea if rng.random() < 0.5 else rq(rng, rng.choice([3, 4, 5, 7]))
-            u = Qu(u.intBits, u.fracBits, True, rng.choice([TRN.TCPL, RND.POS_INF, RND.NEG_INF]), SAT.TCPL)
-            mul, levels = u, [Qu(u.intBits, u.fracBits, True, rng.choice(QM), SAT.TCPL) for _ in range(rng.choice([0, 1, 2]))]
+            sg = rng.random() < 0.7                 # (unsigned: the uint32 / uint16 counterparts, when the operands are unsigned too)
+            u = Qu(u.intBits, u.fracBits, sg, rng.choice([TRN.TCPL, RND.POS_INF, RND.NEG_INF]), SAT.TCPL)
+            mul, levels = u, [Qu(u.intBits, u.fracBits, sg, rng.choice(QM), SAT.TCPL) for _ in range(rng.choice([0, 1, 2]))]
+            if not sg:
+                ea = Qu(ea.intBits, ea.fracBits, False, ea.QuMode, ea.OfMode)
+                eb = Qu(eb.intBits, eb.fracBits, False, eb.QuMode, eb.OfMode)
         ec = rq(rng, rng.choice([7, 12, 16, 24]))
         M, N = rng.randint(1, 130), rng.randint(1, 130)
         K = rng.choice([17, 32, 33, 64, 100, 128, 250, 256, 512, 1000, 2048])

@@ -310,7 +310,13 @@ def test_real_tree_kernel_step_forms(oracle):
         (Qu(6, 5), Qu(9, 2), dict(mul_args=Qu(7, 6, True, RND.NEG_INF, SAT.TCPL), add_args=[Qu(7, 6)]), "one format, SAT::TCPL, left-justified, packed nodes"),   # 14 bits, product shift 4: 32-bit products, packed nodes
         (Qu(7, 8), Qu(7, 8), dict(), "one format, SAT::TCPL, left-justified, packed nodes"),                         # 16-bit words: the high half of the justified product IS the value
         (Qu(7, 8, True, RND.POS_INF, SAT.TCPL), Qu(12, 4), dict(), "one format, SAT::TCPL, left-justified, packed nodes"),
-        (Qu(8, 8, False), Qu(8, 8, False), dict(), "one format, SAT::TCPL"),                                          # unsigned: [0, 2^W - 1] is not the int32 range
+        # unsigned operands and formats: [0, 2^W - 1] is the uint32 range of x * 2^(32 - W): v_mad_u32_u24 / v_add_u32 / v_pk_*_u16 with the clamp bit
+        (Qu(8, 8, False), Qu(8, 8, False), dict(), "one format, SAT::TCPL, left-justified, packed nodes"),
+        (Qu(8, 0, False), Qu(8, 0, False), dict(), "one format, SAT::TCPL, left-justified, packed 16-bit"),
+        (Qu(12, 5, False), Qu(12, 5, False), dict(), "one format, SAT::TCPL, left-justified"),
+        (Qu(5, 4, False), Qu(9, 2, False), dict(mul_args=Qu(7, 4, False, RND.POS_INF, SAT.TCPL), add_args=[Qu(7, 4, False)]), "one format, SAT::TCPL, left-justified, packed 16-bit"),
+        (Qu(7, 6, False), Qu(9, 2, False), dict(mul_args=Qu(8, 6, False, RND.NEG_INF, SAT.TCPL), add_args=[Qu(8, 6, False)]), "one format, SAT::TCPL, left-justified, packed nodes"),
+        (Qu(8, 0, False), Qu(8, 0, False), dict(mul_args=Qu(8, 0, True), add_args=[Qu(8, 0, True)]), "one format, SAT::TCPL, left-justified, packed 16-bit"),   # unsigned operands in a signed format: the signed form
         (e88z, e88z, dict(), "one format, SAT::ZERO"),
         (e88, Qu(12, 8), dict(add_args=[Qu(12, 8)]), "per-level formats, compact (clamps)"),                          # a wider level type (split product)
         (e88z, Qu(12, 6, True, TRN.TCPL, SAT.ZERO), dict(add_args=[Qu(10, 8, True, TRN.TCPL, SAT.ZERO), Qu(12, 6, True, TRN.TCPL, SAT.ZERO)]),
@@ -377,6 +383,9 @@ def test_justified_forms_edge_shapes(oracle, K):
     cases = [(Qu(4, 3), Qu(4, 3), {}, "tree_i32", "packed 16-bit"),
              (Qu(8, 8), Qu(8, 8), {}, "tree_i32", "left-justified"),
              (Qu(7, 8), Qu(7, 8), {}, "tree_i32", "packed nodes"),
+             (Qu(8, 0, False), Qu(8, 0, False), {}, "tree_i32", "packed 16-bit"),
+             (Qu(8, 8, False), Qu(12, 4, False), {}, "tree_i32", "packed nodes"),
+             (Qu(12, 5, False), Qu(12, 5, False), {}, "tree_i32", "left-justified"),
              (Qu(5, 6), Qu(9, 2), {}, "tree_i32", "packed nodes"),
              (c5, c5, dict(mul_args=TFComplexMul()), "tree_cplx_i32", "packed 16-bit"),
              (Qcomplex(P(6, 3), P(6, 3)), c5, dict(mul_args=BasicComplexMul()), "tree_cplx_i32", "packed 16-bit"),
