@@ -301,9 +301,10 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
         cfg = qg_mfma_pick(LA, LB, d->M * parts, d->N * parts, (ep ? QG_OPT_LOCKSTEP_TILES : 0u) | flags);   // (the fused / unfused element-wise chain keeps the kernel it was measured on)
         // (wide plans: the kernels' own epilogues are 64-bit; the composite plan's combine pass is not.  Centred single-limb pairs: the
         //  single-limb kernels' epilogue is 32-bit, sum a b of two uint8 operands is not: raw int32 slab + combine pass)
-        // (... except on the two-group single-limb kernel, whose epilogue restores the sum in 64 bits when its image in C fits 31)
+        // (... except where its image in C fits 31 bits and no element-wise chain follows: the single-limb kernels' epilogues then restore
+        //  the sum in 64 bits themselves)
         const QStep& tc = an->lin.to_c[0];
-        const bool pp_centred = cfg.variant == 9 && !ep && sbits(d->c) <= 31 && (tc.identity || (tc.d >= 0 && tc.W <= 30));
+        const bool pp_centred = cfg.variant && !ep && sbits(d->c) <= 31 && (tc.identity || (tc.d >= 0 && tc.W <= 30));   // (every single-limb kernel has the 64-bit branch)
         if (cfg.variant && (int64_t)mn * d->K <= (1ll << 17) - 1 && !an->wide && !an->generic_only && !(centred && LA == 1 && LB == 1 && !pp_centred))
             kernel = d->is_complex ? QG_KERNEL_MFMA_CPLX : ((LA == 1 && LB == 1) ? QG_KERNEL_MFMA_I8 : QG_KERNEL_MFMA_I8_LIMB);
         // (one output column whose tree the one-column kernels can walk: those stream A once at HBM rate; a composite plan would read

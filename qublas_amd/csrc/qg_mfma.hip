@@ -339,7 +339,18 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void k_mfma(QMfmaArgs g)
                     }
                 }
             }
-            qg_step_all<S, 16>(s, st);
+            bool converted = false;
+            if constexpr (NW == 1 && !KARA) {
+                if (g.rsA) {   // a centred single-limb pair: the sum needs 64 bits, its image in C (at most 31 bits: qg_api.hip) does not
+                    const uint64_t cj = (uint64_t)g.corr - (uint64_t)g.biasA * (uint64_t)g.rsB[(int64_t)tile_n * TN + (wn * TJ + j) * 32 + fr];
+                    const int64_t* ra = g.rsA + (int64_t)tile_m * TM + (wm * TI + i) * 32 + 4 * fh;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        s[e] = (S)qg_step<int64_t>((int64_t)((uint64_t)(int64_t)s[e] + cj - (uint64_t)g.biasB * (uint64_t)ra[(e & 3) + 8 * (e >> 2)]), st);
+                    converted = true;
+                }
+            }
+            if (!converted) qg_step_all<S, 16>(s, st);
             if (ABL == 5 && s[0] != (S)0x7ead1234) continue; // diagnostic: keep the arithmetic, drop the stores
             const int col = (wn * TJ + j) * 32 + fr;
             const int row0 = (wm * TI + i) * 32 + 4 * fh;
@@ -672,7 +683,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_mfma16(QMfmaArgs g)
                 }
                 s[j * 4 + e] = x;
             }
-        qg_step_all<S, 4 * TJ>(s, st);
+        bool converted = false;
+        if constexpr (NW == 1 && !KARA) {
+            if (g.rsA) {   // a centred single-limb pair (k_mfma)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        s[j * 4 + e] = (S)qg_step<int64_t>((int64_t)((uint64_t)(int64_t)s[j * 4 + e] + (uint64_t)g.corr -
+                                                                     (uint64_t)g.biasA * (uint64_t)g.rsB[(int64_t)tile_n * TN + (wn * TJ + j) * 16 + fr] -
+                                                                     (uint64_t)g.biasB * (uint64_t)g.rsA[(int64_t)tile_m * TM + (wm * TI + i) * 16 + 4 * fq + e]), st);
+                converted = true;
+            }
+        }
+        if (!converted) qg_step_all<S, 4 * TJ>(s, st);
         const int row0 = (wm * TI + i) * 16 + 4 * fq;
         if constexpr (EP) {
             const int64_t base0 = tile_base + (int64_t)(wn * TJ * 16 + fr) * TM + row0;   // run j starts 16 columns further

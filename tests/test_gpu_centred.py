@@ -29,6 +29,7 @@ CASES = [
     (U8, U8, Qu(25, -16, False, RND.CONV, SAT.SMGN), dict(mul_args=Tags(16, 0, False), add_args=[Qu(28, 0, False)]), [(4096, 4096, 512)], [1, 1], [2, 2], "mfma_i8"),
     (U8, U8, Qu(23, -16, False), dict(mul_args=Tags(16, 0, False), add_args=[Qu(28, 0, False)]), [(4096, 4096, 512)], [1, 1], [2, 2], "mfma_i8"),
     (U8, E43, Qu(20, 3), dict(mul_args=Tags(12, 3), add_args=[Qu(24, 3)]), [(300, 200, 100), (4096, 4096, 256)], [1, 1], [2, 1], "mfma_i8"),      # one centred, one not
+    (U8, U8, Qu(36, 4, False), dict(mul_args=Tags(16, 0, False), add_args=[Qu(28, 0, False)]), [(300, 200, 100), (1024, 1024, 1024)], [1, 1], [2, 2], "mfma_i8"),   # a C beyond 31 bits: raw int32 slab + combine pass
     (Q78, E43, Qu(20, 8), dict(mul_args=Tags(12, 11), add_args=[Qu(22, 11)]), [(300, 200, 100), (1024, 1024, 256)], [2, 1], [3, 1], "mfma_i8_limb"),
     (E88, Q78, Qu(20, 8), dict(mul_args=Tags(16, 16), add_args=[Qu(28, 16)]), [(200, 300, 128)], [3, 2], [3, 3], "mfma_i8_limb"),
     (U16, U16, Qu(30, 12, False), dict(mul_args=Tags(20, 12, False), add_args=[Qu(32, 12, False)]), [(256, 384, 512)], [2, 2], [3, 3], "mfma_i8_limb"),
