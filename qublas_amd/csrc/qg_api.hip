@@ -355,7 +355,7 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
         const bool fast = !(flags & QG_OPT_GENERIC_TREE);
         kernel = an->wide ? QG_KERNEL_TREE_I128 : d->is_complex ? ((an->cplx_fast_ok && fast) ? QG_KERNEL_TREE_CPLX_I32 : QG_KERNEL_TREE_CPLX)
                                : ((an->gemv_ok && fast) ? QG_KERNEL_GEMV_I32 : (an->gemv_wide_ok && fast) ? QG_KERNEL_GEMV_I64
-                                  : (an->tree_fast_ok && fast) ? QG_KERNEL_TREE_I32 : QG_KERNEL_TREE_I64);
+                                  : (an->tree_fast_ok && fast && !(an->fast_mode == 10 && (flags & QG_OPT_RUNTIME_MODES))) ? QG_KERNEL_TREE_I32 : QG_KERNEL_TREE_I64);   // (fast_mode 10, 32-bit words: no run-time-mode form on that kernel)
         // the 32-bit tree kernels walk a perfect binary tree: their operands are zero-padded along K to 2^n_levels leaves
         // (a node whose right child is a zero leaf / zero subtree is the reference's converting copy of an odd leftover)
         const bool t64 = kernel == QG_KERNEL_TREE_I64 && an->tree64_ok && fast;   // the 2x2-per-lane 64-bit kernel, not the general one
@@ -373,7 +373,7 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     if (kernel == QG_KERNEL_TREE_I32) {
         const int fm = (flags & QG_OPT_RUNTIME_MODES) ? 0 : an->fast_mode;
         snprintf(info->reason, sizeof info->reason, "exact tree evaluation; tree kernel steps: %s",
-                 fm >= 8 ? "one format, SAT::TCPL, left-justified, packed nodes" : fm == 7 ? "one format, SAT::TCPL, left-justified, packed 16-bit" : fm == 6 ? "one format, SAT::TCPL, left-justified" : fm == 1 ? "one format, SAT::ZERO" : fm == 2 ? "one format, SAT::TCPL" : fm == 3 ? "per-level formats, compact (clamps)" : fm == 4 ? "per-level formats, compact" : fm == 5 ? "per-level formats, compact (unbiased)" : "run-time modes");
+                 fm == 10 ? "one 32-bit format, SAT::TCPL, saturating word adds" : fm >= 8 ? "one format, SAT::TCPL, left-justified, packed nodes" : fm == 7 ? "one format, SAT::TCPL, left-justified, packed 16-bit" : fm == 6 ? "one format, SAT::TCPL, left-justified" : fm == 1 ? "one format, SAT::ZERO" : fm == 2 ? "one format, SAT::TCPL" : fm == 3 ? "per-level formats, compact (clamps)" : fm == 4 ? "per-level formats, compact" : fm == 5 ? "per-level formats, compact (unbiased)" : "run-time modes");
     }
     if (kernel == QG_KERNEL_GEMV_I64)
         snprintf(info->reason, sizeof info->reason, "exact tree evaluation; one-column kernel steps: run-time modes, 64-bit values");
@@ -1218,8 +1218,8 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
     case QG_KERNEL_TREE_I32: {
         static const bool no_lj = QG_DIAG_ENV("QG_NO_LEFT_JUSTIFIED");   // A/B switch (diagnostic library): the form such a descriptor had before
         static const bool no_pk = QG_DIAG_ENV("QG_NO_PACKED16");
-        int fm = (p->an.fast_mode >= 6 && no_lj) ? p->an.fast_mode_base : (p->an.fast_mode >= 7 && no_pk) ? 6 : p->an.fast_mode;
-        if (fm >= 6 && p->an.lj_unsigned) fm += 16;   // (the unsigned counterparts: qg_launch_tree_fast)
+        int fm = (p->an.fast_mode >= 6 && p->an.fast_mode <= 9 && no_lj) ? p->an.fast_mode_base : (p->an.fast_mode >= 7 && p->an.fast_mode <= 9 && no_pk) ? 6 : p->an.fast_mode;
+        if (fm >= 6 && fm <= 9 && p->an.lj_unsigned) fm += 16;   // (the unsigned counterparts: qg_launch_tree_fast)
         QG_HIP(qg_launch_tree_fast(p->dev_table, p->an.tree.n_levels_k, p->an.split_s, p->an.mul24_ok,
                                    (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : fm, packedA, packedB, packedC,
                                    p->desc.M, p->desc.N, p->pa.K_p, pcg.cbytes, st));

@@ -789,6 +789,38 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
             }
         }
     }
+    // fast_mode 10, 32-BIT WORDS (Q15.16 with default tags, the 32-bit fixed-point format of most code): the product and every level
+    // clamp into ONE signed SAT::TCPL format of exactly 32 bits — whose range is the int32 range as it stands, no justification and
+    // no bits below the unit — the nodes do not shift, and the product rounds by "add a constant, shift right by d" out of the
+    // exact 64-bit product of two elements of at most 32 bits.  Then a node is ONE v_add_i32 ... clamp, where the 64-bit tree
+    // kernel spends a 64-bit add and a 64-bit clamp; the product is v_mul_hi / v_mul_lo, the shift and a saturation to the word.
+    // Runs on the 32-bit tree kernel's frame (k_tree_fast<., 17>), which has no run-time-mode form for such a format: the plan
+    // flag QG_OPT_RUNTIME_MODES sends the descriptor to the 64-bit kernel (qg_api.hip).
+    if (!out->tree_fast_ok && !cx && !out->wide && !out->generic_only && d->n_levels <= 16 && T.n_levels_k <= 16) {
+        const QStep& pq = T.mul[0].q;
+        const int bitsA = 1 + (int)d->a[0].I + (int)d->a[0].F, bitsB = 1 + (int)d->b[0].I + (int)d->b[0].F;
+        bool w32 = !pq.identity && pq.O == QG_SAT_TCPL && pq.S && pq.lo == -((int64_t)1 << 31) && pq.hi == ((int64_t)1 << 31) - 1 && pq.d >= 0 && pq.d <= 31 &&
+                   (pq.d == 0 || pq.Q == QG_TRN_TCPL || pq.Q == QG_RND_POS_INF || pq.Q == QG_RND_NEG_INF) && bitsA <= 32 && bitsB <= 32 &&
+                   (d->a[0].S || bitsA <= 31) && (d->b[0].S || bitsB <= 31);   // (elements are int32 words in the packed operands)
+        for (uint32_t l = 0; l < (uint32_t)T.n_levels_k && w32; ++l) {
+            const QStep& q = T.level_add[0][l].q;
+            const bool pad = (int)l >= T.n_levels && q.identity;
+            w32 = T.level_cvt[0][l].identity && T.level_add[0][l].sa == 0 && T.level_add[0][l].sb == 0 &&
+                  (pad || (!q.identity && q.O == QG_SAT_TCPL && q.S && q.d == 0 && q.lo == pq.lo && q.hi == pq.hi));
+        }
+        // the root is converted into C by the kernel's 32-bit step: C's bounds must be words too, and no left shift
+        const QStep& cq = T.c_cvt[0];
+        w32 = w32 && (cq.identity || (cq.d >= 0 && 1 + (int)d->c[0].I + (int)d->c[0].F <= 32));
+        if (w32) {
+            memset(&T.lj, 0, sizeof T.lj);
+            T.lj.s = pq.d;                                                                                     // the product's shift
+            T.lj.t[0] = pq.d == 0 ? 0 : pq.Q == QG_RND_POS_INF ? (int32_t)((int64_t)1 << (pq.d - 1)) : pq.Q == QG_RND_NEG_INF ? (int32_t)(((int64_t)1 << (pq.d - 1)) - 1) : 0;
+            out->tree_fast_ok = 1;
+            out->split_s = 0;
+            out->mul24_ok = 0;
+            out->fast_mode = out->fast_mode_base = 10;
+        }
+    }
     out->tree64_ok = (!cx && !out->wide && !out->generic_only && d->n_levels <= 16) ? 1 : 0;   // (64-bit values: not a wide plan)
     // QG_DESC_LEFTOVER0_COPY with an odd K: the zero-padded kernels would form the leftover as x + 0 in level 0's type — a
     // conversion, where the reference copies — so only the general kernel, which has the leftover step itself, may run it

@@ -212,7 +212,9 @@ struct QTreeFastArgs {
 //   (the hardware saturates from the full 48-bit product).
 #define NODE(X, L)                                                         \
     do {                                                                   \
-        if (MODE == 6 || MODE == 16) {                                     \
+        if (MODE == 17) {                                                  \
+            _Pragma("unroll") for (int o_ = 0; o_ < NOUT; ++o_) v[o_] = sat_add(X[o_], v[o_]);   \
+        } else if (MODE == 6 || MODE == 16) {                              \
             _Pragma("unroll") for (int o_ = 0; o_ < NOUT; ++o_) v[o_] = MODE == 16 ? usat_add(X[o_], v[o_]) : sat_add(X[o_], v[o_]);   \
             if ((L) & 1) { _Pragma("unroll") for (int o_ = 0; o_ < NOUT; ++o_) v[o_] &= lj_mask; }               \
         } else if (MODE >= 3) { if ((L) < 4) node_fx_rec<MODE>(v, X, flow[(L) < 4 ? (L) : 0]); else node_fx<MODE>(v, X, tab, L); } \
@@ -258,6 +260,7 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
 #pragma unroll
     for (int l = 0; l < 4; ++l) flow[l] = tab->fadd[0][l];
     // MODE 6 (QTreeTable::lj): shift of the justified values, their mask, the product's scaled rounding addend, the operands' factors
+    const int w_d = MODE == 17 ? tab->lj.s : 0, w_t = MODE == 17 ? tab->lj.t[0] : 0;   // MODE 17 (32-bit words): the product's shift and rounding addend
     constexpr bool LJ = MODE == 6 || MODE == 16;   // (16: the unsigned counterpart — uint32 range, v_mad_u32_u24 / v_add_u32 ... clamp)
     const int lj_s = LJ ? tab->lj.s : 0, lj_mask = LJ ? (int)(~0u << lj_s) : -1, lj_t = LJ ? tab->lj.t[0] : 0;
     const int lj_ea = LJ ? tab->lj.e[0] : 0, lj_eb = LJ ? tab->lj.e[1] : 0;
@@ -319,7 +322,16 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
                         if (SPLIT) blv[j] = e == 0 ? bl4[j].x : e == 1 ? bl4[j].y : e == 2 ? bl4[j].z : bl4[j].w;
                     }
                     // ---- leaves: 8 quantised products
-                    if (LJ) {
+                    if (MODE == 17) {   // 32-bit words (fast_mode 10): floor((a b + t) / 2^d) of the exact 64-bit product, saturated to the word
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const long long q = ((long long)av[i] * (long long)bhv[j] + (long long)w_t) >> w_d;
+                                const int ql = (int)q, qh = (int)(q >> 32);
+                                v[i * 2 + j] = qh == (ql >> 31) ? ql : ((qh >> 31) ^ 0x7fffffff);   // (in range: the high word is the low word's sign)
+                            }
+                    } else if (LJ) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -704,6 +716,10 @@ hipError_t qg_launch_tree_fast(const QTreeTable* dev_table, int n_levels, int sp
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks);
+    if (mode == 10) {   // 32-bit words: exact 64-bit products, saturating adds (qg_plan.cpp, fast_mode 10)
+        launch_tf<false, false, 17>(n_levels, grid, st, g);
+        return hipGetLastError();
+    }
     if (mode != 0 && !mul24) mode = 0;  // the fixed-mode variants are built for 24-bit multiplies only
     const bool uns = mode >= 16;   // (+ 16: the unsigned counterparts)
     if (uns) mode -= 16;

@@ -150,8 +150,10 @@ def test_rejections():
     # The UNROUNDED product of two operands may use all of an int64 on the 64-bit kernels: signed 32-bit words (Q15.16) run there;
     # two unsigned 32-bit words (a 64-bit magnitude) or a 33-bit pair need the 128-bit kernel (round 2 refused them)
     q = Qu(15, 16)
-    st, info = capi.classify_status(lower(q, q, q, 4, 4, 64))
+    st, info = capi.classify_status(lower(q, q, q, 4, 4, 64), capi.OPT_RUNTIME_MODES)
     assert st == capi.QG_OK and info.max_bits == 64 and capi.KERNEL_NAMES[info.kernel] == "tree_i64", info.reason
+    st, info = capi.classify_status(lower(q, q, q, 4, 4, 64))     # (default: the 32-bit-word form on the 32-bit tree kernel's frame)
+    assert st == capi.QG_OK and capi.KERNEL_NAMES[info.kernel] == "tree_i32" and info.reason.endswith(b"saturating word adds"), info.reason
     for a, b in ((Qu(16, 16, False), Qu(16, 16, False)), (Qu(16, 16), Qu(15, 16))):
         st, info = capi.classify_status(lower(a, b, q, 4, 4, 64))
         assert st == capi.QG_OK and capi.KERNEL_NAMES[info.kernel] == "tree_i128", info.reason

@@ -265,7 +265,7 @@ def test_32_bit_fixed_point_words(oracle):
     operands incl. the raw minimum, several modes."""
     q = Qu(15, 16)
     cases = [
-        (q, q, q, dict(), "tree_i64"),                                                                     # default tags: every product and node saturates
+        (q, q, q, dict(), "tree_i32"),                                                                     # default tags: every product and node saturates (the 32-bit-word form)
         (q, q, Qu(24, 16, True, RND.CONV, SAT.SMGN), dict(add_args=[Qu(24, 16), Qu(28, 12, True, RND.ZERO, SAT.ZERO)]), "tree_i64"),
         (Qu(20, 11, True, TRN.SMGN, WRP.TCPL), Qu(3, 28), Qu(20, 11), dict(mul_args=Tags(20, 11)), "tree_i64"),
         (q, Qu(15, 16, False), Qu(18, 13), dict(), "tree_i64"),                                          # signed 32 x unsigned 31 bits
@@ -279,6 +279,9 @@ def test_32_bit_fixed_point_words(oracle):
             B[:2] = eb.raw_min                                                                            # (-2^31) * (-2^31) = 2^62 is present
             got = run_gpu(d, A, B, ec, oracle)
             assert fields_equal(got, oracle.gemm(d, A, B, ec, nthreads=8)), (str(ea), str(eb), M, N, K)
+            if kern == "tree_i32" and N > 1:     # ... and the 64-bit tree kernel on the same descriptor
+                assert capi.KERNEL_NAMES[capi.classify(d, capi.OPT_RUNTIME_MODES).kernel] == "tree_i64"
+                assert fields_equal(run_gpu(d, A, B, ec, oracle, flags=capi.OPT_RUNTIME_MODES), got)
     cq = Qcomplex(q, q)
     for mul in (BasicComplexMul(), TFComplexMul()):
         d = lower(cq, cq, cq, 21, 17, 64, mul_args=mul)
@@ -371,6 +374,34 @@ def test_reference_artefacts_flag_on_the_device(oracle):
         exp = oracle.gemm(d, A, B, u32, nthreads=8)
         assert np.array_equal(got, exp) and (exp < 0).any()       # (negative sums stay negative: unwrapped)
         assert capi.classify_status(lower(e, e, u32, M, N, K, mul_args=Tags(25, 8), add_args=[Qu(40, 8)]))[0] == capi.QG_EUNSUPPORTED
+
+
+@pytest.mark.parametrize("K", [1, 2, 5, 32, 33, 100, 1000, 4096])
+def test_32_bit_word_tree_form(oracle, K):
+    """Q15.16 with default tags — every product and every tree node quantised into the 32-bit word — and relatives: the product
+    from the exact 64-bit product (truncating and rounding shifts, operands of other widths), a node one saturating 32-bit add
+    (`fast_mode` 10 on the 32-bit tree kernel's frame).  Against the oracle, with full-range operands (the sums saturate) and
+    small ones (they do not), and against the 64-bit tree kernel the same descriptor takes with QG_OPT_RUNTIME_MODES."""
+    q = Qu(15, 16)
+    cases = [(q, q, q, {}), (Qu(15, 16, True, RND.POS_INF, SAT.TCPL), Qu(15, 16, True, RND.POS_INF, SAT.TCPL), Qu(20, 4), {}),
+             (Qu(8, 12), Qu(4, 8), q, dict(mul_args=Qu(15, 16, True, RND.NEG_INF, SAT.TCPL), add_args=[q])),
+             (Qu(20, 11), Qu(20, 11), Qu(20, 11), {}), (Qu(2, 29), Qu(2, 29), Qu(9, 3, True, RND.CONV, SAT.SMGN), {}),
+             (Qu(15, 15, False), q, q, dict(mul_args=q, add_args=[q]))]
+    assert capi.KERNEL_NAMES[capi.classify(lower(q, q, Qu(20, 12), 33, 17, K)).kernel] == "tree_i64"     # a C beyond 32 bits: the 64-bit kernel's conversion
+    for ea, eb, ec, kw in cases:
+        for M, N in ((33, 17), (1, 3), (70, 41)):
+            d = lower(ea, eb, ec, M, N, K, **kw)
+            info = capi.classify(d)
+            assert capi.KERNEL_NAMES[info.kernel] == "tree_i32" and info.reason.decode().endswith("saturating word adds"), (str(ea), info.reason)
+            assert capi.KERNEL_NAMES[capi.classify(d, capi.OPT_RUNTIME_MODES).kernel] == "tree_i64"
+            for dist in (0, 1, 2):
+                A, B = oracle.fill(ea, M * K, 5, dist % 2), oracle.fill(eb, K * N, 6, dist % 2)
+                if dist == 2:
+                    A, B = (A >> 9).astype(A.dtype), (B >> 9).astype(B.dtype)
+                got = run_gpu(d, A, B, ec, oracle)
+                exp = oracle.gemm(d, A, B, ec, nthreads=8)
+                assert np.array_equal(got, exp), (str(ea), M, N, K, dist)
+                assert np.array_equal(run_gpu(d, A, B, ec, oracle, flags=capi.OPT_RUNTIME_MODES), exp)
 
 
 @pytest.mark.parametrize("K", [1, 2, 3, 5, 16, 17, 31, 32, 33, 100, 1000])

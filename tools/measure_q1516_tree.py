@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Tree class on 32-bit words (Q15.16 with default tags: every product and node quantised into Q15.16): kernel time."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from qublas_amd import capi  # noqa: E402
+from qublas_amd.desc import Qu, lower  # noqa: E402
+
+def main():
+    q = Qu(15, 16)
+    with capi.Context(0) as ctx:
+        for S in (1024, 2048):
+            d = lower(q, q, q, S, S, S)
+            plan = capi.Plan(ctx, d)
+            pb = plan.info.packed_bytes
+            pA, pB, pC = ctx.alloc(pb[0]), ctx.alloc(pb[1]), ctx.alloc(pb[2])
+            plan.fill(capi.OPERAND_A, 1, 0, pA)
+            plan.fill(capi.OPERAND_B, 2, 0, pB)
+            plan.time_execute(pC, pA, pB, 1, 3)
+            ms = plan.time_execute(pC, pA, pB, 1, 5)
+            print(json.dumps({"case": f"Q15.16 default tags {S}^3", "kernel": capi.KERNEL_NAMES[plan.info.kernel], "reason": plan.info.reason.decode(), "ms": round(ms, 4),
+                              "instr_slots_per_mac_at_2.4GHz": round(ms * 1e-3 * 39.3e12 / S ** 3, 1)}), flush=True)
+            for p in (pA, pB, pC):
+                ctx.free(p)
+            plan.close()
+
+if __name__ == "__main__":
+    main()
