@@ -62,7 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c3L", choices=["c3L", "c3T", "c3Td", "c2L", "c2T", "c4L", "c5TF", "c5B", "c5L", "reduce", "long_k", "w16", "u8"])
+    ap.add_argument("--workload", default="c3L", choices=["c3L", "c3T", "c3Td", "c2L", "c2T", "c4L", "c5TF", "c5B", "c5L", "reduce", "long_k", "w16", "u8", "w32T"])
     ap.add_argument("--size", type=int, default=4096, help="M=N=K per GPU of the primary workload")
     ap.add_argument("--backend", default="rccl", help="transport of the gather for N > 1: rccl (the library's communicator) or host (rehearsal on a box with fewer GPUs than ranks: packed bands through host memory + TCP)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the collective path even with one rank (the RCCL calls on a 1-GPU box)")
@@ -151,6 +151,8 @@ def workloads():
                     text="4096^3 Qgemul int<7,8> signed (16-bit words), linear class: operands stored centred (x - 128) in 2 x 2 int8 limbs instead of 3 x 3"),
         "u8": dict(a=Qu(8, 0, False), b=Qu(8, 0, False), c=Qu(28, 0, False), mul=Tags(16, 0, False), add=[Qu(28, 0, False)], cfg="unsigned bytes, the size of configs[2]", ref=None,
                    text="4096^3 Qgemul of unsigned 8-bit integers with exact sums, linear class: operands stored centred (x - 128) in ONE int8 limb, the centres restored in the kernel epilogue"),
+        "w32T": dict(a=Qu(15, 16), b=Qu(15, 16), c=Qu(15, 16), mul=None, add=None, cfg="32-bit words (Q15.16), default tags", ref=None,
+                     text="2048^3 Qgemul int<15,16> signed (32-bit words) with the reference's default modes and default tags (tree class): exact 64-bit products, one saturating 32-bit add per node"),
         "long_k": dict(a=e88z, b=e88z, c=Qu(33, 16), mul=Tags(17, 16), add=[Qu(33, 16)], cfg="configs[2] operands, K = 65536 (beyond one MFMA launch's exact int32 range)", ref=None,
                        text="4096x4096x65536 Qgemul int<8,8> signed, linear class: 2 k-chunks on the 3x3 int8-limb MFMA kernel + exact combine pass"),
     }
@@ -158,7 +160,7 @@ def workloads():
 
 SHAPES = {"c3L": (4096, 4096, 4096), "c3T": (4096, 4096, 4096), "c3Td": (4096, 4096, 4096), "c2L": (1024, 1024, 1024), "c2T": (1024, 1024, 1024),
           "c4L": (16384, 16384, 4096), "c5TF": (2048, 2048, 2048), "c5B": (2048, 2048, 2048), "c5L": (2048, 2048, 2048), "reduce": (65536, 1, 4096),
-          "long_k": (4096, 4096, 65536), "w16": (4096, 4096, 4096), "u8": (4096, 4096, 4096)}
+          "long_k": (4096, 4096, 65536), "w16": (4096, 4096, 4096), "u8": (4096, 4096, 4096), "w32T": (2048, 2048, 2048)}
 REDUCE_TEXT = "batched Qreduce: 65536 vectors of 4096 int<8,8> elements (TRN::TCPL / SAT::ZERO), every tree node quantised; one wave per row"
 
 
@@ -515,7 +517,7 @@ def main(argv=None):
 
     # setup, untimed: bring the card to its steady clock before the W warm-up steps (the first few hundred ms of MFMA work
     # after an idle period run on a ramping clock, tools/launch_gap.py)
-    slow = name in ("c3T", "c3Td", "c5TF", "c5B", "long_k")
+    slow = name in ("c3T", "c3Td", "c5TF", "c5B", "long_k", "w32T")
     PREWARM = max(0, args.prewarm) if not slow else min(max(0, args.prewarm), 20)
     for _ in range(PREWARM):
         plan.execute(tCs[0], tA, tB)
@@ -615,7 +617,7 @@ def main(argv=None):
             lb.free()
         except Exception as e:
             out["layout_steps"] = {"error": str(e)}
-        for nm, iters in (("c3T", 10), ("c3Td", 10), ("c2L", 200), ("c2T", 20), ("c5TF", 10), ("c5B", 10), ("c5L", 50), ("reduce", 50), ("long_k", 5), ("w16", 50), ("u8", 50)):
+        for nm, iters in (("c3T", 10), ("c3Td", 10), ("c2L", 200), ("c2T", 20), ("c5TF", 10), ("c5B", 10), ("c5L", 50), ("reduce", 50), ("long_k", 5), ("w16", 50), ("u8", 50), ("w32T", 10)):
             if nm == name:
                 continue
             try:

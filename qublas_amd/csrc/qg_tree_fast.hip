@@ -261,6 +261,8 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
     for (int l = 0; l < 4; ++l) flow[l] = tab->fadd[0][l];
     // MODE 6 (QTreeTable::lj): shift of the justified values, their mask, the product's scaled rounding addend, the operands' factors
     const int w_d = MODE == 17 ? tab->lj.s : 0, w_t = MODE == 17 ? tab->lj.t[0] : 0;   // MODE 17 (32-bit words): the product's shift and rounding addend
+    unsigned w_half = MODE == 17 ? 1u << ((w_d - 1) & 31) : 0u, w_lim = MODE == 17 ? 1u << (w_d & 31) : 0u;
+    if (MODE == 17) asm volatile("" : "+s"(w_lim));   // (opaque: the compiler would rewrite "x < 2^d" as a shift and a compare with 0 — one instruction more per product)
     constexpr bool LJ = MODE == 6 || MODE == 16;   // (16: the unsigned counterpart — uint32 range, v_mad_u32_u24 / v_add_u32 ... clamp)
     const int lj_s = LJ ? tab->lj.s : 0, lj_mask = LJ ? (int)(~0u << lj_s) : -1, lj_t = LJ ? tab->lj.t[0] : 0;
     const int lj_ea = LJ ? tab->lj.e[0] : 0, lj_eb = LJ ? tab->lj.e[1] : 0;
@@ -327,9 +329,13 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
                             for (int j = 0; j < 2; ++j) {
-                                const long long q = ((long long)av[i] * (long long)bhv[j] + (long long)w_t) >> w_d;
-                                const int ql = (int)q, qh = (int)(q >> 32);
-                                v[i * 2 + j] = qh == (ql >> 31) ? ql : ((qh >> 31) ^ 0x7fffffff);   // (in range: the high word is the low word's sign)
+                                // all in 32-bit instructions behind the one v_mad_i64_i32 (the compiler turns a 64-bit shift + clamp into
+                                // v_ashrrev_i64 and two v_cmp_*_i64): the word is v_alignbit of the product's halves, and it is in range
+                                // iff the high half lies in [-2^(d-1), 2^(d-1)) — one add, one unsigned compare (1 <= d <= 31, qg_plan.cpp)
+                                const long long p = (long long)av[i] * (long long)bhv[j] + (long long)w_t;
+                                const int ph = (int)(p >> 32);
+                                const int ql = (int)__builtin_amdgcn_alignbit((unsigned)ph, (unsigned)p, (unsigned)w_d);
+                                v[i * 2 + j] = (unsigned)ph + w_half < w_lim ? ql : ((ph >> 31) ^ 0x7fffffff);
                             }
                     } else if (LJ) {
 #pragma unroll

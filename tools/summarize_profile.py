@@ -48,7 +48,7 @@ def main():
         rows = list(csv.DictReader(open(stats)))
         top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
         name = top["Name"]
-        steps = 10 if wl in ("c3T", "c3Td", "c5TF", "c5B", "long_k") else 200
+        steps = 10 if wl in ("c3T", "c3Td", "c5TF", "c5B", "long_k", "w32T") else 200
         out = {"workload": wl, "kernel": name, "calls": int(top["Calls"]), "mean_us": float(top["AverageNs"]) / 1e3,
                "min_us": float(top["MinNs"]) / 1e3, "max_us": float(top["MaxNs"]) / 1e3,
                "command": f"rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --steps {steps} --warmup 5 --no-extra --no-cpu"}
