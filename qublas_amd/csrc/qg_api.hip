@@ -353,8 +353,11 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
         }
     } else {
         const bool fast = !(flags & QG_OPT_GENERIC_TREE);
+        // 32-bit words on the one-column kernel (QAnalysis::gemv_w32): rows of at least 256 leaves; like fast_mode 10 it has no
+        // run-time-mode form, QG_OPT_RUNTIME_MODES keeps the 64-bit-value form (the tests' second opinion)
+        const bool gemv_w32 = an->gemv_wide_ok && an->gemv_w32 && !(flags & QG_OPT_RUNTIME_MODES) && an->tree.n_levels_k >= 8;
         kernel = an->wide ? QG_KERNEL_TREE_I128 : d->is_complex ? ((an->cplx_fast_ok && fast) ? QG_KERNEL_TREE_CPLX_I32 : QG_KERNEL_TREE_CPLX)
-                               : ((an->gemv_ok && fast) ? QG_KERNEL_GEMV_I32 : (an->gemv_wide_ok && fast) ? QG_KERNEL_GEMV_I64
+                               : (((an->gemv_ok || gemv_w32) && fast) ? QG_KERNEL_GEMV_I32 : (an->gemv_wide_ok && fast) ? QG_KERNEL_GEMV_I64
                                   : (an->tree_fast_ok && fast && !(an->fast_mode == 10 && (flags & QG_OPT_RUNTIME_MODES))) ? QG_KERNEL_TREE_I32 : QG_KERNEL_TREE_I64);   // (fast_mode 10, 32-bit words: no run-time-mode form on that kernel)
         // the 32-bit tree kernels walk a perfect binary tree: their operands are zero-padded along K to 2^n_levels leaves
         // (a node whose right child is a zero leaf / zero subtree is the reference's converting copy of an odd leftover)
@@ -380,7 +383,7 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     if (kernel == QG_KERNEL_GEMV_I32) {
         const int fm = (flags & QG_OPT_RUNTIME_MODES) ? 0 : an->gemv_fixed;
         snprintf(info->reason, sizeof info->reason, "exact tree evaluation; one-column kernel steps: %s",
-                 fm == 1 ? "one format, SAT::ZERO" : fm == 2 ? "one format, SAT::TCPL" : fm == 3 ? "per-level formats, compact (clamps)" : fm == 5 ? "per-level formats, compact" : "run-time modes");
+                 fm == 1 ? "one format, SAT::ZERO" : fm == 2 ? "one format, SAT::TCPL" : fm == 3 ? "per-level formats, compact (clamps)" : fm == 5 ? "per-level formats, compact" : fm == 6 ? "one 32-bit format, SAT::TCPL, saturating word adds" : "run-time modes");
     }
     if (kernel == QG_KERNEL_TREE_CPLX_I32) {
         // which form of the complex kernel's steps this descriptor gets (tests assert their coverage through it)

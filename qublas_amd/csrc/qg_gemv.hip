@@ -20,6 +20,7 @@
 // vectors are re-read per segment from L2.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "qg_kernels.h"
 #include "qg_fix.h"
@@ -77,6 +78,7 @@ __device__ __forceinline__ void node_all(T (&acc)[N], const T (&x)[N], CTab tab,
 template <int MODE>
 __device__ __forceinline__ int node_fixed(int a, int b, int lo, int hi)
 {
+    if (MODE == 6) return sat_add(a, b);   // 32-bit words (QAnalysis::gemv_w32): the format's range IS the int32 range — one v_add_i32 ... clamp
     const int t = a + b;
     if (MODE == 1) return ((unsigned)(t - lo) > (unsigned)(hi - lo)) ? 0 : t;
     return qg_clamp_i32(t, lo, hi);
@@ -110,7 +112,7 @@ __device__ __forceinline__ T lane_tree(T (&v)[CNT], CTab tab, int level, int lo,
 #pragma unroll
             for (int o = 0; o < CNT / 2; ++o) h[o] = v[2 * o] + v[2 * o + 1];   // left child + right child, in the tree's order
             qg_step_all<T, CNT / 2>(h, load_step(&tab->level_add[0][level].q));
-        } else if constexpr (MODE >= 3) {
+        } else if constexpr (MODE == 3 || MODE == 5) {
             int r[CNT / 2];
 #pragma unroll
             for (int o = 0; o < CNT / 2; ++o) { h[o] = v[2 * o]; r[o] = v[2 * o + 1]; }
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
             for (int i = 0; i < 6; ++i) {
                 T y[1] = {__shfl_down(x[0], 1 << i)};
                 if constexpr (MODE == 0) node_all<1, T>(x, y, tab, Q + i);
-                else if constexpr (MODE >= 3) node_rec<MODE, 1>(x, y, g.tab, Q + i);
+                else if constexpr (MODE == 3 || MODE == 5) node_rec<MODE, 1>(x, y, g.tab, Q + i);
                 else x[0] = node_fixed<MODE>(x[0], y[0], flo, fhi);
             }
             // x[0] in lane 0 = the segment's node of level Q + 6; carry it into the counter
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
                     T l[1] = {up[u]};
                     node_all<1, T>(l, x, tab, base + u);
                     x[0] = l[0];
-                } else if constexpr (MODE >= 3) {
+                } else if constexpr (MODE == 3 || MODE == 5) {
                     int l[1] = {up[u]};
                     node_rec<MODE, 1>(l, x, g.tab, base + u);
                     x[0] = l[0];
@@ -239,13 +241,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
                 }
             }
         }
-        T r[1] = {root};
-        qg_step_all<T, 1>(r, c_cvt);
+        typename std::conditional<MODE == 6, int64_t, T>::type r[1] = {root};   // (MODE 6: a rounding addend on a full 32-bit word needs the 64-bit step)
+        qg_step_all<typename std::conditional<MODE == 6, int64_t, T>::type, 1>(r, c_cvt);
         if (lane == 0) {
             switch (g.cbytes) {
             case 1: ((int8_t*)g.C)[row] = (int8_t)r[0]; break;
             case 2: ((int16_t*)g.C)[row] = (int16_t)r[0]; break;
-            case 4: ((int32_t*)g.C)[row] = r[0]; break;
+            case 4: ((int32_t*)g.C)[row] = (int32_t)r[0]; break;
             default: ((int64_t*)g.C)[row] = (int64_t)r[0]; break;
             }
         }
@@ -407,6 +409,7 @@ hipError_t launch_gemv(const QGemvArgs& g, hipStream_t st)
         if (g.pad_ == 2) return launch_gemv<CH, 2>(g, st);
         if (g.pad_ == 3) return launch_gemv<CH, 3>(g, st);
         if (g.pad_ == 5) return launch_gemv<CH, 5>(g, st);
+        if (g.pad_ == 6) return launch_gemv<CH, 6>(g, st);
     }
     constexpr int IMG = 64 * (CH * 4 + 16);
     const int64_t nseg = g.K / (64 * CH);
@@ -438,6 +441,7 @@ hipError_t qg_launch_gemv(const QTreeTable* dev_table, int n_levels, int b_is_bi
         default: return launch_gemv_short_wide<128>(g, st);
         }
     }
+    if (fixed_mode == 6 && K < 256) return hipErrorInvalidValue;   // (32-bit words: long rows only — qg_api.hip keeps short rows on the 64-bit form)
     switch (K) {
     case 16: return launch_gemv_short<16>(g, st);
     case 32: return launch_gemv_short<32>(g, st);

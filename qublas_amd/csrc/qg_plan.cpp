@@ -799,8 +799,8 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     if (!out->tree_fast_ok && !cx && !out->wide && !out->generic_only && d->n_levels <= 16 && T.n_levels_k <= 16) {
         const QStep& pq = T.mul[0].q;
         const int bitsA = 1 + (int)d->a[0].I + (int)d->a[0].F, bitsB = 1 + (int)d->b[0].I + (int)d->b[0].F;
-        bool w32 = !pq.identity && pq.O == QG_SAT_TCPL && pq.S && pq.lo == -((int64_t)1 << 31) && pq.hi == ((int64_t)1 << 31) - 1 && pq.d >= 1 && pq.d <= 31 &&   // (d = 0: the kernel's range test of the high half has no form)
-                   (pq.Q == QG_TRN_TCPL || pq.Q == QG_RND_POS_INF || pq.Q == QG_RND_NEG_INF) && bitsA <= 32 && bitsB <= 32 &&
+        bool w32 = !pq.identity && pq.O == QG_SAT_TCPL && pq.S && pq.lo == -((int64_t)1 << 31) && pq.hi == ((int64_t)1 << 31) - 1 && pq.d >= 0 && pq.d <= 31 &&
+                   (pq.d == 0 || pq.Q == QG_TRN_TCPL || pq.Q == QG_RND_POS_INF || pq.Q == QG_RND_NEG_INF) && bitsA <= 32 && bitsB <= 32 &&
                    (d->a[0].S || bitsA <= 31) && (d->b[0].S || bitsB <= 31);   // (elements are int32 words in the packed operands)
         for (uint32_t l = 0; l < (uint32_t)T.n_levels_k && w32; ++l) {
             const QStep& q = T.level_add[0][l].q;
@@ -835,7 +835,23 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         if (smgn) leaf.O = QG_SAT_TCPL;
         out->gemv_b_bit = ((out->gemv_ok || out->gemv_wide_ok) && d->b[0].I == 1 && d->b[0].F == 0 && !d->b[0].S && same(d->mul[0], leaf)) ? 1 : 0;
     }
-    out->gemv_fixed = 0;
+    // 32-bit words in the one-column kernel (a Qreduce / GEMV of Q15.16 with default levels): the values fit the element
+    // registers and a node is one v_add_i32 ... clamp; the 64-bit-value form of the same kernel spends a 64-bit add and a
+    // run-time step per node (65 536 x 4096: 7.6 ms where the bytes take 0.2).  The product is formed in 64 bits by the
+    // general step (or not at all: gemv_b_bit), so any rounding / overflow pair into a format of at most 32 bits will do.
+    out->gemv_w32 = 0;
+    if (out->gemv_wide_ok && d->n_levels >= 1) {
+        const int bitsM = (d->mul[0].S ? 1 : 0) + (int)d->mul[0].I + (int)d->mul[0].F;
+        bool w32 = bitsM <= (d->mul[0].S ? 32 : 31) && (int)d->mul[0].I + (int)d->mul[0].F >= 0;
+        for (uint32_t l = 0; l < (uint32_t)T.n_levels_k && w32; ++l) {
+            const QStep& q = T.level_add[0][l].q;
+            const bool pad = (int)l >= T.n_levels && q.identity;
+            w32 = T.level_cvt[0][l].identity && T.level_add[0][l].sa == 0 && T.level_add[0][l].sb == 0 &&
+                  (pad || (!q.identity && q.O == QG_SAT_TCPL && q.S && q.d == 0 && q.lo == -((int64_t)1 << 31) && q.hi == ((int64_t)1 << 31) - 1));
+        }
+        out->gemv_w32 = w32 ? 1 : 0;
+    }
+    out->gemv_fixed = out->gemv_w32 ? 6 : 0;   // (6: only with gemv_wide_ok, i.e. never together with the forms below)
     if (out->gemv_ok) {
         // all levels one format (the product's), exact alignment (d == 0), SAT::ZERO or SAT::TCPL
         const qfmt lf = d->level_add[0][0];

@@ -87,6 +87,7 @@ struct QAnalysis {
     int gemv_ok;             // the one-column 32-bit tree kernel applies (N = 1, K = 2^p >= 16)
     int gemv_wide_ok;        // ... or its 64-bit-value form: elements of at most 32 storage bits, wider sums / level types
     int gemv_fixed;          // 1 / 2: every tree level has one format, no rounding shift, SAT::ZERO / SAT::TCPL (fixed-mode nodes); 3 / 5: per-level formats in compact records
+    int gemv_w32;            // gemv_wide_ok descriptors whose product and every level live in ONE signed SAT::TCPL format of exactly 32 bits: values stay 32-bit words, a node is one saturating add (k_gemv<., 6>)
     int gemv_b_bit;          // ... and B is a 0/1 vector whose product with a is a itself (the Qreduce lowering)
     int wide;                // an intermediate, a level / product format or C needs more than 62 bits: 128-bit kernels (qg_ops.h: qg_step_w)
     int generic_only;        // C's WRP::TCPL_SAT can let the root through unclamped: the general kernels / the composite plan's combine pass only

@@ -166,7 +166,8 @@ def test_one_column_64_bit_values(oracle):
         for rows, K in ((300, 16), (37, 64), (700, 128), (9, 256), (41, 1024), (5, 8192)):
             d = lower_reduce(e, rows, K, levels)
             info = capi.classify(d)
-            assert capi.KERNEL_NAMES[info.kernel] == "gemv_i64", (str(e), K, info.reason)
+            w32 = e is q and levels is None and K >= 256      # (every node in the 32-bit word itself: test_one_column_32_bit_words)
+            assert capi.KERNEL_NAMES[info.kernel] == ("gemv_i32" if w32 else "gemv_i64"), (str(e), K, info.reason)
             ec = reduce_result_type(e, levels or [], K)
             A = oracle.fill(e, rows * K, 21, 0)
             A[:2] = e.raw_min
@@ -181,3 +182,50 @@ def test_one_column_64_bit_values(oracle):
         got = capi.run(d, np.zeros(130, dtype=oracle.host_dtype(Qu(28, 12))), A, B)
         assert np.array_equal(got, oracle.gemm(d, A, B, Qu(28, 12)))
 
+
+
+@pytest.mark.parametrize("K", [256, 300, 1024, 4096, 5000, 65536])
+def test_one_column_32_bit_words(oracle, K):
+    """Qreduce / GEMV on 32-bit words — Q15.16, Q31, int32 with default levels: product and every node in ONE signed SAT::TCPL
+    format of exactly 32 bits.  The values stay 32-bit words and a node is one saturating add (`k_gemv<., 6>`, rows of at least
+    256 leaves) where the 64-bit-value form spent a 64-bit add and a run-time step per node.  Against the oracle with full-range
+    elements (the sums saturate, in the tree's own order) and small ones (they do not), and against the 64-bit-value form the
+    same descriptor takes under QG_OPT_RUNTIME_MODES."""
+    from qublas_amd.desc import reduce_result_type
+    rows = 333 if K <= 5000 else 21
+    form = "saturating word adds"
+    for e in (Qu(15, 16), Qu(0, 31), Qu(31, 0)):
+        d = lower_reduce(e, rows, K)
+        info = capi.classify(d)
+        assert capi.KERNEL_NAMES[info.kernel] == "gemv_i32" and info.reason.decode().endswith(form), (str(e), info.reason)
+        assert capi.KERNEL_NAMES[capi.classify(d, capi.OPT_RUNTIME_MODES).kernel] == "gemv_i64"
+        ec = reduce_result_type(e, [], K)
+        ones = np.ones(K, dtype=np.int32)
+        for dist in (0, 1, 2):
+            A = oracle.fill(e, rows * K, 31 + dist, dist % 2)
+            if dist == 2:
+                A = (A >> 13).astype(A.dtype)
+            A[:2] = e.raw_min
+            A[K:K + 2] = e.raw_max
+            got = capi.run(d, np.zeros(rows, dtype=oracle.host_dtype(ec)), A, ones)
+            exp = oracle.gemm(d, A, ones, ec, nthreads=8)
+            assert np.array_equal(got, exp), (str(e), K, dist)
+            assert np.array_equal(capi.run(d, np.zeros(rows, dtype=oracle.host_dtype(ec)), A, ones, flags=capi.OPT_RUNTIME_MODES), exp)
+        # a 0/1 mask instead of all ones
+        mask = (np.arange(K) % 3 != 0).astype(np.int32)
+        A = oracle.fill(e, rows * K, 40, 0)
+        assert np.array_equal(capi.run(d, np.zeros(rows, dtype=oracle.host_dtype(ec)), A, mask), oracle.gemm(d, A, mask, ec, nthreads=8))
+    # GEMVs: B a vector of elements, the product rounded into the word (several roundings, shifts 16 / 31 / 4), C of other widths
+    q = Qu(15, 16)
+    for ea, eb, ec, kw in ((q, q, q, {}), (Qu(0, 31), Qu(0, 31), Qu(0, 31), {}),
+                           (q, q, Qu(9, 3, True, RND.CONV, SAT.SMGN), dict(mul_args=Qu(15, 16, True, RND.POS_INF, SAT.TCPL), add_args=[q])),
+                           (Qu(8, 12), Qu(4, 8), Qu(20, 11), dict(mul_args=Qu(15, 16, True, RND.CONV, SAT.ZERO), add_args=[q]))):
+        d = lower(ea, eb, ec, 130, 1, K, **kw)
+        info = capi.classify(d)
+        assert capi.KERNEL_NAMES[info.kernel] == "gemv_i32" and info.reason.decode().endswith(form), (str(ea), info.reason)
+        for dist in (0, 1):
+            A, B = oracle.fill(ea, 130 * K, 5, dist), oracle.fill(eb, K, 6, dist)
+            got = capi.run(d, np.zeros(130, dtype=oracle.host_dtype(ec)), A, B)
+            exp = oracle.gemm(d, A, B, ec, nthreads=8)
+            assert np.array_equal(got, exp), (str(ea), str(ec), K, dist)
+            assert np.array_equal(capi.run(d, np.zeros(130, dtype=oracle.host_dtype(ec)), A, B, flags=capi.OPT_RUNTIME_MODES), exp)

@@ -265,15 +265,16 @@ def test_32_bit_fixed_point_words(oracle):
     operands incl. the raw minimum, several modes."""
     q = Qu(15, 16)
     cases = [
-        (q, q, q, dict(), "tree_i32"),                                                                     # default tags: every product and node saturates (the 32-bit-word form)
-        (q, q, Qu(24, 16, True, RND.CONV, SAT.SMGN), dict(add_args=[Qu(24, 16), Qu(28, 12, True, RND.ZERO, SAT.ZERO)]), "tree_i64"),
-        (Qu(20, 11, True, TRN.SMGN, WRP.TCPL), Qu(3, 28), Qu(20, 11), dict(mul_args=Tags(20, 11)), "tree_i32"),   # product and levels Qu<20,11>: a 32-bit word too (product shift 28)
-        (q, Qu(15, 16, False), Qu(18, 13), dict(), "tree_i64"),                                          # signed 32 x unsigned 31 bits
+        (q, q, q, dict(), "tree_i32", "gemv_i32"),                                                                     # default tags: every product and node saturates (the 32-bit-word form)
+        (q, q, Qu(24, 16, True, RND.CONV, SAT.SMGN), dict(add_args=[Qu(24, 16), Qu(28, 12, True, RND.ZERO, SAT.ZERO)]), "tree_i64", "gemv_i64"),
+        (Qu(20, 11, True, TRN.SMGN, WRP.TCPL), Qu(3, 28), Qu(20, 11), dict(mul_args=Tags(20, 11)), "tree_i32", "gemv_i32"),   # product and levels Qu<20,11>: a 32-bit word too (product shift 28)
+        (q, Qu(15, 16, False), Qu(18, 13), dict(), "tree_i64", "gemv_i32"),                                          # signed 32 x unsigned 31 bits
     ]
-    for ea, eb, ec, kw, kern in cases:
+    for ea, eb, ec, kw, kern, col in cases:      # (col: the one-column kernel; 32-bit words there: tests/test_gpu_gemv.py)
         for M, N, K, ta in ((37, 29, 64, False), (16, 40, 300, True), (50, 1, 1024, False)):
             d = lower(ea, eb, ec, M, N, K, transposed_a=ta, **kw)
-            assert capi.KERNEL_NAMES[capi.classify(d).kernel] == ("gemv_i64" if N == 1 else kern)
+            # (one column: the one-column kernels — 32-bit words there too when the tree kernel has them, tests/test_gpu_gemv.py)
+            assert capi.KERNEL_NAMES[capi.classify(d).kernel] == (col if N == 1 else kern)
             A, B = oracle.fill(ea, M * K, 3, 0), oracle.fill(eb, K * N, 4, 0)
             A[:2] = ea.raw_min
             B[:2] = eb.raw_min                                                                            # (-2^31) * (-2^31) = 2^62 is present
@@ -387,12 +388,8 @@ def test_32_bit_word_tree_form(oracle, K):
              (Qu(8, 12), Qu(4, 8), q, dict(mul_args=Qu(15, 16, True, RND.NEG_INF, SAT.TCPL), add_args=[q])),
              (Qu(20, 11), Qu(20, 11), Qu(20, 11), {}), (Qu(2, 29), Qu(2, 29), Qu(9, 3, True, RND.CONV, SAT.SMGN), {}),
              (Qu(15, 15, False), q, q, dict(mul_args=q, add_args=[q])),
-             (Qu(0, 31), Qu(0, 31), Qu(0, 31), {}), (Qu(30, 1), Qu(30, 1), Qu(30, 1), {})]            # (Q31: product shift 31; shift 1)
-    i32 = Qu(31, 0)                                                                                    # product shift 0: not this form (the 64-bit kernel)
-    d = lower(i32, i32, i32, 33, 17, K)
-    assert capi.KERNEL_NAMES[capi.classify(d).kernel] == "tree_i64"
-    A, B = oracle.fill(i32, 33 * K, 5, 0), oracle.fill(i32, K * 17, 6, 1)
-    assert np.array_equal(run_gpu(d, A, B, i32, oracle), oracle.gemm(d, A, B, i32, nthreads=8))
+             (Qu(0, 31), Qu(0, 31), Qu(0, 31), {}), (Qu(30, 1), Qu(30, 1), Qu(30, 1), {}),            # (Q31: product shift 31; shift 1)
+             (Qu(20, 0), Qu(24, 0), Qu(31, 0), dict(mul_args=Qu(31, 0), add_args=[Qu(31, 0)]))]                                                     # (integers: no shift at all)
     assert capi.KERNEL_NAMES[capi.classify(lower(q, q, Qu(20, 12), 33, 17, K)).kernel] == "tree_i64"     # a C beyond 32 bits: the 64-bit kernel's conversion
     for ea, eb, ec, kw in cases:
         for M, N in ((33, 17), (1, 3), (70, 41)):

@@ -23,5 +23,29 @@ def main():
                 ctx.free(p)
             plan.close()
 
+def reduce_part():
+    """batched Qreduce of 65 536 vectors of 4096 Q15.16 elements (1 GiB of elements): the 32-bit-word form of the one-column kernel
+    against its 64-bit-value form (QG_OPT_RUNTIME_MODES), and a Q15.16 GEMV of the same size"""
+    from qublas_amd.desc import lower_reduce
+    q = Qu(15, 16)
+    M, K = 65536, 4096
+    with capi.Context(0) as ctx:
+        for name, d in (("Qreduce Q15.16 65536 x 4096", lower_reduce(q, M, K)), ("GEMV Q15.16 65536 x 4096", lower(q, q, q, M, 1, K))):
+            for flags in (0, capi.OPT_RUNTIME_MODES):
+                plan = capi.Plan(ctx, d, flags)
+                pb = plan.info.packed_bytes
+                pA, pB, pC = ctx.alloc(pb[0]), ctx.alloc(pb[1]), ctx.alloc(pb[2])
+                plan.fill(capi.OPERAND_A, 1, 0, pA)
+                plan.fill(capi.OPERAND_B, 2, 0, pB)
+                plan.time_execute(pC, pA, pB, 1, 3)
+                ms = plan.time_execute(pC, pA, pB, 1, 10)
+                print(json.dumps({"case": name, "kernel": capi.KERNEL_NAMES[plan.info.kernel], "reason": plan.info.reason.decode(), "ms": round(ms, 4),
+                                  "TBps_of_elements": round(M * K * 4 / (ms * 1e-3) / 1e12, 2)}), flush=True)
+                for p in (pA, pB, pC):
+                    ctx.free(p)
+                plan.close()
+
+
 if __name__ == "__main__":
+    reduce_part()
     main()
