@@ -62,7 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c3L", choices=["c3L", "c3T", "c3Td", "c2L", "c2T", "c4L", "c5TF", "c5B", "c5L", "reduce", "long_k", "w16", "u8", "w32T"])
+    ap.add_argument("--workload", default="c3L", choices=["c3L", "c3T", "c3Td", "c2L", "c2T", "c4L", "c5TF", "c5B", "c5L", "reduce", "long_k", "w16", "u8", "w32T", "reduceW"])
     ap.add_argument("--size", type=int, default=4096, help="M=N=K per GPU of the primary workload")
     ap.add_argument("--backend", default="rccl", help="transport of the gather for N > 1: rccl (the library's communicator) or host (rehearsal on a box with fewer GPUs than ranks: packed bands through host memory + TCP)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the collective path even with one rank (the RCCL calls on a 1-GPU box)")
@@ -160,14 +160,17 @@ def workloads():
 
 SHAPES = {"c3L": (4096, 4096, 4096), "c3T": (4096, 4096, 4096), "c3Td": (4096, 4096, 4096), "c2L": (1024, 1024, 1024), "c2T": (1024, 1024, 1024),
           "c4L": (16384, 16384, 4096), "c5TF": (2048, 2048, 2048), "c5B": (2048, 2048, 2048), "c5L": (2048, 2048, 2048), "reduce": (65536, 1, 4096),
-          "long_k": (4096, 4096, 65536), "w16": (4096, 4096, 4096), "u8": (4096, 4096, 4096), "w32T": (2048, 2048, 2048)}
+          "long_k": (4096, 4096, 65536), "w16": (4096, 4096, 4096), "u8": (4096, 4096, 4096), "w32T": (2048, 2048, 2048), "reduceW": (65536, 1, 4096)}
 REDUCE_TEXT = "batched Qreduce: 65536 vectors of 4096 int<8,8> elements (TRN::TCPL / SAT::ZERO), every tree node quantised; one wave per row"
+REDUCEW_TEXT = "batched Qreduce: 65536 vectors of 4096 int<15,16> elements (32-bit words, default modes), every tree node one saturating 32-bit add; one wave per row"
 
 
 def make_desc(name, wls, M, N, K):
     from qublas_amd.desc import Qu, SAT, TRN, lower, lower_reduce
     if name == "reduce":
         return lower_reduce(Qu(8, 8, True, TRN.TCPL, SAT.ZERO), M, K)
+    if name == "reduceW":
+        return lower_reduce(Qu(15, 16), M, K)
     wl = wls[name]
     return lower(wl["a"], wl["b"], wl["c"], M, N, K, mul_args=wl["mul"], add_args=wl["add"])
 
@@ -256,7 +259,7 @@ def roofline_block(name, info, M, N, K, kms, singles, capi, cb):
     in_bytes = lambda bits: max(1, (bits + 7) // 8)
     parts = 2 if kernel.startswith("tree_cplx") or kernel == "mfma_cplx" else 1
     alg_bytes = int((M * K * in_bytes(info.in_bits[0]) + K * N * in_bytes(info.in_bits[1]) + M * N * cb) * parts)
-    if name == "reduce":
+    if name in ("reduce", "reduceW"):
         alg_bytes = int(4 * M * K + M * cb)       # the one-column kernels read 4-byte packed leaves once
     prof, why = profmeta.lookup(name, kernel, reason)
     r = {"kernel": kernel, "kernel_form": reason, "kernel_ms": kms, "kernel_ms_median_of_single_launches": singles[len(singles) // 2] if singles else None,
@@ -306,13 +309,13 @@ def measure_config(ctx, name, wls, capi, iters, flags=0):
         b = p.info.packed_bytes
         xa, xb, xc = bufs.alloc(b[0]), bufs.alloc(b[1]), bufs.alloc(b[2])
         p.fill(capi.OPERAND_A, 1, 0, xa)
-        if name == "reduce":
+        if name in ("reduce", "reduceW"):
             import numpy as np
             ctx.h2d(xb, np.ones(int(b[1]) // 4, np.int32))       # the Qreduce lowering's vector of ones
         else:
             p.fill(capi.OPERAND_B, 2, 0, xb)
         ms, singles = timed(p, xc, xa, xb, iters)
-        rec = {"config": wls[name]["cfg"] if name in wls else "SURVEY.md 8-f #1", "workload": wls[name]["text"] if name in wls else REDUCE_TEXT, "M": M, "N": N, "K": K,
+        rec = {"config": wls[name]["cfg"] if name in wls else "SURVEY.md 8-f #1", "workload": wls[name]["text"] if name in wls else (REDUCEW_TEXT if name == "reduceW" else REDUCE_TEXT), "M": M, "N": N, "K": K,
                "launches_timed": iters, "value": float(p.info.ops) / (ms * 1e-3),
                "unit": "int-op/s (algorithmic: 2*M*N*K real, 6 / 8 M*N*K complex TF / Basic)", "class": "linear" if p.info.cls == 1 else "tree",
                "roofline": roofline_block(name, p.info, M, N, K, ms, singles, capi, c_container_bytes(wls[name]["c"]) if name in wls else 4)}
@@ -486,7 +489,7 @@ def main(argv=None):
     tCs = [bufs.alloc(pb[2]) for _ in range(2 if use_dist else 1)]   # the gather of step i travels while the GEMM of step i+1 runs
     tC = tCs[0]
     plan.fill(capi.OPERAND_A, 1 + 1000 * rank, 0, tA)   # rank r's rows of A: a distinct seed stream
-    if name == "reduce":
+    if name in ("reduce", "reduceW"):
         ctx.h2d(tB, np.ones(int(pb[1]) // 4, np.int32))
     else:
         plan.fill(capi.OPERAND_B, 2, 0, tB)
@@ -543,7 +546,7 @@ def main(argv=None):
         singles = sorted(plan.time_execute(tC, tA, tB, 0, 1) for _ in range(30))
         roof = roofline_block(name, info, M, N, K, kms, singles, capi, c_container_bytes(wls[name]["c"]) if name in wls else 4)
         mfma = roof["bound"] == "mfma"
-        wtext = wls[name]["text"] if name in wls else REDUCE_TEXT
+        wtext = wls[name]["text"] if name in wls else (REDUCEW_TEXT if name == "reduceW" else REDUCE_TEXT)
         out = {"metric": "int-MAC/s (2*M*N*K/s) for Qgemul 4096^3 int<8,8>; % of MI355X int8 peak", "value": value,
                "unit": "int-op/s (2*M*N*K/s)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "ms_per_step_events": kms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -617,7 +620,7 @@ def main(argv=None):
             lb.free()
         except Exception as e:
             out["layout_steps"] = {"error": str(e)}
-        for nm, iters in (("c3T", 10), ("c3Td", 10), ("c2L", 200), ("c2T", 20), ("c5TF", 10), ("c5B", 10), ("c5L", 50), ("reduce", 50), ("long_k", 5), ("w16", 50), ("u8", 50), ("w32T", 10)):
+        for nm, iters in (("c3T", 10), ("c3Td", 10), ("c2L", 200), ("c2T", 20), ("c5TF", 10), ("c5B", 10), ("c5L", 50), ("reduce", 50), ("long_k", 5), ("w16", 50), ("u8", 50), ("w32T", 10), ("reduceW", 50)):
             if nm == name:
                 continue
             try:

@@ -383,7 +383,7 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     if (kernel == QG_KERNEL_GEMV_I32) {
         const int fm = (flags & QG_OPT_RUNTIME_MODES) ? 0 : an->gemv_fixed;
         snprintf(info->reason, sizeof info->reason, "exact tree evaluation; one-column kernel steps: %s",
-                 fm == 1 ? "one format, SAT::ZERO" : fm == 2 ? "one format, SAT::TCPL" : fm == 3 ? "per-level formats, compact (clamps)" : fm == 5 ? "per-level formats, compact" : fm == 6 ? "one 32-bit format, SAT::TCPL, saturating word adds" : "run-time modes");
+                 fm == 1 ? "one format, SAT::ZERO" : fm == 2 ? "one format, SAT::TCPL" : fm == 3 ? "per-level formats, compact (clamps)" : fm == 5 ? "per-level formats, compact" : (fm == 6 || fm == 7) ? "one 32-bit format, saturating adds" : "run-time modes");
     }
     if (kernel == QG_KERNEL_TREE_CPLX_I32) {
         // which form of the complex kernel's steps this descriptor gets (tests assert their coverage through it)

@@ -78,7 +78,7 @@ __device__ __forceinline__ void node_all(T (&acc)[N], const T (&x)[N], CTab tab,
 template <int MODE>
 __device__ __forceinline__ int node_fixed(int a, int b, int lo, int hi)
 {
-    if (MODE == 6) return sat_add(a, b);   // 32-bit words (QAnalysis::gemv_w32): the format's range IS the int32 range — one v_add_i32 ... clamp
+    if (MODE == 6 || MODE == 7) return sat_add(a, b);   // 32-bit words (QAnalysis::gemv_w32): the format's range IS the int32 range — one v_add_i32 ... clamp
     const int t = a + b;
     if (MODE == 1) return ((unsigned)(t - lo) > (unsigned)(hi - lo)) ? 0 : t;
     return qg_clamp_i32(t, lo, hi);
@@ -176,6 +176,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
     pnode.q = load_step(&tab->mul[0].q);
     const QStep c_cvt = load_step(&tab->c_cvt[0]);
     const int flo = (int)tab->level_add[0][0].q.lo, fhi = (int)tab->level_add[0][0].q.hi;   // MODE 1 / 2: the one level format
+    // MODE 7: the product's shift, its rounding addend (TRN::TCPL 0, RND::POS_INF 2^(d-1), RND::NEG_INF 2^(d-1) - 1) and the range test's constants
+    const int w_d = MODE == 7 ? pnode.q.d : 0;
+    const int w_t = MODE == 7 ? (pnode.q.Q == QG_RND_POS_INF ? 1 << ((w_d - 1) & 31) : pnode.q.Q == QG_RND_NEG_INF ? (1 << ((w_d - 1) & 31)) - 1 : 0) : 0;
+    unsigned w_half = MODE == 7 ? 1u << ((w_d - 1) & 31) : 0u, w_lim = MODE == 7 ? 1u << (w_d & 31) : 0u;
+    if (MODE == 7) asm volatile("" : "+s"(w_lim));   // (opaque: see k_tree_fast)
     for (; row < g.M; row += wstride) {
         T root = 0;
         for (int64_t s = 0; s < nseg; ++s) {
@@ -205,12 +210,24 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
                     v4i b;
                     if (b_in_lds) b = *(const v4i*)(bimg + lane * CHUNK + t * 16);
                     else b = *(const v4i*)(g.B + s * SEG + lane * CH + t * 4);
-                    int64_t p[4];
+                    if constexpr (MODE == 7) {
+                        // 32-bit words, product "add a constant, shift right by 1 ... 31, saturate to the word" (QAnalysis::gemv_fixed 7):
+                        // the steps of k_tree_fast<., 17> — v_mad_i64_i32, v_alignbit, range test of the high half, select
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) p[e] = (int64_t)a[e] * (int64_t)b[e];
-                    qg_step_all<int64_t, 4>(p, pnode.q);                          // Qmul: round + overflow into the product format
+                        for (int e = 0; e < 4; ++e) {
+                            const long long pr = (long long)a[e] * (long long)b[e] + (long long)w_t;
+                            const int ph = (int)(pr >> 32);
+                            const int ql = (int)__builtin_amdgcn_alignbit((unsigned)ph, (unsigned)pr, (unsigned)w_d);
+                            v[4 * t + e] = (unsigned)ph + w_half < w_lim ? ql : ((ph >> 31) ^ 0x7fffffff);
+                        }
+                    } else {
+                        int64_t p[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * t + e] = (T)p[e];
+                        for (int e = 0; e < 4; ++e) p[e] = (int64_t)a[e] * (int64_t)b[e];
+                        qg_step_all<int64_t, 4>(p, pnode.q);                          // Qmul: round + overflow into the product format
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * t + e] = (T)p[e];
+                    }
                 }
             }
             // across the lanes: level Q + i pairs lane j (left) with lane j + 2^i
@@ -241,8 +258,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv(QGemvArgs g)
                 }
             }
         }
-        typename std::conditional<MODE == 6, int64_t, T>::type r[1] = {root};   // (MODE 6: a rounding addend on a full 32-bit word needs the 64-bit step)
-        qg_step_all<typename std::conditional<MODE == 6, int64_t, T>::type, 1>(r, c_cvt);
+        typename std::conditional<MODE == 6 || MODE == 7, int64_t, T>::type r[1] = {root};   // (MODE 6 / 7: a rounding addend on a full 32-bit word needs the 64-bit step)
+        qg_step_all<typename std::conditional<MODE == 6 || MODE == 7, int64_t, T>::type, 1>(r, c_cvt);
         if (lane == 0) {
             switch (g.cbytes) {
             case 1: ((int8_t*)g.C)[row] = (int8_t)r[0]; break;
@@ -410,6 +427,7 @@ hipError_t launch_gemv(const QGemvArgs& g, hipStream_t st)
         if (g.pad_ == 3) return launch_gemv<CH, 3>(g, st);
         if (g.pad_ == 5) return launch_gemv<CH, 5>(g, st);
         if (g.pad_ == 6) return launch_gemv<CH, 6>(g, st);
+        if (g.pad_ == 7) return launch_gemv<CH, 7>(g, st);
     }
     constexpr int IMG = 64 * (CH * 4 + 16);
     const int64_t nseg = g.K / (64 * CH);
@@ -441,7 +459,7 @@ hipError_t qg_launch_gemv(const QTreeTable* dev_table, int n_levels, int b_is_bi
         default: return launch_gemv_short_wide<128>(g, st);
         }
     }
-    if (fixed_mode == 6 && K < 256) return hipErrorInvalidValue;   // (32-bit words: long rows only — qg_api.hip keeps short rows on the 64-bit form)
+    if ((fixed_mode == 6 || fixed_mode == 7) && K < 256) return hipErrorInvalidValue;   // (32-bit words: long rows only — qg_api.hip keeps short rows on the 64-bit form)
     switch (K) {
     case 16: return launch_gemv_short<16>(g, st);
     case 32: return launch_gemv_short<32>(g, st);

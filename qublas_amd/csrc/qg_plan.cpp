@@ -799,8 +799,8 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     if (!out->tree_fast_ok && !cx && !out->wide && !out->generic_only && d->n_levels <= 16 && T.n_levels_k <= 16) {
         const QStep& pq = T.mul[0].q;
         const int bitsA = 1 + (int)d->a[0].I + (int)d->a[0].F, bitsB = 1 + (int)d->b[0].I + (int)d->b[0].F;
-        bool w32 = !pq.identity && pq.O == QG_SAT_TCPL && pq.S && pq.lo == -((int64_t)1 << 31) && pq.hi == ((int64_t)1 << 31) - 1 && pq.d >= 0 && pq.d <= 31 &&
-                   (pq.d == 0 || pq.Q == QG_TRN_TCPL || pq.Q == QG_RND_POS_INF || pq.Q == QG_RND_NEG_INF) && bitsA <= 32 && bitsB <= 32 &&
+        bool w32 = !pq.identity && pq.O == QG_SAT_TCPL && pq.S && pq.lo == -((int64_t)1 << 31) && pq.hi == ((int64_t)1 << 31) - 1 && pq.d >= 1 && pq.d <= 31 &&   // (d = 0: the kernel's range test of the high half has no form)
+                   (pq.Q == QG_TRN_TCPL || pq.Q == QG_RND_POS_INF || pq.Q == QG_RND_NEG_INF) && bitsA <= 32 && bitsB <= 32 &&
                    (d->a[0].S || bitsA <= 31) && (d->b[0].S || bitsB <= 31);   // (elements are int32 words in the packed operands)
         for (uint32_t l = 0; l < (uint32_t)T.n_levels_k && w32; ++l) {
             const QStep& q = T.level_add[0][l].q;
@@ -852,6 +852,12 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         out->gemv_w32 = w32 ? 1 : 0;
     }
     out->gemv_fixed = out->gemv_w32 ? 6 : 0;   // (6: only with gemv_wide_ok, i.e. never together with the forms below)
+    if (out->gemv_w32 && !out->gemv_b_bit) {    // 7: ... and the product itself is fast_mode 10's "add a constant, shift right, saturate to the word"
+        const QStep& pq = T.mul[0].q;
+        if (!pq.identity && pq.O == QG_SAT_TCPL && pq.S && pq.lo == -((int64_t)1 << 31) && pq.hi == ((int64_t)1 << 31) - 1 && pq.d >= 1 && pq.d <= 31 &&
+            (pq.Q == QG_TRN_TCPL || pq.Q == QG_RND_POS_INF || pq.Q == QG_RND_NEG_INF))
+            out->gemv_fixed = 7;
+    }
     if (out->gemv_ok) {
         // all levels one format (the product's), exact alignment (d == 0), SAT::ZERO or SAT::TCPL
         const qfmt lf = d->level_add[0][0];

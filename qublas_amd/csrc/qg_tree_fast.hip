@@ -331,13 +331,9 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
                             for (int j = 0; j < 2; ++j) {
                                 // all in 32-bit instructions behind the one v_mad_i64_i32 (the compiler turns a 64-bit shift + clamp into
                                 // v_ashrrev_i64 and two v_cmp_*_i64): the word is v_alignbit of the product's halves, and it is in range
-                                // iff the high half lies in [-2^(d-1), 2^(d-1)) — one add, one unsigned compare (1 <= d <= 31)
+                                // iff the high half lies in [-2^(d-1), 2^(d-1)) — one add, one unsigned compare (1 <= d <= 31, qg_plan.cpp; a wave-uniform branch for d = 0 cost 35 % at 2048^3)
                                 const long long p = (long long)av[i] * (long long)bhv[j] + (long long)w_t;
                                 const int ph = (int)(p >> 32);
-                                if (w_d == 0) {   // (wave-uniform; no shift: in range iff the high half is the low half's sign)
-                                    v[i * 2 + j] = ph == ((int)p >> 31) ? (int)p : ((ph >> 31) ^ 0x7fffffff);
-                                    continue;
-                                }
                                 const int ql = (int)__builtin_amdgcn_alignbit((unsigned)ph, (unsigned)p, (unsigned)w_d);
                                 v[i * 2 + j] = (unsigned)ph + w_half < w_lim ? ql : ((ph >> 31) ^ 0x7fffffff);
                             }

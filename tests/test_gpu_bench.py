@@ -100,7 +100,7 @@ def test_single_gpu_line_carries_every_baseline_configuration():
     check_common(j, 1)
     assert j["cpu_baseline"]["value"] and j["cpu_baseline"]["kind"] in ("reference", "port")
     ex = j["extra"]
-    for name, bound in (("c2L", "mfma"), ("c2T", "valu"), ("c3T", "valu"), ("c3Td", "valu"), ("w32T", "valu"), ("c5TF", "valu"), ("c5B", "valu"), ("c5L", "mfma"), ("reduce", "hbm"),
+    for name, bound in (("c2L", "mfma"), ("c2T", "valu"), ("c3T", "valu"), ("c3Td", "valu"), ("w32T", "valu"), ("c5TF", "valu"), ("c5B", "valu"), ("c5L", "mfma"), ("reduce", "hbm"), ("reduceW", "hbm"),
                         ("long_k", "mfma")):
         assert "error" not in ex[name], ex[name]
         r = ex[name]["roofline"]

@@ -193,7 +193,7 @@ def test_one_column_32_bit_words(oracle, K):
     same descriptor takes under QG_OPT_RUNTIME_MODES."""
     from qublas_amd.desc import reduce_result_type
     rows = 333 if K <= 5000 else 21
-    form = "saturating word adds"
+    form = "one 32-bit format, saturating adds"
     for e in (Qu(15, 16), Qu(0, 31), Qu(31, 0)):
         d = lower_reduce(e, rows, K)
         info = capi.classify(d)
@@ -219,7 +219,8 @@ def test_one_column_32_bit_words(oracle, K):
     q = Qu(15, 16)
     for ea, eb, ec, kw in ((q, q, q, {}), (Qu(0, 31), Qu(0, 31), Qu(0, 31), {}),
                            (q, q, Qu(9, 3, True, RND.CONV, SAT.SMGN), dict(mul_args=Qu(15, 16, True, RND.POS_INF, SAT.TCPL), add_args=[q])),
-                           (Qu(8, 12), Qu(4, 8), Qu(20, 11), dict(mul_args=Qu(15, 16, True, RND.CONV, SAT.ZERO), add_args=[q]))):
+                           (Qu(20, 11), Qu(20, 11), Qu(20, 11, True, RND.NEG_INF, SAT.TCPL), dict(mul_args=Qu(20, 11, True, RND.NEG_INF, SAT.TCPL), add_args=[Qu(20, 11)])),
+                           (Qu(8, 12), Qu(4, 8), Qu(20, 11), dict(mul_args=Qu(15, 16, True, RND.CONV, SAT.ZERO), add_args=[q]))):   # (the last: the general product step)
         d = lower(ea, eb, ec, 130, 1, K, **kw)
         info = capi.classify(d)
         assert capi.KERNEL_NAMES[info.kernel] == "gemv_i32" and info.reason.decode().endswith(form), (str(ea), info.reason)

@@ -388,8 +388,13 @@ def test_32_bit_word_tree_form(oracle, K):
              (Qu(8, 12), Qu(4, 8), q, dict(mul_args=Qu(15, 16, True, RND.NEG_INF, SAT.TCPL), add_args=[q])),
              (Qu(20, 11), Qu(20, 11), Qu(20, 11), {}), (Qu(2, 29), Qu(2, 29), Qu(9, 3, True, RND.CONV, SAT.SMGN), {}),
              (Qu(15, 15, False), q, q, dict(mul_args=q, add_args=[q])),
-             (Qu(0, 31), Qu(0, 31), Qu(0, 31), {}), (Qu(30, 1), Qu(30, 1), Qu(30, 1), {}),            # (Q31: product shift 31; shift 1)
-             (Qu(20, 0), Qu(24, 0), Qu(31, 0), dict(mul_args=Qu(31, 0), add_args=[Qu(31, 0)]))]                                                     # (integers: no shift at all)
+             (Qu(0, 31), Qu(0, 31), Qu(0, 31), {}), (Qu(30, 1), Qu(30, 1), Qu(30, 1), {})]            # (Q31: product shift 31; shift 1)
+    # integers (no shift at all) are not this form: the 64-bit tree kernel
+    i20, i24, i31 = Qu(20, 0), Qu(24, 0), Qu(31, 0)
+    d = lower(i20, i24, i31, 33, 17, K, mul_args=i31, add_args=[i31])
+    assert capi.KERNEL_NAMES[capi.classify(d).kernel] == "tree_i64"
+    A, B = oracle.fill(i20, 33 * K, 5, 0), oracle.fill(i24, K * 17, 6, 0)
+    assert np.array_equal(run_gpu(d, A, B, i31, oracle), oracle.gemm(d, A, B, i31, nthreads=8))
     assert capi.KERNEL_NAMES[capi.classify(lower(q, q, Qu(20, 12), 33, 17, K)).kernel] == "tree_i64"     # a C beyond 32 bits: the 64-bit kernel's conversion
     for ea, eb, ec, kw in cases:
         for M, N in ((33, 17), (1, 3), (70, 41)):

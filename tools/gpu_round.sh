@@ -6,7 +6,7 @@
 #          SKIP_TESTS=1: only the profile passes — one gpurun call does not fit the tests and nine workloads)
 set -o pipefail
 TAG=${1:-r01}; shift
-WLS=${@:-c3L c4L c3T c3Td c2T c5TF c5B c5L reduce long_k c2L w16 u8 w32T}
+WLS=${@:-c3L c4L c3T c3Td c2T c5TF c5B c5L reduce long_k c2L w16 u8 w32T reduceW}
 export QG_GIT_HEAD=${QG_GIT_HEAD:-unknown}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
