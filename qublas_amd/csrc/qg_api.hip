@@ -1222,6 +1222,7 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
         static const bool no_lj = QG_DIAG_ENV("QG_NO_LEFT_JUSTIFIED");   // A/B switch (diagnostic library): the form such a descriptor had before
         static const bool no_pk = QG_DIAG_ENV("QG_NO_PACKED16");
         int fm = (p->an.fast_mode >= 6 && p->an.fast_mode <= 9 && no_lj) ? p->an.fast_mode_base : (p->an.fast_mode >= 7 && p->an.fast_mode <= 9 && no_pk) ? 6 : p->an.fast_mode;
+        if (fm == 10 && p->an.tree.lj.s >= 10 && p->an.tree.lj.s <= 23) fm = 11;   // (32-bit words, product shift 10 ... 23: k_tree_fast<., 18>)
         if (fm >= 6 && fm <= 9 && p->an.lj_unsigned) fm += 16;   // (the unsigned counterparts: qg_launch_tree_fast)
         QG_HIP(qg_launch_tree_fast(p->dev_table, p->an.tree.n_levels_k, p->an.split_s, p->an.mul24_ok,
                                    (p->flags & QG_OPT_RUNTIME_MODES) ? 0 : fm, packedA, packedB, packedC,

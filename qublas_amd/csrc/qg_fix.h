@@ -43,6 +43,12 @@ __device__ __forceinline__ int sat_sub(int a, int b)
     asm("v_sub_i32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ int sat_mad24_vsv(int a, int b, int c)   // (b wave-uniform)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ int sat_mad24_vvs(int a, int b, int c)
 {
     int r;

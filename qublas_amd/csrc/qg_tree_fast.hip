@@ -212,7 +212,7 @@ struct QTreeFastArgs {
 //   (the hardware saturates from the full 48-bit product).
 #define NODE(X, L)                                                         \
     do {                                                                   \
-        if (MODE == 17) {                                                  \
+        if (MODE == 17 || MODE == 18) {                                    \
             _Pragma("unroll") for (int o_ = 0; o_ < NOUT; ++o_) v[o_] = sat_add(X[o_], v[o_]);   \
         } else if (MODE == 6 || MODE == 16) {                              \
             _Pragma("unroll") for (int o_ = 0; o_ < NOUT; ++o_) v[o_] = MODE == 16 ? usat_add(X[o_], v[o_]) : sat_add(X[o_], v[o_]);   \
@@ -260,8 +260,10 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
 #pragma unroll
     for (int l = 0; l < 4; ++l) flow[l] = tab->fadd[0][l];
     // MODE 6 (QTreeTable::lj): shift of the justified values, their mask, the product's scaled rounding addend, the operands' factors
-    const int w_d = MODE == 17 ? tab->lj.s : 0, w_t = MODE == 17 ? tab->lj.t[0] : 0;   // MODE 17 (32-bit words): the product's shift and rounding addend
+    constexpr bool W32 = MODE == 17 || MODE == 18;
+    const int w_d = W32 ? tab->lj.s : 0, w_t = W32 ? tab->lj.t[0] : 0;   // MODE 17 / 18 (32-bit words): the product's shift and rounding addend
     unsigned w_half = MODE == 17 ? 1u << ((w_d - 1) & 31) : 0u, w_lim = MODE == 17 ? 1u << (w_d & 31) : 0u;
+    const int w_f = MODE == 18 ? 1 << ((32 - w_d) & 31) : 0;             // MODE 18: 2^(32 - d), the weight of the product's high half in the word
     if (MODE == 17) asm volatile("" : "+s"(w_lim));   // (opaque: the compiler would rewrite "x < 2^d" as a shift and a compare with 0 — one instruction more per product)
     constexpr bool LJ = MODE == 6 || MODE == 16;   // (16: the unsigned counterpart — uint32 range, v_mad_u32_u24 / v_add_u32 ... clamp)
     const int lj_s = LJ ? tab->lj.s : 0, lj_mask = LJ ? (int)(~0u << lj_s) : -1, lj_t = LJ ? tab->lj.t[0] : 0;
@@ -324,7 +326,22 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
                         if (SPLIT) blv[j] = e == 0 ? bl4[j].x : e == 1 ? bl4[j].y : e == 2 ? bl4[j].z : bl4[j].w;
                     }
                     // ---- leaves: 8 quantised products
-                    if (MODE == 17) {   // 32-bit words (fast_mode 10): floor((a b + t) / 2^d) of the exact 64-bit product, saturated to the word
+                    if (MODE == 18) {
+                        // 32-bit words with a product shift of 10 ... 23 (Q15.16: 16): floor(p / 2^d) = hi * 2^(32-d) + (lo >> d), and the clamp
+                        // bit of v_mad_i32_i24 saturates exactly that sum to the word (the hardware clamps the full-width result,
+                        // tools/ubench/sat_semantics.hip).  hi enters as a 24-bit factor: every in-range hi is within 2^(d-1) <= 2^22, and one
+                        // clamped to +-2^23 still carries the sum past the word's range (d <= 23) — 4 instructions per product where the
+                        // range test and select of MODE 17 take 7
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const long long p = (long long)av[i] * (long long)bhv[j] + (long long)w_t;
+                                int ph = (int)(p >> 32);
+                                asm("v_med3_i32 %0, %0, %1, %2" : "+v"(ph) : "s"(-(1 << 23)), "v"((1 << 23) - 1));
+                                v[i * 2 + j] = sat_mad24_vsv(ph, w_f, (int)((unsigned)p >> w_d));
+                            }
+                    } else if (MODE == 17) {   // 32-bit words (fast_mode 10): floor((a b + t) / 2^d) of the exact 64-bit product, saturated to the word
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -724,6 +741,10 @@ hipError_t qg_launch_tree_fast(const QTreeTable* dev_table, int n_levels, int sp
     dim3 grid((unsigned)blocks);
     if (mode == 10) {   // 32-bit words: exact 64-bit products, saturating adds (qg_plan.cpp, fast_mode 10)
         launch_tf<false, false, 17>(n_levels, grid, st, g);
+        return hipGetLastError();
+    }
+    if (mode == 11) {   // ... with a product shift of 10 ... 23 (qg_api.hip reads it from the table): the product's word from one saturating multiply-add
+        launch_tf<false, false, 18>(n_levels, grid, st, g);
         return hipGetLastError();
     }
     if (mode != 0 && !mul24) mode = 0;  // the fixed-mode variants are built for 24-bit multiplies only

@@ -388,7 +388,10 @@ def test_32_bit_word_tree_form(oracle, K):
              (Qu(8, 12), Qu(4, 8), q, dict(mul_args=Qu(15, 16, True, RND.NEG_INF, SAT.TCPL), add_args=[q])),
              (Qu(20, 11), Qu(20, 11), Qu(20, 11), {}), (Qu(2, 29), Qu(2, 29), Qu(9, 3, True, RND.CONV, SAT.SMGN), {}),
              (Qu(15, 15, False), q, q, dict(mul_args=q, add_args=[q])),
-             (Qu(0, 31), Qu(0, 31), Qu(0, 31), {}), (Qu(30, 1), Qu(30, 1), Qu(30, 1), {})]            # (Q31: product shift 31; shift 1)
+             (Qu(0, 31), Qu(0, 31), Qu(0, 31), {}), (Qu(30, 1), Qu(30, 1), Qu(30, 1), {}),            # (Q31: product shift 31; shift 1)
+             # shifts 10 ... 23 take the product's word from one saturating multiply-add (k_tree_fast<., 18>): both ends, and 24 beside them
+             (Qu(21, 10), Qu(21, 10), Qu(21, 10), {}), (Qu(8, 23), Qu(8, 23), Qu(8, 23), {}), (Qu(7, 24), Qu(7, 24), Qu(7, 24), {}),
+             (Qu(8, 23, True, RND.POS_INF, SAT.TCPL), Qu(8, 23), Qu(8, 23, True, RND.NEG_INF, SAT.TCPL), {})]
     # integers (no shift at all) are not this form: the 64-bit tree kernel
     i20, i24, i31 = Qu(20, 0), Qu(24, 0), Qu(31, 0)
     d = lower(i20, i24, i31, 33, 17, K, mul_args=i31, add_args=[i31])
