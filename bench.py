@@ -54,7 +54,7 @@ N_SIMD, LANES, CYCLES_PER_VALU_INSTR = 256 * 4, 64, 4.0
 # vector instructions per MAC that an exact leaf + node of the form cannot go below, counted on the ISA; None: no account
 # (c2T: packed 16-bit halves, per MAC 1/2 multiply-add + 1/2 and + 1/2 add + 1/6 and; c3Td: the same steps unpacked; c5TF: per complex MAC
 #  (3 multiply-adds + 3 and + 2 subtracts + 2 adds + 4/3 and) / 2; c3T: SAT::ZERO, split product 5 + range test and select per leaf and node 3)
-ISA_FLOOR = {"c3T": 8.0, "c2T": 1.67, "c3Td": 3.33, "c5TF": 5.67}
+ISA_FLOOR = {"c3T": 8.0, "c2T": 1.67, "c3Td": 3.33, "c5TF": 5.67, "w32T": 5.0}   # (w32T: v_mad_i64_i32, v_med3, v_lshrrev, v_mad_i32_i24 clamp + one saturating add per node)
 
 
 def parse_args(argv=None):
