@@ -799,7 +799,15 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
     if (!out->tree_fast_ok && !cx && !out->wide && !out->generic_only && d->n_levels <= 16 && T.n_levels_k <= 16) {
         const QStep& pq = T.mul[0].q;
         const int bitsA = 1 + (int)d->a[0].I + (int)d->a[0].F, bitsB = 1 + (int)d->b[0].I + (int)d->b[0].F;
-        bool w32 = !pq.identity && pq.O == QG_SAT_TCPL && pq.S && pq.lo == -((int64_t)1 << 31) && pq.hi == ((int64_t)1 << 31) - 1 && pq.d >= 1 && pq.d <= 31 &&   // (d = 0: the kernel's range test of the high half has no form)
+        // ... and JUSTIFIED WORDS: a signed SAT::TCPL format of Wt < 32 bits (Q11.12: 24-bit words) held as x * 2^sj, sj = 32 - Wt, as
+        // fast_mode 6 holds it, when the product needs a net RIGHT shift dn = d - sj >= 1 (fast_mode 6 needs a left one, and 24-bit
+        // factors): the word is floor((a b + t) / 2^dn) of the same exact 64-bit product with its low sj bits cleared, the nodes
+        // are fast_mode 6's (T.lj.e[0] = sj; k_tree_fast<., 19 / 20>).  Such descriptors ran on the 64-bit tree kernel.
+        int Wt = 1;
+        while (Wt < 33 && pq.S && ((int64_t)1 << (Wt - 1)) <= pq.hi) ++Wt;      // hi = 2^(Wt-1) - 1
+        const int sj = 32 - Wt, dn = pq.d - sj;
+        bool w32 = !pq.identity && pq.O == QG_SAT_TCPL && pq.S && Wt >= 2 && Wt <= 32 && pq.hi == ((int64_t)1 << (Wt - 1)) - 1 && pq.lo == -pq.hi - 1 &&
+                   dn >= 1 && dn <= 31 && pq.d <= 31 &&   // (dn = 0: the kernel's range test of the high half has no form; d <= 31: the rounding addend is an int32)
                    (pq.Q == QG_TRN_TCPL || pq.Q == QG_RND_POS_INF || pq.Q == QG_RND_NEG_INF) && bitsA <= 32 && bitsB <= 32 &&
                    (d->a[0].S || bitsA <= 31) && (d->b[0].S || bitsB <= 31);   // (elements are int32 words in the packed operands)
         for (uint32_t l = 0; l < (uint32_t)T.n_levels_k && w32; ++l) {
@@ -813,7 +821,8 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         w32 = w32 && (cq.identity || (cq.d >= 0 && 1 + (int)d->c[0].I + (int)d->c[0].F <= 32));
         if (w32) {
             memset(&T.lj, 0, sizeof T.lj);
-            T.lj.s = pq.d;                                                                                     // the product's shift
+            T.lj.s = dn;                                                                                       // the product's shift (to the justified word)
+            T.lj.e[0] = sj;                                                                                    // bits below the unit in a word (0: 32-bit formats)
             T.lj.t[0] = pq.d == 0 ? 0 : pq.Q == QG_RND_POS_INF ? (int32_t)((int64_t)1 << (pq.d - 1)) : pq.Q == QG_RND_NEG_INF ? (int32_t)(((int64_t)1 << (pq.d - 1)) - 1) : 0;
             out->tree_fast_ok = 1;
             out->split_s = 0;

@@ -212,8 +212,9 @@ struct QTreeFastArgs {
 //   (the hardware saturates from the full 48-bit product).
 #define NODE(X, L)                                                         \
     do {                                                                   \
-        if (MODE == 17 || MODE == 18) {                                    \
+        if (MODE >= 17 && MODE <= 20) {                                    \
             _Pragma("unroll") for (int o_ = 0; o_ < NOUT; ++o_) v[o_] = sat_add(X[o_], v[o_]);   \
+            if ((MODE == 19 || MODE == 20) && ((L) & 1)) { _Pragma("unroll") for (int o_ = 0; o_ < NOUT; ++o_) v[o_] &= w_mask; }   \
         } else if (MODE == 6 || MODE == 16) {                              \
             _Pragma("unroll") for (int o_ = 0; o_ < NOUT; ++o_) v[o_] = MODE == 16 ? usat_add(X[o_], v[o_]) : sat_add(X[o_], v[o_]);   \
             if ((L) & 1) { _Pragma("unroll") for (int o_ = 0; o_ < NOUT; ++o_) v[o_] &= lj_mask; }               \
@@ -260,11 +261,13 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
 #pragma unroll
     for (int l = 0; l < 4; ++l) flow[l] = tab->fadd[0][l];
     // MODE 6 (QTreeTable::lj): shift of the justified values, their mask, the product's scaled rounding addend, the operands' factors
-    constexpr bool W32 = MODE == 17 || MODE == 18;
-    const int w_d = W32 ? tab->lj.s : 0, w_t = W32 ? tab->lj.t[0] : 0;   // MODE 17 / 18 (32-bit words): the product's shift and rounding addend
-    unsigned w_half = MODE == 17 ? 1u << ((w_d - 1) & 31) : 0u, w_lim = MODE == 17 ? 1u << (w_d & 31) : 0u;
-    const int w_f = MODE == 18 ? 1 << ((32 - w_d) & 31) : 0;             // MODE 18: 2^(32 - d), the weight of the product's high half in the word
-    if (MODE == 17) asm volatile("" : "+s"(w_lim));   // (opaque: the compiler would rewrite "x < 2^d" as a shift and a compare with 0 — one instruction more per product)
+    constexpr bool W32 = MODE >= 17 && MODE <= 20;   // 19 / 20: 17 / 18 on JUSTIFIED words (formats of fewer than 32 bits held as x * 2^sj, qg_plan.cpp)
+    constexpr bool WJ = MODE == 19 || MODE == 20, WCMP = MODE == 17 || MODE == 19, WMAD = MODE == 18 || MODE == 20;
+    const int w_d = W32 ? tab->lj.s : 0, w_t = W32 ? tab->lj.t[0] : 0;   // the product's shift and rounding addend
+    unsigned w_half = WCMP ? 1u << ((w_d - 1) & 31) : 0u, w_lim = WCMP ? 1u << (w_d & 31) : 0u;
+    const int w_f = WMAD ? 1 << ((32 - w_d) & 31) : 0;                   // 2^(32 - d), the weight of the product's high half in the word
+    const int w_j = WJ ? tab->lj.e[0] : 0, w_mask = WJ ? (int)(~0u << w_j) : -1;   // bits below the unit in a justified word, cleared as MODE 6 clears them
+    if (WCMP) asm volatile("" : "+s"(w_lim));   // (opaque: the compiler would rewrite "x < 2^d" as a shift and a compare with 0 — one instruction more per product)
     constexpr bool LJ = MODE == 6 || MODE == 16;   // (16: the unsigned counterpart — uint32 range, v_mad_u32_u24 / v_add_u32 ... clamp)
     const int lj_s = LJ ? tab->lj.s : 0, lj_mask = LJ ? (int)(~0u << lj_s) : -1, lj_t = LJ ? tab->lj.t[0] : 0;
     const int lj_ea = LJ ? tab->lj.e[0] : 0, lj_eb = LJ ? tab->lj.e[1] : 0;
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
                         if (SPLIT) blv[j] = e == 0 ? bl4[j].x : e == 1 ? bl4[j].y : e == 2 ? bl4[j].z : bl4[j].w;
                     }
                     // ---- leaves: 8 quantised products
-                    if (MODE == 18) {
+                    if (WMAD) {
                         // 32-bit words with a product shift of 10 ... 23 (Q15.16: 16): floor(p / 2^d) = hi * 2^(32-d) + (lo >> d), and the clamp
                         // bit of v_mad_i32_i24 saturates exactly that sum to the word (the hardware clamps the full-width result,
                         // tools/ubench/sat_semantics.hip).  hi enters as a 24-bit factor: every in-range hi is within 2^(d-1) <= 2^22, and one
@@ -339,9 +342,9 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
                                 const long long p = (long long)av[i] * (long long)bhv[j] + (long long)w_t;
                                 int ph = (int)(p >> 32);
                                 asm("v_med3_i32 %0, %0, %1, %2" : "+v"(ph) : "s"(-(1 << 23)), "v"((1 << 23) - 1));
-                                v[i * 2 + j] = sat_mad24_vsv(ph, w_f, (int)((unsigned)p >> w_d));
+                                v[i * 2 + j] = sat_mad24_vsv(ph, w_f, (int)((unsigned)p >> w_d)) & w_mask;   // (w_mask: -1 unless justified — folded away)
                             }
-                    } else if (MODE == 17) {   // 32-bit words (fast_mode 10): floor((a b + t) / 2^d) of the exact 64-bit product, saturated to the word
+                    } else if (WCMP) {   // 32-bit words (fast_mode 10): floor((a b + t) / 2^d) of the exact 64-bit product, saturated to the word
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
                                 const long long p = (long long)av[i] * (long long)bhv[j] + (long long)w_t;
                                 const int ph = (int)(p >> 32);
                                 const int ql = (int)__builtin_amdgcn_alignbit((unsigned)ph, (unsigned)p, (unsigned)w_d);
-                                v[i * 2 + j] = (unsigned)ph + w_half < w_lim ? ql : ((ph >> 31) ^ 0x7fffffff);
+                                v[i * 2 + j] = ((unsigned)ph + w_half < w_lim ? ql : ((ph >> 31) ^ 0x7fffffff)) & w_mask;
                             }
                     } else if (LJ) {
 #pragma unroll
@@ -507,6 +510,10 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
     if (LJ) {   // floor(v / 2^s): the value
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) v[o] = MODE == 16 ? (int)((unsigned)v[o] >> lj_s) : v[o] >> lj_s;
+    }
+    if (WJ) {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) v[o] >>= w_j;
     }
     step_all(v, tab->c_cvt[0]);
 #pragma unroll
@@ -741,6 +748,11 @@ hipError_t qg_launch_tree_fast(const QTreeTable* dev_table, int n_levels, int sp
     dim3 grid((unsigned)blocks);
     if (mode == 10) {   // 32-bit words: exact 64-bit products, saturating adds (qg_plan.cpp, fast_mode 10)
         launch_tf<false, false, 17>(n_levels, grid, st, g);
+        return hipGetLastError();
+    }
+    if (mode == 12 || mode == 13) {   // ... on justified words (formats of fewer than 32 bits): 12 the compare form, 13 the multiply-add form
+        if (mode == 12) launch_tf<false, false, 19>(n_levels, grid, st, g);
+        else launch_tf<false, false, 20>(n_levels, grid, st, g);
         return hipGetLastError();
     }
     if (mode == 11) {   // ... with a product shift of 10 ... 23 (qg_api.hip reads it from the table): the product's word from one saturating multiply-add

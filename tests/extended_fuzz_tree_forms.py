@@ -45,8 +45,8 @@ def main():
         mul = None if r < 0.35 else rq(rng, rng.choice([8, 12, 16, 20])) if r < 0.8 else Tags(intBits=ea.intBits + rng.randint(0, 5), fracBits=ea.fracBits + rng.randint(-3, 3))
         levels = [rq(rng, rng.choice([10, 14, 18, 22, 26])) for _ in range(rng.choice([0, 1, 1, 2, 3]))]
         if rng.random() < 0.2:   # one signed SAT::TCPL format for the product and every level: the left-justified saturating form
-            u = rq(rng, rng.choice([3, 5, 7, 9, 11, 12, 14, 15, 15, 16, 20, 31, 31]), True)   # (value bits; 15 + sign: 16-bit words; 31 + sign: 32-bit words)
-            if u.intBits + u.fracBits == 31 and rng.random() < 0.6:
+            u = rq(rng, rng.choice([3, 5, 7, 9, 11, 12, 14, 15, 15, 16, 20, 23, 23, 25, 27, 30, 31, 31]), True)   # (value bits; 15 + sign: 16-bit words; 31 + sign: 32-bit words)
+            if u.intBits + u.fracBits >= 23 and rng.random() < 0.6:     # (32-bit words and justified words: elements of up to 32 bits)
                 ea = rq(rng, rng.choice([12, 16, 24, 31]), True)
                 eb = ea if rng.random() < 0.5 else rq(rng, rng.choice([7, 16, 31]), True)
             if rng.random() < 0.5:   # narrow operands too: the packed 16-bit form needs format bits + the product's shift <= 16

@@ -377,6 +377,33 @@ def test_reference_artefacts_flag_on_the_device(oracle):
         assert capi.classify_status(lower(e, e, u32, M, N, K, mul_args=Tags(25, 8), add_args=[Qu(40, 8)]))[0] == capi.QG_EUNSUPPORTED
 
 
+@pytest.mark.parametrize("K", [1, 5, 33, 100, 1000, 4096])
+def test_justified_word_tree_form(oracle, K):
+    """Default tags on words of fewer than 32 bits whose product needs a net right shift (Q11.12, the 24-bit words of much
+    fixed-point code; Q13.12; Q14.16; Q3.20): held as x * 2^(32 - bits), the product's word out of the exact 64-bit product (compare
+    form for net shifts 1 ... 9 and 24 ... 31, one saturating multiply-add for 10 ... 23), low bits cleared, a node one saturating
+    add (`k_tree_fast<., 19 / 20>`).  They ran on the 64-bit tree kernel, which is the second opinion here."""
+    cases = [(Qu(11, 12), Qu(11, 12), Qu(11, 12), {}), (Qu(13, 12), Qu(13, 12), Qu(13, 12), {}), (Qu(14, 16), Qu(14, 16), Qu(14, 16), {}),
+             (Qu(3, 20), Qu(3, 20), Qu(3, 20), {}), (Qu(1, 29), Qu(1, 29), Qu(1, 29), {}),
+             (Qu(11, 12, True, RND.POS_INF, SAT.TCPL), Qu(11, 12, True, RND.POS_INF, SAT.TCPL), Qu(8, 4, True, RND.CONV, SAT.SMGN), {}),
+             (Qu(15, 16), Qu(7, 8), Qu(11, 12), dict(mul_args=Qu(11, 12, True, RND.NEG_INF, SAT.TCPL), add_args=[Qu(11, 12)])),
+             (Qu(15, 15, False), Qu(14, 16), Qu(14, 16), dict(mul_args=Qu(14, 16), add_args=[Qu(14, 16)]))]
+    for ea, eb, ec, kw in cases:
+        for M, N in ((33, 17), (1, 3), (70, 41)):
+            d = lower(ea, eb, ec, M, N, K, **kw)
+            info = capi.classify(d)
+            assert capi.KERNEL_NAMES[info.kernel] == "tree_i32" and info.reason.decode().endswith("justified words"), (str(ea), info.reason)
+            assert capi.KERNEL_NAMES[capi.classify(d, capi.OPT_RUNTIME_MODES).kernel] == "tree_i64"
+            for dist in (0, 1, 2):
+                A, B = oracle.fill(ea, M * K, 5, dist % 2), oracle.fill(eb, K * N, 6, dist % 2)
+                if dist == 2:
+                    A, B = (A >> 7).astype(A.dtype), (B >> 7).astype(B.dtype)
+                got = run_gpu(d, A, B, ec, oracle)
+                exp = oracle.gemm(d, A, B, ec, nthreads=8)
+                assert np.array_equal(got, exp), (str(ea), M, N, K, dist)
+                assert np.array_equal(run_gpu(d, A, B, ec, oracle, flags=capi.OPT_RUNTIME_MODES), exp)
+
+
 @pytest.mark.parametrize("K", [1, 2, 5, 32, 33, 100, 1000, 4096])
 def test_32_bit_word_tree_form(oracle, K):
     """Q15.16 with default tags — every product and every tree node quantised into the 32-bit word — and relatives: the product

@@ -6,9 +6,8 @@ from qublas_amd import capi  # noqa: E402
 from qublas_amd.desc import Qu, lower  # noqa: E402
 
 def main():
-    q = Qu(15, 16)
     with capi.Context(0) as ctx:
-        for S in (1024, 2048):
+        for q, S in ((Qu(15, 16), 1024), (Qu(15, 16), 2048), (Qu(11, 12), 2048), (Qu(14, 16), 2048)):   # (the last two: justified words)
             d = lower(q, q, q, S, S, S)
             plan = capi.Plan(ctx, d)
             pb = plan.info.packed_bytes
@@ -17,7 +16,7 @@ def main():
             plan.fill(capi.OPERAND_B, 2, 0, pB)
             plan.time_execute(pC, pA, pB, 1, 3)
             ms = plan.time_execute(pC, pA, pB, 1, 5)
-            print(json.dumps({"case": f"Q15.16 default tags {S}^3", "kernel": capi.KERNEL_NAMES[plan.info.kernel], "reason": plan.info.reason.decode(), "ms": round(ms, 4),
+            print(json.dumps({"case": f"Q{q.intBits}.{q.fracBits} default tags {S}^3", "kernel": capi.KERNEL_NAMES[plan.info.kernel], "reason": plan.info.reason.decode(), "ms": round(ms, 4),
                               "instr_slots_per_mac_at_2.4GHz": round(ms * 1e-3 * 39.3e12 / S ** 3, 1)}), flush=True)
             for p in (pA, pB, pC):
                 ctx.free(p)
