@@ -376,7 +376,7 @@ static int plan_geometry(const qgemul_desc* d, uint32_t flags, QAnalysis* an, qg
     if (kernel == QG_KERNEL_TREE_I32) {
         const int fm = (flags & QG_OPT_RUNTIME_MODES) ? 0 : an->fast_mode;
         snprintf(info->reason, sizeof info->reason, "exact tree evaluation; tree kernel steps: %s",
-                 fm == 10 ? (an->tree.lj.e[0] > 0 ? "one format, SAT::TCPL, justified words" : "one 32-bit format, SAT::TCPL, saturating word adds") : fm >= 8 ? "one format, SAT::TCPL, left-justified, packed nodes" : fm == 7 ? "one format, SAT::TCPL, left-justified, packed 16-bit" : fm == 6 ? "one format, SAT::TCPL, left-justified" : fm == 1 ? "one format, SAT::ZERO" : fm == 2 ? "one format, SAT::TCPL" : fm == 3 ? "per-level formats, compact (clamps)" : fm == 4 ? "per-level formats, compact" : fm == 5 ? "per-level formats, compact (unbiased)" : "run-time modes");
+                 fm == 10 ? (an->tree.lj.e[1] ? "one 32-bit format, WRP::TCPL, wrapping word adds" : an->tree.lj.e[0] > 0 ? "one format, SAT::TCPL, justified words" : "one 32-bit format, SAT::TCPL, saturating word adds") : fm >= 8 ? "one format, SAT::TCPL, left-justified, packed nodes" : fm == 7 ? "one format, SAT::TCPL, left-justified, packed 16-bit" : fm == 6 ? "one format, SAT::TCPL, left-justified" : fm == 1 ? "one format, SAT::ZERO" : fm == 2 ? "one format, SAT::TCPL" : fm == 3 ? "per-level formats, compact (clamps)" : fm == 4 ? "per-level formats, compact" : fm == 5 ? "per-level formats, compact (unbiased)" : "run-time modes");
     }
     if (kernel == QG_KERNEL_GEMV_I64)
         snprintf(info->reason, sizeof info->reason, "exact tree evaluation; one-column kernel steps: run-time modes, 64-bit values");
@@ -1224,7 +1224,7 @@ static int execute_kernel(qgemul_plan* p, void* packedC, const void* packedA, co
         int fm = (p->an.fast_mode >= 6 && p->an.fast_mode <= 9 && no_lj) ? p->an.fast_mode_base : (p->an.fast_mode >= 7 && p->an.fast_mode <= 9 && no_pk) ? 6 : p->an.fast_mode;
         if (fm == 10) {   // 32-bit words: product shift 10 ... 23 -> k_tree_fast<., 18>; justified words (lj.e[0] > 0) -> <., 19 / 20>
             const bool mad = p->an.tree.lj.s >= 10 && p->an.tree.lj.s <= 23;
-            fm = p->an.tree.lj.e[0] > 0 ? (mad ? 13 : 12) : (mad ? 11 : 10);
+            fm = p->an.tree.lj.e[1] ? 14 : p->an.tree.lj.e[0] > 0 ? (mad ? 13 : 12) : (mad ? 11 : 10);   // (14: a wrapping word, k_tree_fast<., 21>)
         }
         if (fm >= 6 && fm <= 9 && p->an.lj_unsigned) fm += 16;   // (the unsigned counterparts: qg_launch_tree_fast)
         QG_HIP(qg_launch_tree_fast(p->dev_table, p->an.tree.n_levels_k, p->an.split_s, p->an.mul24_ok,

@@ -819,6 +819,28 @@ void qg_analyze(const qgemul_desc* d, QAnalysis* out)
         // the root is converted into C by the kernel's 32-bit step: C's bounds must be words too, and no left shift
         const QStep& cq = T.c_cvt[0];
         w32 = w32 && (cq.identity || (cq.d >= 0 && 1 + (int)d->c[0].I + (int)d->c[0].F <= 32));
+        // ... and WRAPPING words: the same frame for a signed WRP::TCPL format of exactly 32 bits (T.lj.e[1] = 1; k_tree_fast<., 21>) — the
+        // product's word is the low 32 bits of floor((a b + t) / 2^d), 0 <= d <= 31, a node a plain 32-bit add
+        bool wrap32 = !w32 && !pq.identity && pq.O == QG_WRP_TCPL && pq.S && pq.W == 31 && pq.d >= 0 && pq.d <= 31 &&
+                      (pq.d == 0 || pq.Q == QG_TRN_TCPL || pq.Q == QG_RND_POS_INF || pq.Q == QG_RND_NEG_INF) && bitsA <= 32 && bitsB <= 32 &&
+                      (d->a[0].S || bitsA <= 31) && (d->b[0].S || bitsB <= 31);
+        for (uint32_t l = 0; l < (uint32_t)T.n_levels_k && wrap32; ++l) {
+            const QStep& q = T.level_add[0][l].q;
+            const bool pad = (int)l >= T.n_levels && q.identity;
+            wrap32 = T.level_cvt[0][l].identity && T.level_add[0][l].sa == 0 && T.level_add[0][l].sb == 0 &&
+                     (pad || (!q.identity && q.O == QG_WRP_TCPL && q.S && q.W == 31 && q.d == 0));
+        }
+        wrap32 = wrap32 && (cq.identity || (cq.d >= 0 && 1 + (int)d->c[0].I + (int)d->c[0].F <= 32));
+        if (wrap32) {
+            memset(&T.lj, 0, sizeof T.lj);
+            T.lj.s = pq.d;
+            T.lj.e[1] = 1;
+            T.lj.t[0] = pq.d == 0 ? 0 : pq.Q == QG_RND_POS_INF ? (int32_t)((int64_t)1 << (pq.d - 1)) : pq.Q == QG_RND_NEG_INF ? (int32_t)(((int64_t)1 << (pq.d - 1)) - 1) : 0;
+            out->tree_fast_ok = 1;
+            out->split_s = 0;
+            out->mul24_ok = 0;
+            out->fast_mode = out->fast_mode_base = 10;
+        }
         if (w32) {
             memset(&T.lj, 0, sizeof T.lj);
             T.lj.s = dn;                                                                                       // the product's shift (to the justified word)

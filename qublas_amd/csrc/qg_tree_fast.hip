@@ -212,7 +212,9 @@ struct QTreeFastArgs {
 //   (the hardware saturates from the full 48-bit product).
 #define NODE(X, L)                                                         \
     do {                                                                   \
-        if (MODE >= 17 && MODE <= 20) {                                    \
+        if (MODE == 21) {                                                  \
+            _Pragma("unroll") for (int o_ = 0; o_ < NOUT; ++o_) v[o_] = (int)((unsigned)X[o_] + (unsigned)v[o_]);   \
+        } else if (MODE >= 17 && MODE <= 20) {                             \
             _Pragma("unroll") for (int o_ = 0; o_ < NOUT; ++o_) v[o_] = sat_add(X[o_], v[o_]);   \
             if ((MODE == 19 || MODE == 20) && ((L) & 1)) { _Pragma("unroll") for (int o_ = 0; o_ < NOUT; ++o_) v[o_] &= w_mask; }   \
         } else if (MODE == 6 || MODE == 16) {                              \
@@ -261,7 +263,9 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
 #pragma unroll
     for (int l = 0; l < 4; ++l) flow[l] = tab->fadd[0][l];
     // MODE 6 (QTreeTable::lj): shift of the justified values, their mask, the product's scaled rounding addend, the operands' factors
-    constexpr bool W32 = MODE >= 17 && MODE <= 20;   // 19 / 20: 17 / 18 on JUSTIFIED words (formats of fewer than 32 bits held as x * 2^sj, qg_plan.cpp)
+    // 21: a WRAPPING 32-bit word (signed WRP::TCPL — what `(int32_t)(((int64_t)a * b) >> 16)` and a plain `+=` compute): the word is
+    // v_alignbit of the exact product's halves and a node a plain 32-bit add, nothing is tested or selected
+    constexpr bool W32 = MODE >= 17 && MODE <= 21;   // 19 / 20: 17 / 18 on JUSTIFIED words (formats of fewer than 32 bits held as x * 2^sj, qg_plan.cpp)
     constexpr bool WJ = MODE == 19 || MODE == 20, WCMP = MODE == 17 || MODE == 19, WMAD = MODE == 18 || MODE == 20;
     const int w_d = W32 ? tab->lj.s : 0, w_t = W32 ? tab->lj.t[0] : 0;   // the product's shift and rounding addend
     unsigned w_half = WCMP ? 1u << ((w_d - 1) & 31) : 0u, w_lim = WCMP ? 1u << (w_d & 31) : 0u;
@@ -329,7 +333,15 @@ __global__ __launch_bounds__(256) void k_tree_fast(QTreeFastArgs g)
                         if (SPLIT) blv[j] = e == 0 ? bl4[j].x : e == 1 ? bl4[j].y : e == 2 ? bl4[j].z : bl4[j].w;
                     }
                     // ---- leaves: 8 quantised products
-                    if (WMAD) {
+                    if (MODE == 21) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const long long p = (long long)av[i] * (long long)bhv[j] + (long long)w_t;
+                                v[i * 2 + j] = (int)__builtin_amdgcn_alignbit((unsigned)(p >> 32), (unsigned)p, (unsigned)w_d);
+                            }
+                    } else if (WMAD) {
                         // 32-bit words with a product shift of 10 ... 23 (Q15.16: 16): floor(p / 2^d) = hi * 2^(32-d) + (lo >> d), and the clamp
                         // bit of v_mad_i32_i24 saturates exactly that sum to the word (the hardware clamps the full-width result,
                         // tools/ubench/sat_semantics.hip).  hi enters as a 24-bit factor: every in-range hi is within 2^(d-1) <= 2^22, and one
@@ -748,6 +760,10 @@ hipError_t qg_launch_tree_fast(const QTreeTable* dev_table, int n_levels, int sp
     dim3 grid((unsigned)blocks);
     if (mode == 10) {   // 32-bit words: exact 64-bit products, saturating adds (qg_plan.cpp, fast_mode 10)
         launch_tf<false, false, 17>(n_levels, grid, st, g);
+        return hipGetLastError();
+    }
+    if (mode == 14) {   // a wrapping 32-bit word (signed WRP::TCPL)
+        launch_tf<false, false, 21>(n_levels, grid, st, g);
         return hipGetLastError();
     }
     if (mode == 12 || mode == 13) {   // ... on justified words (formats of fewer than 32 bits): 12 the compare form, 13 the multiply-add form

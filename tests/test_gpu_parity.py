@@ -377,6 +377,34 @@ def test_reference_artefacts_flag_on_the_device(oracle):
         assert capi.classify_status(lower(e, e, u32, M, N, K, mul_args=Tags(25, 8), add_args=[Qu(40, 8)]))[0] == capi.QG_EUNSUPPORTED
 
 
+@pytest.mark.parametrize("K", [1, 2, 33, 100, 1000, 4096])
+def test_wrapping_32_bit_word_tree_form(oracle, K):
+    """A signed WRP::TCPL format of exactly 32 bits with default tags — what `(int32_t)(((int64_t)a * b) >> 16)` and a plain `+=`
+    compute: the product's word is the low 32 bits of the shifted exact product (`v_alignbit_b32`), a node a plain 32-bit add
+    (`k_tree_fast<., 21>`).  Full-range operands (everything wraps) and small ones, truncating and rounding products, shifts
+    16 / 31 / 4 / 28, against the oracle and against the 64-bit tree kernel."""
+    w = Qu(15, 16, True, TRN.TCPL, WRP.TCPL)
+    w31 = Qu(0, 31, True, RND.NEG_INF, WRP.TCPL)
+    cases = [(w, w, w, {}), (w31, w31, w31, {}),
+             (Qu(15, 16), Qu(15, 16), Qu(20, 4), dict(mul_args=Qu(15, 16, True, RND.POS_INF, WRP.TCPL), add_args=[w])),
+             (Qu(8, 12), Qu(4, 8), w, dict(mul_args=w, add_args=[w])),
+             (Qu(20, 11, True, TRN.TCPL, WRP.TCPL), Qu(3, 28), Qu(20, 11, True, TRN.TCPL, WRP.TCPL), dict(mul_args=Qu(20, 11, True, TRN.TCPL, WRP.TCPL)))]
+    for ea, eb, ec, kw in cases:
+        for M, N in ((33, 17), (1, 3), (70, 41)):
+            d = lower(ea, eb, ec, M, N, K, **kw)
+            info = capi.classify(d)
+            assert capi.KERNEL_NAMES[info.kernel] == "tree_i32" and info.reason.decode().endswith("wrapping word adds"), (str(ea), info.reason)
+            assert capi.KERNEL_NAMES[capi.classify(d, capi.OPT_RUNTIME_MODES).kernel] == "tree_i64"
+            for dist in (0, 1, 2):
+                A, B = oracle.fill(ea, M * K, 5, dist % 2), oracle.fill(eb, K * N, 6, dist % 2)
+                if dist == 2:
+                    A, B = (A >> 9).astype(A.dtype), (B >> 9).astype(B.dtype)
+                got = run_gpu(d, A, B, ec, oracle)
+                exp = oracle.gemm(d, A, B, ec, nthreads=8)
+                assert np.array_equal(got, exp), (str(ea), M, N, K, dist)
+                assert np.array_equal(run_gpu(d, A, B, ec, oracle, flags=capi.OPT_RUNTIME_MODES), exp)
+
+
 @pytest.mark.parametrize("K", [1, 5, 33, 100, 1000, 4096])
 def test_justified_word_tree_form(oracle, K):
     """Default tags on words of fewer than 32 bits whose product needs a net right shift (Q11.12, the 24-bit words of much

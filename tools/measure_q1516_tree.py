@@ -7,7 +7,7 @@ from qublas_amd.desc import Qu, lower  # noqa: E402
 
 def main():
     with capi.Context(0) as ctx:
-        for q, S in ((Qu(15, 16), 1024), (Qu(15, 16), 2048), (Qu(11, 12), 2048), (Qu(14, 16), 2048)):   # (the last two: justified words)
+        for q, S in ((Qu(15, 16), 1024), (Qu(15, 16), 2048), (Qu(11, 12), 2048), (Qu(14, 16), 2048), (Qu(15, 16, True, 5, 3), 2048)):   # (the last two: justified words)
             d = lower(q, q, q, S, S, S)
             plan = capi.Plan(ctx, d)
             pb = plan.info.packed_bytes
