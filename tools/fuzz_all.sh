@@ -18,4 +18,5 @@ run tests/extended_fuzz_cplx_eltwise.py 600 $SEED
 run tests/extended_fuzz_pingpong.py 600 $SEED
 run tests/extended_fuzz_misc.py 3 $SEED
 run tests/extended_fuzz_wide.py 900 $SEED
+run tests/extended_fuzz_words.py 1500 $SEED
 cat $OUT
